@@ -1,0 +1,128 @@
+"""Generate tests/golden/*.npz from the REAL reference.  TEST INFRASTRUCTURE ONLY.
+
+Run in the build container only:  ``python -m oracle.gen_golden``  (needs /root/reference).
+Every fixture is *data*: inputs are re-derived from ``oracle/portable.py`` seeds, the file keeps the
+reference's outputs for one teacher-forced pretext step (free-running trajectories
+are chaotic, so each "step" is its own seeded pre-step state with non-zero SGD momentum buffers,
+non-zero queue_ptr and non-trivial BN running stats).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+from typing import Dict
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import portable as P  # noqa: E402
+
+# (arch, B per rank, H=W, K, world sizes, seeds)
+CASES = [
+    ("c3d", 4, 32, 64, (1, 2), (1, 2)),
+    ("resnet18", 8, 64, 64, (1, 2), (1,)),
+    ("r2plus1d-vcop", 4, 32, 64, (1, 2), (1,)),
+    ("s3dg", 4, 64, 64, (1, 2), (1,)),
+]
+LR = 0.05
+SPEED = 2
+T_IN = 32
+
+
+def case_name(arch, ws, seed):
+    return f"{arch.replace('-', '_')}_ws{ws}_s{seed}"
+
+
+def case_inputs(spec, arch, B, HW, K, ws, seed):
+    """Everything a consumer needs to replay the step: state, momentum, clips, permutations."""
+    state = P.fill_state(spec, seed)
+    state["queue_ptr"][:] = (B * ws * (seed % 3 + 1)) % K
+    tk = [k for k in spec if k.startswith("encoder_q.") and not k.endswith(
+        ("running_mean", "running_var", "num_batches_tracked"))]
+    mom = P.fill_momentum([(k, spec[k][0]) for k in tk], seed)
+    clips = [P.clips(seed, r, (B, 3, T_IN, HW, HW)) for r in range(ws)]
+    perms_B = [P.permutation(f"perm:{r}", seed, B) for r in range(ws)]
+    sh = (P.permutation("shuffle1", seed, B * ws), P.permutation("shuffle2", seed, B * ws))
+    return state, mom, clips, perms_B, sh
+
+
+def pack(res: Dict, rank: int, out: Dict[str, np.ndarray]):
+    pre = f"r{rank}."
+    for k in ("loss", "loss_A", "loss_M", "logits1", "logits2", "l_pos_M", "l_neg_M", "q_A", "q_M",
+              "k_A_shuf", "k_M_shuf", "kneg_A_shuf", "kneg_M_shuf"):
+        out[pre + k] = np.asarray(res[k])
+    out[pre + "post.queue"] = res["post_state"]["queue"]
+    out[pre + "post.queue_ptr"] = res["post_state"]["queue_ptr"]
+    for k, v in res["post_state"].items():
+        if k in ("queue", "queue_ptr"):
+            continue
+        if k.endswith("num_batches_tracked"):
+            out[pre + "post." + k] = np.asarray(v)
+        else:
+            out[pre + "postsum." + k] = P.summarise(k, v)
+    for k, g in res["grads"].items():
+        out[pre + "gradsum." + k] = np.zeros(0) if g is None else P.summarise(k, g)
+    for k, v in res["momentum_post"].items():
+        out[pre + "momsum." + k] = P.summarise(k, v)
+
+
+def _worker(rank, ws, arch, B, HW, K, seed, port, tmpdir):
+    import torch
+    from oracle import ref_harness as R
+    torch.set_num_threads(max(1, 8 // ws))
+    R.ensure_process_group(rank, ws, port)
+    model = R.build_reference_model(arch, K=K)
+    spec = R.state_spec(model)
+    state, mom, clips, perms_B, sh = case_inputs(spec, arch, B, HW, K, ws, seed)
+    res = R.run_reference_step(model, state, clips[rank][0], clips[rank][1], [perms_B[rank], sh[0], sh[1]],
+                               SPEED, lr=LR, momentum_buffers=mom, ddp=(ws > 1))
+    out: Dict[str, np.ndarray] = {}
+    pack(res, rank, out)
+    np.savez(os.path.join(tmpdir, f"r{rank}.npz"), **out)
+    if rank == 0:
+        with open(os.path.join(tmpdir, "spec.json"), "w") as f:
+            json.dump({k: [list(s), d] for k, (s, d) in spec.items()}, f)
+
+
+def run_case(arch, B, HW, K, ws, seed):
+    import torch.multiprocessing as mp
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        port = _free_port()
+        mp.spawn(_worker, args=(ws, arch, B, HW, K, seed, port, tmp), nprocs=ws, join=True)
+        out: Dict[str, np.ndarray] = {}
+        for r in range(ws):
+            with np.load(os.path.join(tmp, f"r{r}.npz")) as z:
+                out.update({k: z[k] for k in z.files})
+        with open(os.path.join(tmp, "spec.json")) as f:
+            spec = json.load(f)
+    out["meta"] = np.array(json.dumps(dict(arch=arch, B=B, HW=HW, K=K, ws=ws, seed=seed, lr=LR, speed=SPEED,
+                                           T_in=T_IN, m=0.999, T=0.07, sgd_momentum=0.9, weight_decay=1e-4,
+                                           margin=2.0, A=1.0, M=1.0)))
+    return out, spec
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    only = sys.argv[1:] or None
+    for arch, B, HW, K, wss, seeds in CASES:
+        if only and arch not in only:
+            continue
+        for ws in wss:
+            for seed in seeds:
+                out, spec = run_case(arch, B, HW, K, ws, seed)
+                name = case_name(arch, ws, seed)
+                np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+                with open(os.path.join(GOLDEN, f"state_spec_{arch.replace('-', '_')}.json"), "w") as f:
+                    json.dump(spec, f, indent=0)
+                print("wrote", name, "loss", out["r0.loss"], flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""Drive the REAL reference (/root/reference) on CPU to pin the oracle.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the build container (the reference tree does not exist on the GPU box).  Used by
+``oracle/gen_golden.py`` to produce the committed fixtures under ``tests/golden/`` and by
+``tests/test_oracle_vs_reference.py`` (skipped when /root/reference is absent).
+
+Harness-side shims (no reference edits):
+  1. ``pyhocon`` stub in ``sys.modules``         (moco/__init__.py:3, models/__init__.py:6 import it)
+  2. ``torch.Tensor.cuda`` → identity            (builder_diffspeed_diffloss.py:375 on a CPU-only box)
+  3. ``ranking_target.view(-1, 1)`` for ``Loss`` (torch ≥ 1.10 shape check; same value/grad, a14)
+RNG (``torch.randperm`` ×3 per forward, ``random.choice``) is replayed from caller-supplied values.
+"""
+from __future__ import annotations
+
+import os
+import random
+import socket
+import sys
+import types
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "moco"))
+
+
+def _install_shims():
+    if "pyhocon" not in sys.modules:
+        stub = types.ModuleType("pyhocon")
+
+        class ConfigTree(dict):
+            def get_string(self, k, default=None):
+                return self.get(k, default)
+
+            def get_int(self, k, default=None):
+                return self.get(k, default)
+
+            def get_bool(self, k, default=None):
+                return self.get(k, default)
+
+        class ConfigFactory:
+            @staticmethod
+            def from_dict(d):
+                return ConfigTree(d)
+
+        stub.ConfigTree = ConfigTree
+        stub.ConfigFactory = ConfigFactory
+        sys.modules["pyhocon"] = stub
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    if not torch.cuda.is_available():
+        torch.Tensor.cuda = lambda self, *a, **k: self  # shim 2
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def ensure_process_group(rank: int = 0, world_size: int = 1, port: Optional[int] = None):
+    if dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port or _free_port())
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+
+
+def build_reference_model(arch: str, dim=128, K=64, m=0.999, T=0.07, diff_speed=(2,), fc_type="linear"):
+    """Exactly what moco/__init__.py:29-46 does, minus .cuda()/DDP."""
+    _install_shims()
+    from moco.builder_diffspeed_diffloss import MoCoDiffLossTwoFc
+    from moco.split_wrapper import MultiTaskWrapper
+    from models import get_model_class
+
+    base = get_model_class(arch=arch)
+
+    def model_class(num_classes=128):
+        return MultiTaskWrapper(base, num_classes=num_classes, fc_type=fc_type, finetune=False, groups=1)
+
+    return MoCoDiffLossTwoFc(model_class, dim=dim, K=K, m=m, T=T, diff_speed=list(diff_speed))
+
+
+def state_spec(model) -> "OrderedDict[str, tuple]":
+    return OrderedDict((k, (tuple(v.shape), str(v.dtype).replace("torch.", "")))
+                       for k, v in model.state_dict().items())
+
+
+class _ReplayRNG:
+    """Replays torch.randperm / random.choice results in call order and records the requests."""
+
+    def __init__(self, perms: Sequence[np.ndarray], speed: int):
+        self.perms = [torch.from_numpy(np.asarray(p, dtype=np.int64)) for p in perms]
+        self.speed = speed
+        self.calls: List[int] = []
+        self._orig_randperm = torch.randperm
+        self._orig_choice = random.choice
+
+    def __enter__(self):
+        def randperm(n, *a, **k):
+            p = self.perms[len(self.calls)]
+            assert p.numel() == n, (p.numel(), n)
+            self.calls.append(n)
+            return p.clone()
+
+        torch.randperm = randperm
+        random.choice = lambda seq: self.speed
+        return self
+
+    def __exit__(self, *exc):
+        torch.randperm = self._orig_randperm
+        random.choice = self._orig_choice
+
+
+def run_reference_step(model, state: Dict[str, np.ndarray], im_q: np.ndarray, im_k: np.ndarray,
+                       perms: Sequence[np.ndarray], speed: int, *, lr: float, momentum=0.9,
+                       weight_decay=1e-4, momentum_buffers: Optional[Dict[str, np.ndarray]] = None,
+                       margin=2.0, A=1.0, M=1.0, ddp=False) -> Dict[str, np.ndarray]:
+    """One teacher-forced pretext step of the reference from `state`; returns everything golden files pin.
+
+    Mirrors pretrain.py:157-165 (forward, Loss, zero_grad/backward/step with torch.optim.SGD).
+    """
+    _install_shims()
+    from moco.builder_diffspeed_diffloss import Loss
+
+    ensure_process_group()
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+    model.train()
+    net = model
+    if ddp:
+        net = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    names = {id(p): n for n, p in model.named_parameters()}
+    opt = torch.optim.SGD(params, lr=lr, momentum=momentum, dampening=0.0, weight_decay=weight_decay,
+                          nesterov=False)
+    if momentum_buffers is not None:
+        for p in params:
+            n = names[id(p)]
+            if n in momentum_buffers:
+                opt.state[p]["momentum_buffer"] = torch.from_numpy(np.array(momentum_buffers[n]))
+
+    feats = {}
+
+    def hook(tag):
+        def fn(_mod, _inp, out):
+            feats.setdefault(tag, []).append([o.detach().clone() for o in out])
+        return fn
+
+    h1 = model.encoder_q.register_forward_hook(hook("q"))
+    h2 = model.encoder_k.register_forward_hook(hook("k"))
+    crit = Loss(margin=margin, A=A, M=M)
+    with _ReplayRNG(perms, speed):
+        out, tgt, rl, rt = net(torch.from_numpy(im_q), torch.from_numpy(im_k))
+    loss, loss_A, loss_M = crit(out, tgt, rl, rt.view(-1, 1))  # shim 3
+    opt.zero_grad()
+    loss.backward()
+    grads = {names[id(p)]: (None if p.grad is None else p.grad.detach().clone()) for p in params}
+    opt.step()
+    h1.remove()
+    h2.remove()
+
+    res: Dict[str, np.ndarray] = {
+        "loss": loss.detach().numpy(), "loss_A": loss_A.detach().numpy(), "loss_M": loss_M.detach().numpy(),
+        "logits1": out[0].detach().numpy(), "logits2": out[1].detach().numpy(),
+        "l_pos_M": rl[0].detach().numpy(), "l_neg_M": rl[1].detach().numpy(),
+        "labels_A": tgt.numpy(), "labels_M": rt.numpy(),
+        # encoder_k forward order: pass #1 = im_k_negative, pass #2 = im_k (builder…:445,512); these are the
+        # SHUFFLED-order outputs of this rank's encoder_k.
+        "kneg_A_shuf": feats["k"][0][0].numpy(), "kneg_M_shuf": feats["k"][0][1].numpy(),
+        "k_A_shuf": feats["k"][1][0].numpy(), "k_M_shuf": feats["k"][1][1].numpy(),
+        "q_A": feats["q"][0][0].numpy(), "q_M": feats["q"][0][1].numpy(),
+    }
+    post = model.state_dict()
+    res["post_state"] = {k: v.detach().numpy().copy() for k, v in post.items()}
+    res["grads"] = {k: (None if g is None else g.numpy()) for k, g in grads.items()}
+    res["momentum_post"] = {names[id(p)]: opt.state[p]["momentum_buffer"].numpy().copy()
+                            for p in params if "momentum_buffer" in opt.state[p]}
+    return res

@@ -1,0 +1,108 @@
+"""Shared helpers for parity tests: load a golden case, rebuild its inputs, run the oracle restatement."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import portable as P
+from oracle import restatement as S
+from oracle.gen_golden import case_inputs, case_name
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+ALL_CASES = [
+    ("c3d", 1, 1), ("c3d", 1, 2), ("c3d", 2, 1), ("c3d", 2, 2),
+    ("resnet18", 1, 1), ("resnet18", 2, 1),
+    ("r2plus1d-vcop", 1, 1), ("r2plus1d-vcop", 2, 1),
+    ("s3dg", 1, 1), ("s3dg", 2, 1),
+]
+
+
+def load_spec(arch):
+    with open(os.path.join(GOLDEN, f"state_spec_{arch.replace('-', '_')}.json")) as f:
+        raw = json.load(f)
+    return {k: (tuple(s), d) for k, (s, d) in raw.items()}
+
+
+def load_case(arch, ws, seed):
+    z = np.load(os.path.join(GOLDEN, case_name(arch, ws, seed) + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    return z, meta
+
+
+def build_inputs(arch, meta):
+    spec = load_spec(arch)
+    return spec, case_inputs(spec, arch, meta["B"], meta["HW"], meta["K"], meta["ws"], meta["seed"])
+
+
+def rel_err(a, b, floor=1e-5):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+def summary_err(key, mine, golden_summary, null_norm=1e-4):
+    """rel err between summarise(mine) and a golden summary.  Tensors whose reference l2-norm is below
+    `null_norm` are mathematically-zero quantities (e.g. grads of C3D's conv biases, which the following
+    BatchNorm cancels): rounding noise there is not comparable, only its smallness is."""
+    s = P.summarise(key, np.asarray(mine))
+    if golden_summary[0] < null_norm:
+        assert s[0] < 100 * null_norm, (key, s[0])
+        return 0.0
+    return rel_err(s, golden_summary)
+
+
+def run_restatement(arch, meta, inputs):
+    state, mom, clips, perms_B, sh = inputs
+    ws = meta["ws"]
+    states = [{k: torch.from_numpy(v.copy()) for k, v in state.items()} for _ in range(ws)]
+    moms = [{k: torch.from_numpy(v.copy()) for k, v in mom.items()} for _ in range(ws)]
+    outs = S.moco_step(arch, states, [torch.from_numpy(c[0]) for c in clips], [torch.from_numpy(c[1]) for c in clips],
+                       [torch.from_numpy(p) for p in perms_B], (torch.from_numpy(sh[0]), torch.from_numpy(sh[1])),
+                       meta["speed"], K=meta["K"], m=meta["m"], T=meta["T"], margin=meta["margin"], A=meta["A"],
+                       Mw=meta["M"], lr=meta["lr"], sgd_momentum=meta["sgd_momentum"],
+                       weight_decay=meta["weight_decay"], momentum_buffers=moms)
+    return outs, states, moms
+
+
+def compare_to_golden(z, rank, out, post_state, mom_post, tol, tol_grad=None, check=("fwd", "state", "grad")):
+    """Compare one rank's results with the golden file. Returns dict name -> rel err; asserts under tol."""
+    pre = f"r{rank}."
+    errs = {}
+    tol_grad = tol_grad or tol
+    if "fwd" in check:
+        for k in ("loss", "loss_A", "loss_M", "logits1", "logits2", "l_pos_M", "l_neg_M", "q_A", "q_M",
+                  "k_A_shuf", "k_M_shuf", "kneg_A_shuf", "kneg_M_shuf"):
+            if k in out:
+                errs[k] = rel_err(np.asarray(out[k]), z[pre + k])
+                assert errs[k] <= tol, (k, errs[k])
+    if "state" in check:
+        errs["queue"] = rel_err(np.asarray(post_state["queue"]), z[pre + "post.queue"])
+        assert errs["queue"] <= tol, errs["queue"]
+        assert int(np.asarray(post_state["queue_ptr"]).reshape(-1)[0]) == int(z[pre + "post.queue_ptr"][0])
+        worst = ("", 0.0)
+        for name in z.files:
+            if name.startswith(pre + "post.") and name.endswith("num_batches_tracked"):
+                key = name[len(pre + "post."):]
+                assert int(np.asarray(post_state[key])) == int(z[name]), key
+            if name.startswith(pre + "postsum."):
+                key = name[len(pre + "postsum."):]
+                e = rel_err(P.summarise(key, np.asarray(post_state[key])), z[name])
+                if e > worst[1]:
+                    worst = (key, e)
+        errs["post_state"] = worst[1]
+        assert worst[1] <= tol_grad, worst
+    if "grad" in check and mom_post is not None:
+        worst = ("", 0.0)
+        for name in z.files:
+            if name.startswith(pre + "momsum."):
+                key = name[len(pre + "momsum."):]
+                if z[pre + "gradsum." + key].size == 0:
+                    continue                     # never gets a grad: torch.optim.SGD skips it entirely
+                e = summary_err(key, mom_post[key], z[name])
+                if e > worst[1]:
+                    worst = (key, e)
+        errs["momentum_post"] = worst[1]
+        assert worst[1] <= tol_grad, worst
+    return errs
