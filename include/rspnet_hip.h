@@ -1,0 +1,176 @@
+/*
+ * rspnet_hip.h — C ABI of librspnet_hip.so: the MI355X (gfx950) kernels behind RSPNet's pretext hot path.
+ *
+ * The reference (PeihaoChen/RSPNet) has NO native interface: every op on the path is an ATen call made from
+ * Python.  Each entry point below therefore cites the *reference call site* whose ATen op
+ * it replaces; the Python binding a maintainer would add is the ctypes stub shown in INTEGRATION.md (our own
+ * host side, rspnet_amd/_lib.py, is exactly that stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless its type says otherwise; tensors are dense NDHWC
+ *     ("rows" = N*D*H*W positions, channels contiguous, row pitch given by an `ld` argument in floats);
+ *   - weights cross the boundary in the reference's own layout (Cout,Cin,kT,kH,kW) (nn.Conv3d.weight,
+ *     SURVEY.md §A.5) and are re-packed on device by rsp_conv3d_pack_*;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work (no sync, no allocation: graph-capturable);
+ *   - return value: 0 = ok, negative = RSP_E* (see rsp_strerror); nothing is written on a negative return.
+ */
+#ifndef RSPNET_HIP_H
+#define RSPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSP_OK 0
+#define RSP_EINVAL (-1)      /* bad geometry / null pointer / misaligned pointer */
+#define RSP_EWORKSPACE (-2)  /* workspace too small */
+#define RSP_ELAUNCH (-3)     /* hipLaunch error (hipGetLastError text via rsp_last_error) */
+#define RSP_EUNSUPPORTED (-4)
+
+const char* rsp_strerror(int code);
+const char* rsp_last_error(void);
+int rsp_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 3-D convolution (nn.Conv3d, groups=1, dilation=1): models/c3d.py:21-52, models/resnet.py:20-28,131-138,
+ * models/s3dg.py:19-20,48-51,60, models/r2plus1d_vcop.py:54-55,66-67.
+ * x: [N,Di,Hi,Wi,(in_ld)]  y: [N,Do,Ho,Wo,(out_ld)]  with Do = (Di+2pT-kT)/sT+1 ...
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct rsp_conv3d_desc {
+  int32_t N, Di, Hi, Wi, Cin;
+  int32_t Do, Ho, Wo, Cout;
+  int32_t kT, kH, kW;
+  int32_t sT, sH, sW;
+  int32_t pT, pH, pW;
+  int32_t in_ld;   /* floats between consecutive positions of x (>= Cin; lets x be a channel slice) */
+  int32_t out_ld;  /* same for y */
+} rsp_conv3d_desc;
+
+/* Number of floats of the packed forward weight ([Cout][taps][Cin], K padded to a multiple of 4). */
+size_t rsp_conv3d_packed_fwd_elems(const rsp_conv3d_desc* d);
+/* (Cout,Cin,kT,kH,kW) -> forward-packed. */
+int rsp_conv3d_pack_fwd(const rsp_conv3d_desc* d, const float* w_ref, float* w_packed, void* stream);
+
+/* Number of 128-row tiles of the output grid: stat partials are [tiles][Cout][2] (sum, sum of squares of the
+ * bias-free conv output) — consumed by rsp_bn_finalize.  */
+int32_t rsp_conv3d_stat_tiles(const rsp_conv3d_desc* d);
+size_t rsp_conv3d_fwd_workspace(const rsp_conv3d_desc* d);
+/* y = conv(x, w) + bias.  bias and stat_partials may be NULL. */
+int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                   float* stat_partials, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dgrad: dx = conv_transpose(dy, w).  Replaces autograd's conv backward-input for every conv on the path
+ * (loss.backward(), pretrain.py:164).  w_ref in reference layout; packs per stride-parity class into workspace. */
+size_t rsp_conv3d_dgrad_workspace(const rsp_conv3d_desc* d);
+int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_ref, float* dx, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* wgrad: dw (reference layout, overwritten) = sum over positions of dy ⊗ im2col(x); dbias (nullable) = sum dy. */
+size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d);
+int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * BatchNorm3d (train mode) fused with ReLU / residual add / MaxPool3d:
+ * models/c3d.py:22-24 (bn+relu+pool), models/resnet.py:61-77, models/s3dg.py:23,28-33, r2plus1d_vcop.py:59-60,116-123.
+ * ------------------------------------------------------------------------------------------------------- */
+/* Reduce stat partials -> mean (incl. conv bias), invstd; update running stats
+ * (running_var with the unbiased n/(n-1) estimate), as F.batch_norm(training=True) does.
+ * count = number of positions per channel.  scale_shift out: [2][C] = (gamma*invstd, beta - mean*gamma*invstd). */
+size_t rsp_bn_finalize_workspace(int32_t tiles, int32_t C);
+int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int64_t count, const float* conv_bias,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, float* mean_invstd /*[2][C]*/, float* scale_shift /*[2][C]*/, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* Standalone per-channel statistics of y (for convs whose epilogue did not produce partials): writes
+ * [tiles][C][2] partials with tiles = rsp_bn_stat_tiles(rows). */
+int32_t rsp_bn_stat_tiles(int64_t rows);
+int rsp_bn_stats(const float* y, int64_t rows, int32_t C, int32_t ld, float* stat_partials, void* stream);
+
+typedef struct rsp_pool3d_desc {
+  int32_t N, Di, Hi, Wi, C;
+  int32_t Do, Ho, Wo;
+  int32_t kT, kH, kW, sT, sH, sW, pT, pH, pW; /* k=s=1,p=0: no pooling */
+  int32_t in_ld, out_ld, res_ld;
+} rsp_pool3d_desc;
+
+/* out = maxpool(act(scale*y + shift (+ residual))) ; act = ReLU if relu!=0.  residual (nullable) has y's shape. */
+int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
+                        int relu, float* out, void* stream);
+
+/* Backward of the fused block, two launches:
+ *  reduce: per-channel partial sums of dz and dz*xhat (dz = grad at the BN output after pool routing + ReLU mask)
+ *  apply : dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also d(residual) = dz (if dres != NULL),
+ *          dgamma = sum(dz*xhat), dbeta = sum(dz).
+ * The pooled activation is recomputed from y (saved conv output), never stored. */
+size_t rsp_bn_bwd_workspace(const rsp_pool3d_desc* d);
+int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* residual, const float* dout,
+                        const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
+                        float* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Projection heads: AdaptiveAvgPool3d(1) -> Flatten -> Linear x2 -> F.normalize (moco/split_wrapper.py:138-152,163-169)
+ * feat: [B][P][C] (ld = feat_ld).  w1,w2: (dim, C) row-major (nn.Linear.weight), b1,b2: (dim).
+ * out: qa,qm [B][dim] unit-norm; saves pooled [B][C] and raw (pre-normalize) [2][B][dim] for backward.
+ * ------------------------------------------------------------------------------------------------------- */
+int rsp_head_fwd(const float* feat, int32_t B, int32_t P, int32_t C, int32_t feat_ld, const float* w1,
+                 const float* b1, const float* w2, const float* b2, int32_t dim, float* out1, float* out2,
+                 float* pooled, float* raw, void* stream);
+size_t rsp_head_bwd_workspace(int32_t B, int32_t dim);
+int rsp_head_bwd(const float* dout1, const float* dout2, const float* pooled, const float* raw, const float* w1,
+                 const float* w2, int32_t B, int32_t P, int32_t C, int32_t feat_ld, int32_t dim, float* dw1,
+                 float* db1, float* dw2, float* db2, float* dfeat, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Contrastive block (moco/builder_diffspeed_diffloss.py:521-538) and Loss (:263-283).
+ * logits1 = [qA.kA | qA@queue]/T, logits2 = [qA.knegA | qA@queue]/T  each [B][1+K];  lposM = qM.kM/T, lnegM = qM.knegM/T
+ * queue: [dim][K] (register_buffer "queue", :329-330).
+ * ------------------------------------------------------------------------------------------------------- */
+int rsp_logits_fwd(const float* qA, const float* qM, const float* kA, const float* kM, const float* knegA,
+                   const float* knegM, const float* queue, int32_t B, int32_t dim, int32_t K, float inv_T,
+                   float* logits1, float* logits2, float* lposM, float* lnegM, void* stream);
+size_t rsp_logits_bwd_workspace(int32_t B, int32_t dim, int32_t K);
+int rsp_logits_bwd(const float* dlogits1, const float* dlogits2, const float* dlposM, const float* dlnegM,
+                   const float* kA, const float* kM, const float* knegA, const float* knegM, const float* queue,
+                   int32_t B, int32_t dim, int32_t K, float inv_T, float* dqA, float* dqM, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* losses[3] = (A*(ce1+ce2)+M*ranking, ce1+ce2, ranking); CE targets are class 0 (labels_A), ranking target +1.
+ * Also writes the gradients for d(losses[0]) = 1: dlogits1/2 [B][1+K], dlpos/dlneg [B]. */
+int rsp_loss_fwd_bwd(const float* logits1, const float* logits2, const float* lposM, const float* lnegM, int32_t B,
+                     int32_t K1 /* = 1+K */, float margin, float A, float M, float* losses, float* dlogits1,
+                     float* dlogits2, float* dlposM, float* dlnegM, float* row_scratch /*[2*B]*/, void* stream);
+
+/* queue[:, ptr:ptr+n] = keys.T  (_dequeue_and_enqueue, :345-359); keys [n][dim]. */
+int rsp_queue_enqueue(float* queue, int32_t dim, int32_t K, int32_t ptr, const float* keys, int32_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Step glue
+ * ------------------------------------------------------------------------------------------------------- */
+/* _diff_speed frame gather (:421-443) fused with the shuffle-BN sample permutation (:384-387) and the
+ * NCDHW -> NDHWC layout change:  out[j] = im[src[j]][:, frames(step[j])], frames(s) = 0, s, 2s, ... (T_out of them).
+ * im: (B_in, C, T_in, H, W) NCDHW as the reference's data loader hands it over; out: [B_out][T_out][H][W][C]. */
+int rsp_clip_gather(const float* im, int32_t B_in, int32_t C, int32_t T_in, int32_t H, int32_t W, const int32_t* src,
+                    const int32_t* step, int32_t B_out, int32_t T_out, float* out, void* stream);
+
+/* _momentum_update_key_encoder (:337-343) on flat parameter buffers: k = k*m + q*(1-m). */
+int rsp_momentum_update(float* k, const float* q, int64_t n, float m, void* stream);
+
+/* torch.optim.SGD step (pretrain.py:65-72,165) on flat buffers: d = g*gscale + wd*p; buf = first ? d : mu*buf + d;
+ * p -= lr*buf. */
+int rsp_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float wd, float gscale,
+                 int first, void* stream);
+
+/* rows gather: out[j][:] = in[idx[j]][:]  (feature un-shuffle, :389-406). */
+int rsp_rows_gather(const float* in, const int32_t* idx, int32_t n, int32_t width, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSPNET_HIP_H */

@@ -1,0 +1,107 @@
+"""ctypes binding of librspnet_hip.so (include/rspnet_hip.h).  No torch types cross this boundary.
+
+This is the binding a maintainer of the reference would add (INTEGRATION.md shows the same stub): the
+reference has no FFI of its own — its ops are ATen calls — so the Python side passes raw device pointers,
+sizes and the current HIP stream.  Importing this module never falls back to anything: if the shared
+library is missing, ``load()`` raises and every op in ``rspnet_amd.ops`` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librspnet_hip.so")
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """rsp_conv3d_desc"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "Di", "Hi", "Wi", "Cin", "Do", "Ho", "Wo", "Cout", "kT", "kH", "kW", "sT", "sH", "sW",
+        "pT", "pH", "pW", "in_ld", "out_ld")]
+
+
+class PoolDesc(C.Structure):
+    """rsp_pool3d_desc"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "Di", "Hi", "Wi", "C", "Do", "Ho", "Wo", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW",
+        "in_ld", "out_ld", "res_ld")]
+
+
+_PD = C.POINTER(ConvDesc)
+_PP = C.POINTER(PoolDesc)
+_sz = C.c_size_t
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f = C.c_float
+_p = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/rspnet_hip.h one to one (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "rsp_strerror": (C.c_char_p, [C.c_int]),
+    "rsp_last_error": (C.c_char_p, []),
+    "rsp_version": (C.c_int, []),
+    "rsp_conv3d_packed_fwd_elems": (_sz, [_PD]),
+    "rsp_conv3d_pack_fwd": (C.c_int, [_PD, _p, _p, _p]),
+    "rsp_conv3d_stat_tiles": (_i32, [_PD]),
+    "rsp_conv3d_fwd_workspace": (_sz, [_PD]),
+    "rsp_conv3d_fwd": (C.c_int, [_PD, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_conv3d_dgrad_workspace": (_sz, [_PD]),
+    "rsp_conv3d_dgrad": (C.c_int, [_PD, _p, _p, _p, _p, _sz, _p]),
+    "rsp_conv3d_wgrad_workspace": (_sz, [_PD]),
+    "rsp_conv3d_wgrad": (C.c_int, [_PD, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_bn_finalize_workspace": (_sz, [_i32, _i32]),
+    "rsp_bn_finalize": (C.c_int, [_p, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_bn_stat_tiles": (_i32, [_i64]),
+    "rsp_bn_stats": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "rsp_bn_act_pool_fwd": (C.c_int, [_PP, _p, _p, _p, C.c_int, _p, _p]),
+    "rsp_bn_bwd_workspace": (_sz, [_PP]),
+    "rsp_bn_act_pool_bwd": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_head_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "rsp_head_bwd_workspace": (_sz, [_i32, _i32]),
+    "rsp_head_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_logits_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p]),
+    "rsp_logits_bwd_workspace": (_sz, [_i32, _i32, _i32]),
+    "rsp_logits_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
+    "rsp_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "rsp_queue_enqueue": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
+    "rsp_clip_gather": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _p, _p]),
+    "rsp_momentum_update": (C.c_int, [_p, _p, _i64, _f, _p]),
+    "rsp_sgd_step": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _f, C.c_int, _p]),
+    "rsp_rows_gather": (C.c_int, [_p, _p, _i32, _i32, _p, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class RspError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise — there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RspError(
+            f"{LIB_PATH} not found: build it with rspnet_amd/csrc/build.sh (or __graft_entry__.build()). "
+            "rspnet_amd has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        lib = load()
+        raise RspError(f"{what} failed: {lib.rsp_strerror(rc).decode()} ({lib.rsp_last_error().decode()})")

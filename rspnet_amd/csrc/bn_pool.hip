@@ -1,0 +1,504 @@
+// BatchNorm3d (train mode) fused with ReLU / residual add / non-overlapping MaxPool3d — HBM-bound kernels.
+// Reference call sites: models/c3d.py:22-24 (bn → relu → pool), models/resnet.py:61-77, models/s3dg.py:23,28-33,
+// models/r2plus1d_vcop.py:59-60,116-123; semantics per SURVEY.md App. C (biased var for y, unbiased for running_var).
+//
+// The conv epilogue already produced per-128-row-tile (sum, sumsq) partials, so forward costs one read of y and one
+// write of the (pooled) activation; backward recomputes xhat / ReLU mask / pool arg-max from the saved y instead of
+// storing masks or indices.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// statistics
+// ------------------------------------------------------------------------------------------------------------------
+// stage 1: [tiles][C][2] float partials -> [S][C][2] double partials
+__global__ __launch_bounds__(256) void bn_finalize_stage1(const float* __restrict__ part, int tiles, int C, int S,
+                                                          double* __restrict__ out) {
+  __shared__ double red[4][64][2];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int per = (tiles + S - 1) / S;
+  const int t0 = blockIdx.y * per, t1 = min(tiles, t0 + per);
+  double s = 0.0, ss = 0.0;
+  if (c < C)
+    for (int t = t0 + rl; t < t1; t += 4) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * C + c) * 2);
+      s += (double)v.x;
+      ss += (double)v.y;
+    }
+  red[rl][threadIdx.x & 63][0] = s;
+  red[rl][threadIdx.x & 63][1] = ss;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const int l = threadIdx.x;
+    out[((long long)blockIdx.y * C + c) * 2 + 0] = red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0];
+    out[((long long)blockIdx.y * C + c) * 2 + 1] = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
+  }
+}
+
+__global__ void bn_finalize_stage2(const double* __restrict__ part, int S, int C, long long count,
+                                   const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int i = 0; i < S; ++i) {
+    s += part[((long long)i * C + c) * 2 + 0];
+    ss += part[((long long)i * C + c) * 2 + 1];
+  }
+  const double n = (double)count;
+  const double mean0 = s / n;                   // mean of the bias-free conv output
+  double var = ss / n - mean0 * mean0;          // biased
+  var = var > 0.0 ? var : 0.0;
+  const double mean = mean0 + (conv_bias ? (double)conv_bias[c] : 0.0);
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_invstd[c] = (float)mean;
+  mean_invstd[C + c] = invstd;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = b - (float)mean * sc;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// standalone stats over 128-row tiles (same partial layout as the conv epilogue)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, long long rows, int C, int ld,
+                                                       float* __restrict__ part) {
+  __shared__ float red[4][64][2];
+  const int tile = blockIdx.x;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f, ss = 0.f;
+  if (c < C)
+    for (int r = rl; r < 128; r += 4) {
+      const long long row = (long long)tile * 128 + r;
+      if (row >= rows) break;
+      const float v = y[row * ld + c];
+      s += v;
+      ss = fmaf(v, v, ss);
+    }
+  red[rl][threadIdx.x & 63][0] = s;
+  red[rl][threadIdx.x & 63][1] = ss;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const int l = threadIdx.x;
+    part[((long long)tile * C + c) * 2 + 0] = red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0];
+    part[((long long)tile * C + c) * 2 + 1] = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: out = maxpool(act(scale*y + shift + res))
+// ------------------------------------------------------------------------------------------------------------------
+struct PoolParams {
+  rsp_pool3d_desc d;
+  const float* __restrict__ y;
+  const float* __restrict__ ss;   // [2][C] scale, shift
+  const float* __restrict__ res;  // nullable
+  float* __restrict__ out;
+  int relu;
+  int cg;  // channel groups = C / VEC
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
+  if (VEC == 4) {
+    const floatx4 t = *reinterpret_cast<const floatx4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else {
+    v[0] = p[0];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
+  if (VEC == 4) {
+    floatx4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<floatx4*>(p) = t;
+  } else {
+    p[0] = v[0];
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  const long long total = (long long)d.N * d.Do * d.Ho * d.Wo * p.cg;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+    const int cgi = (int)(idx % p.cg);
+    long long q = idx / p.cg;
+    const int ow = (int)(q % d.Wo); q /= d.Wo;
+    const int oh = (int)(q % d.Ho); q /= d.Ho;
+    const int od = (int)(q % d.Do);
+    const int n = (int)(q / d.Do);
+    const int c = cgi * VEC;
+    float sc[VEC], sh[VEC], best[VEC];
+    load_vec<VEC>(p.ss + c, sc);
+    load_vec<VEC>(p.ss + d.C + c, sh);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) best[e] = -INFINITY;
+    for (int kt = 0; kt < d.kT; ++kt) {
+      const int id = od * d.sT - d.pT + kt;
+      if ((unsigned)id >= (unsigned)d.Di) continue;
+      for (int kh = 0; kh < d.kH; ++kh) {
+        const int ih = oh * d.sH - d.pH + kh;
+        if ((unsigned)ih >= (unsigned)d.Hi) continue;
+        for (int kw = 0; kw < d.kW; ++kw) {
+          const int iw = ow * d.sW - d.pW + kw;
+          if ((unsigned)iw >= (unsigned)d.Wi) continue;
+          const long long pos = (((long long)n * d.Di + id) * d.Hi + ih) * d.Wi + iw;
+          float v[VEC];
+          load_vec<VEC>(p.y + pos * d.in_ld + c, v);
+          float r[VEC];
+          if (p.res) load_vec<VEC>(p.res + pos * d.res_ld + c, r);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float z = fmaf(v[e], sc[e], sh[e]);
+            if (p.res) z += r[e];
+            if (p.relu) z = fmaxf(z, 0.f);
+            best[e] = fmaxf(best[e], z);
+          }
+        }
+      }
+    }
+    const long long opos = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
+    store_vec<VEC>(p.out + opos * d.out_ld + c, best);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------------------
+struct BwdParams {
+  rsp_pool3d_desc d;
+  const float* __restrict__ y;
+  const float* __restrict__ res;
+  const float* __restrict__ dout;  // [N,Do,Ho,Wo,C] pitch out_ld
+  const float* __restrict__ gamma;
+  const float* __restrict__ mi;    // mean, invstd [2][C]
+  const float* __restrict__ ss;    // scale, shift [2][C]
+  const double* __restrict__ sums; // [C][2] (sum dz, sum dz*xhat)  (apply only)
+  float* __restrict__ partial;     // reduce: [blocks][C][2]
+  float* __restrict__ dy;
+  float* __restrict__ dres;
+  int relu;
+  int cg;
+  int nblocks;
+  long long count;  // positions per channel of y
+};
+
+// z of one input position (post affine + residual), VEC channels
+template <int VEC>
+__device__ __forceinline__ void zval(const BwdParams& p, long long pos, int c, const float (&sc)[VEC],
+                                     const float (&sh)[VEC], float (&yv)[VEC], float (&z)[VEC]) {
+  load_vec<VEC>(p.y + pos * p.d.in_ld + c, yv);
+  float r[VEC];
+  if (p.res) load_vec<VEC>(p.res + pos * p.d.res_ld + c, r);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    z[e] = fmaf(yv[e], sc[e], sh[e]);
+    if (p.res) z[e] += r[e];
+  }
+}
+
+// pass 1: output-centric.  For each pooled output: arg-max (first max in scan order, like max_pool3d), dz = dout*mask.
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  __shared__ float red[256][2 * VEC];
+  const int cg0 = blockIdx.y * 256;
+  const int cgc = min(p.cg - cg0, 256);
+  const int ppi = 256 / cgc;
+  const int t = threadIdx.x;
+  const int cgi = cg0 + t % cgc, pl = t / cgc;
+  const bool active = pl < ppi;
+  const int c = cgi * VEC;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+  if (active) {
+    float sc[VEC], sh[VEC], mean[VEC], invstd[VEC];
+    load_vec<VEC>(p.ss + c, sc);
+    load_vec<VEC>(p.ss + d.C + c, sh);
+    load_vec<VEC>(p.mi + c, mean);
+    load_vec<VEC>(p.mi + d.C + c, invstd);
+    const long long npos = (long long)d.N * d.Do * d.Ho * d.Wo;
+    for (long long op = (long long)blockIdx.x * ppi + pl; op < npos; op += (long long)gridDim.x * ppi) {
+      long long q = op;
+      const int ow = (int)(q % d.Wo); q /= d.Wo;
+      const int oh = (int)(q % d.Ho); q /= d.Ho;
+      const int od = (int)(q % d.Do);
+      const int n = (int)(q / d.Do);
+      float best[VEC], by[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; by[e] = 0.f; }
+      for (int kt = 0; kt < d.kT; ++kt) {
+        const int id = od * d.sT - d.pT + kt;
+        if ((unsigned)id >= (unsigned)d.Di) continue;
+        for (int kh = 0; kh < d.kH; ++kh) {
+          const int ih = oh * d.sH - d.pH + kh;
+          if ((unsigned)ih >= (unsigned)d.Hi) continue;
+          for (int kw = 0; kw < d.kW; ++kw) {
+            const int iw = ow * d.sW - d.pW + kw;
+            if ((unsigned)iw >= (unsigned)d.Wi) continue;
+            const long long pos = (((long long)n * d.Di + id) * d.Hi + ih) * d.Wi + iw;
+            float yv[VEC], z[VEC];
+            zval<VEC>(p, pos, c, sc, sh, yv, z);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float zz = p.relu ? fmaxf(z[e], 0.f) : z[e];
+              if (zz > best[e]) { best[e] = zz; by[e] = yv[e]; }
+            }
+          }
+        }
+      }
+      float g[VEC];
+      load_vec<VEC>(p.dout + op * d.out_ld + c, g);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float dz = (p.relu && !(best[e] > 0.f)) ? 0.f : g[e];
+        s1[e] += dz;
+        s2[e] = fmaf(dz, (by[e] - mean[e]) * invstd[e], s2[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { red[t][e] = s1[e]; red[t][VEC + e] = s2[e]; }
+  __syncthreads();
+  if (t < cgc) {
+    float a1[VEC], a2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a1[e] = a2[e] = 0.f;
+    for (int l = 0; l < ppi; ++l)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { a1[e] += red[l * cgc + t][e]; a2[e] += red[l * cgc + t][VEC + e]; }
+    float* o = p.partial + ((long long)blockIdx.x * d.C + (cg0 + t) * VEC) * 2;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { o[2 * e] = a1[e]; o[2 * e + 1] = a2[e]; }
+  }
+}
+
+// sums[c] = (sum dz, sum dz*xhat) in double; also dgamma / dbeta.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nblocks; ++i) {
+    a += (double)partial[((long long)i * C + c) * 2 + 0];
+    b += (double)partial[((long long)i * C + c) * 2 + 1];
+  }
+  sums[2 * c] = a;
+  sums[2 * c + 1] = b;
+  if (dbeta) dbeta[c] = (float)a;
+  if (dgamma) dgamma[c] = (float)b;
+}
+
+// pass 2: input-centric.  dy = gamma*invstd*(dz_in - mean(dz) - xhat*mean(dz*xhat)); dz_in = dout*mask if this position
+// is its window's arg-max else 0 (windows are disjoint: kernel == stride, no padding).
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  const long long total = (long long)d.N * d.Di * d.Hi * d.Wi * p.cg;
+  const double invn = 1.0 / (double)p.count;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+    const int cgi = (int)(idx % p.cg);
+    long long q = idx / p.cg;
+    const long long pos = q;
+    const int iw = (int)(q % d.Wi); q /= d.Wi;
+    const int ih = (int)(q % d.Hi); q /= d.Hi;
+    const int id = (int)(q % d.Di);
+    const int n = (int)(q / d.Di);
+    const int c = cgi * VEC;
+    float sc[VEC], sh[VEC], mean[VEC], invstd[VEC], gam[VEC];
+    load_vec<VEC>(p.ss + c, sc);
+    load_vec<VEC>(p.ss + d.C + c, sh);
+    load_vec<VEC>(p.mi + c, mean);
+    load_vec<VEC>(p.mi + d.C + c, invstd);
+    if (p.gamma) load_vec<VEC>(p.gamma + c, gam);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) gam[e] = 1.f;
+    }
+    float yv[VEC], z[VEC], dz[VEC];
+    zval<VEC>(p, pos, c, sc, sh, yv, z);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dz[e] = 0.f;
+    const int od = id / d.sT, oh = ih / d.sH, ow = iw / d.sW;
+    if (od < d.Do && oh < d.Ho && ow < d.Wo) {
+      // is this position the first maximum of its window?
+      bool win[VEC];
+      float mine[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { mine[e] = p.relu ? fmaxf(z[e], 0.f) : z[e]; win[e] = true; }
+      const int my = ((id - od * d.sT) * d.kH + (ih - oh * d.sH)) * d.kW + (iw - ow * d.sW);
+      if (d.kT * d.kH * d.kW > 1) {
+        for (int kt = 0; kt < d.kT; ++kt)
+          for (int kh = 0; kh < d.kH; ++kh)
+            for (int kw = 0; kw < d.kW; ++kw) {
+              const int o = (kt * d.kH + kh) * d.kW + kw;
+              if (o == my) continue;
+              const long long pp = (((long long)n * d.Di + od * d.sT + kt) * d.Hi + oh * d.sH + kh) * d.Wi + ow * d.sW + kw;
+              float y2[VEC], z2[VEC];
+              zval<VEC>(p, pp, c, sc, sh, y2, z2);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                const float v = p.relu ? fmaxf(z2[e], 0.f) : z2[e];
+                // earlier positions win ties; later ones must be strictly greater to displace us
+                if (o < my ? (v >= mine[e]) : (v > mine[e])) win[e] = false;
+              }
+            }
+      }
+      const long long op = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
+      float g[VEC];
+      load_vec<VEC>(p.dout + op * d.out_ld + c, g);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dz[e] = (win[e] && !(p.relu && !(mine[e] > 0.f))) ? g[e] : 0.f;
+    }
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float m1 = (float)(p.sums[2 * (c + e)] * invn);
+      const float m2 = (float)(p.sums[2 * (c + e) + 1] * invn);
+      const float xhat = (yv[e] - mean[e]) * invstd[e];
+      o[e] = gam[e] * invstd[e] * (dz[e] - m1 - xhat * m2);
+    }
+    store_vec<VEC>(p.dy + pos * d.in_ld + c, o);
+    if (p.dres) store_vec<VEC>(p.dres + pos * d.res_ld + c, dz);
+  }
+}
+
+bool pool_ok(const rsp_pool3d_desc* d, bool need_disjoint) {
+  if (!d) return false;
+  if (d->N <= 0 || d->C <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0) return false;
+  if (d->sT <= 0 || d->sH <= 0 || d->sW <= 0 || d->pT < 0 || d->pH < 0 || d->pW < 0) return false;
+  if (d->Do != (d->Di + 2 * d->pT - d->kT) / d->sT + 1) return false;
+  if (d->Ho != (d->Hi + 2 * d->pH - d->kH) / d->sH + 1) return false;
+  if (d->Wo != (d->Wi + 2 * d->pW - d->kW) / d->sW + 1) return false;
+  if (d->in_ld < d->C || d->out_ld < d->C) return false;
+  if (need_disjoint) {
+    if (d->kT != d->sT || d->kH != d->sH || d->kW != d->sW || d->pT || d->pH || d->pW) return false;
+  }
+  return true;
+}
+
+int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+int reduce_blocks(const rsp_pool3d_desc* d, int cg) {
+  const int cgc = cg < 256 ? cg : 256;
+  const int ppi = 256 / cgc;
+  const long long npos = (long long)d->N * d->Do * d->Ho * d->Wo;
+  long long b = (npos + (long long)ppi * 8 - 1) / ((long long)ppi * 8);  // >= 8 positions per thread
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rsp_bn_stat_tiles(int64_t rows) { return rsp_cdiv(rows, 128); }
+
+int rsp_bn_stats(const float* y, int64_t rows, int32_t C, int32_t ld, float* stat_partials, void* stream) {
+  RSP_REQUIRE(y && stat_partials && rows > 0 && C > 0 && ld >= C, "rsp_bn_stats: bad argument");
+  dim3 grid(rsp_cdiv(rows, 128), rsp_cdiv(C, 64));
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, (long long)rows, C, ld, stat_partials);
+  return rsp_check_launch("bn_stats_kernel");
+}
+
+size_t rsp_bn_finalize_workspace(int32_t tiles, int32_t C) {
+  const int S = tiles >= 4096 ? 64 : (tiles >= 64 ? 16 : 1);
+  return (size_t)S * C * 2 * sizeof(double);
+}
+
+int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int64_t count, const float* conv_bias,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, float* mean_invstd, float* scale_shift, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(stat_partials && mean_invstd && scale_shift && workspace, "rsp_bn_finalize: null pointer");
+  RSP_REQUIRE(tiles > 0 && C > 0 && count > 0, "rsp_bn_finalize: bad size");
+  const int S = tiles >= 4096 ? 64 : (tiles >= 64 ? 16 : 1);
+  if (workspace_bytes < (size_t)S * C * 2 * sizeof(double)) {
+    rsp_set_error("rsp_bn_finalize: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(bn_finalize_stage1, dim3(rsp_cdiv(C, 64), S), dim3(256), 0, s, stat_partials, tiles, C, S, part);
+  int rc = rsp_check_launch("bn_finalize_stage1");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(bn_finalize_stage2, dim3(rsp_cdiv(C, 128)), dim3(128), 0, s, part, S, C, (long long)count, conv_bias,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
+  return rsp_check_launch("bn_finalize_stage2");
+}
+
+int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
+                        int relu, float* out, void* stream) {
+  RSP_REQUIRE(pool_ok(d, false), "rsp_bn_act_pool_fwd: bad descriptor");
+  RSP_REQUIRE(y && scale_shift && out, "rsp_bn_act_pool_fwd: null pointer");
+  PoolParams p;
+  p.d = *d; p.y = y; p.ss = scale_shift; p.res = residual; p.out = out; p.relu = relu;
+  const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(out) &&
+                   rsp_aligned16(scale_shift) && (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual)));
+  p.cg = vec ? d->C / 4 : d->C;
+  const long long total = (long long)d->N * d->Do * d->Ho * d->Wo * p.cg;
+  if (vec) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return rsp_check_launch("bn_act_pool_fwd_kernel");
+}
+
+size_t rsp_bn_bwd_workspace(const rsp_pool3d_desc* d) {
+  if (!pool_ok(d, true)) return 0;
+  return rsp_align_up((size_t)2048 * d->C * 2 * sizeof(float), 256) + (size_t)d->C * 2 * sizeof(double);
+}
+
+int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* residual, const float* dout,
+                        const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
+                        float* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  RSP_REQUIRE(pool_ok(d, true), "rsp_bn_act_pool_bwd: needs disjoint windows (kernel == stride, no padding)");
+  RSP_REQUIRE(y && dout && mean_invstd && scale_shift && dy && workspace, "rsp_bn_act_pool_bwd: null pointer");
+  if (workspace_bytes < rsp_bn_bwd_workspace(d)) {
+    rsp_set_error("rsp_bn_act_pool_bwd: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  BwdParams p;
+  memset(&p, 0, sizeof p);
+  p.d = *d; p.y = y; p.res = residual; p.dout = dout; p.gamma = gamma; p.mi = mean_invstd; p.ss = scale_shift;
+  p.dy = dy; p.dres = dres; p.relu = relu;
+  p.count = (long long)d->N * d->Di * d->Hi * d->Wi;
+  const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(dout) &&
+                   rsp_aligned16(dy) && rsp_aligned16(scale_shift) && rsp_aligned16(mean_invstd) &&
+                   (!gamma || rsp_aligned16(gamma)) &&
+                   (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual) && (!dres || rsp_aligned16(dres))));
+  p.cg = vec ? d->C / 4 : d->C;
+  p.partial = reinterpret_cast<float*>(workspace);
+  double* sums = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(workspace) +
+                                           rsp_align_up((size_t)2048 * d->C * 2 * sizeof(float), 256));
+  p.sums = sums;
+  p.nblocks = reduce_blocks(d, p.cg);
+  dim3 rgrid(p.nblocks, rsp_cdiv(p.cg, 256));
+  if (vec) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, rgrid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, rgrid, dim3(256), 0, s, p);
+  int rc = rsp_check_launch("bn_bwd_reduce_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, 128)), dim3(128), 0, s, p.partial, p.nblocks, d->C, sums,
+                     dgamma, dbeta);
+  rc = rsp_check_launch("bn_bwd_finalize_kernel");
+  if (rc != RSP_OK) return rc;
+  const long long total = (long long)d->N * d->Di * d->Hi * d->Wi * p.cg;
+  if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, p);
+  return rsp_check_launch("bn_bwd_apply_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,659 @@
+// Implicit-GEMM 3-D convolution for gfx950 on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// One kernel serves nn.Conv3d forward (reference call sites: models/c3d.py:21-52 & friends) and, through
+// per-stride-parity "affine gather" geometry, its input gradient (autograd conv backward-input).
+//
+//   out[row, co] = sum_{tap, ci} in[ gather(row, tap), ci ] * Wp[co, tap*Cin + ci]      (+ bias[co])
+//   gather(row, tap): row -> (n, gd, gh, gw) on the output grid;  in_coord = g*S + off(tap)  per dim
+//
+// GEMM view: M = rows (positions), N = Cout, K = taps*Cin.  NDHWC activations make each (row, tap) slice a
+// contiguous Cin run, the packed weight makes each co row a contiguous K run, so both LDS tiles are
+// [row][k] with k contiguous and every MFMA operand fragment is one ds_read_b128.
+//
+// Tile: BM x BN x 32 per 256-thread workgroup (4 waves), register-staged double-buffered LDS, one barrier per
+// K-chunk.  The fp32 MFMA issues every 64 cycles per SIMD, so a 32-deep chunk is 4096 MFMA-cycles per wave
+// against 8 x 16-B global loads per thread: staging hides completely behind the matrix pipe; tap re-reads of the
+// input are served by L2 (27 x re-read of conv2's 411 MB input = 1.6 TB/s of L2 traffic, L2 peak 34 TB/s).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;         // K-chunk (floats)
+constexpr int LDK = BK + 4;    // LDS row pitch: 36 floats => ds_read_b128 conflict-free (9r mod 16 distinct)
+constexpr int MAX_TAPS = 343;  // 7x7x7
+
+struct IgemmParams {
+  const float* __restrict__ x;
+  const float* __restrict__ w;     // packed [Cout][Kld]
+  const float* __restrict__ bias;  // nullable
+  float* __restrict__ y;
+  float* __restrict__ stat;     // nullable: [m_tiles][Cout][2]
+  float* __restrict__ partial;  // split-K: [splitk][M][Cout]
+  int M;                        // rows of the output grid
+  int Gd, Gh, Gw;               // output grid dims (rows decode as n,gd,gh,gw)
+  int oDm, oHm, oWm;            // output memory dims
+  int oSd, oSh, oSw, oOd, oOh, oOw;  // memory coord = g*oS + oO
+  int out_ld, Cout;
+  int Di, Hi, Wi, in_ld, Cin;   // input tensor
+  int sD, sH, sW;               // in coord = g*s + off(tap)
+  int nTd, nTh, nTw;            // taps per dim (tap index = (a_d*nTh + a_h)*nTw + a_w)
+  int off0d, off0h, off0w;      // first tap offset per dim
+  int offstep;                  // +1 forward, -1 dgrad
+  int K, Kld, nchunks;
+  int splitk, chunks_per_split;
+  int m_tiles, n_tiles;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);             // [2][BM][LDK]
+  float* Bs = As + 2 * BM * LDK;                              // [2][BN][LDK]
+  int4* taptab = reinterpret_cast<int4*>(Bs + 2 * BN * LDK);  // [ntaps] {offd, offh, offw, delta}
+  long long* rowaddr = reinterpret_cast<long long*>(taptab + MAX_TAPS + 1);  // [BM]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tile = rsp_xcd_remap(blockIdx.x, gridDim.x);
+  const int m_tile = tile / p.n_tiles, n_tile = tile - m_tile * p.n_tiles;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int z = blockIdx.y;
+  const int kc_begin = z * p.chunks_per_split;
+  const int kc_end = min(p.nchunks, kc_begin + p.chunks_per_split);
+
+  // ---- tap table --------------------------------------------------------------------------------------
+  const int ntaps = p.nTd * p.nTh * p.nTw;
+  for (int i = t; i < ntaps; i += 256) {
+    const int aw = i % p.nTw, q = i / p.nTw;
+    const int ah = q % p.nTh, ad = q / p.nTh;
+    const int od = p.off0d + ad * p.offstep, oh = p.off0h + ah * p.offstep, ow = p.off0w + aw * p.offstep;
+    taptab[i] = make_int4(od, oh, ow, ((od * p.Hi + oh) * p.Wi + ow) * p.in_ld);
+  }
+
+  // ---- per-thread row geometry for the A (im2col) tile ----------------------------------------------------
+  const int arow = t >> 3;        // + 32*i
+  const int kcol = (t & 7) * 4;   // k offset inside the chunk
+  long long abase[AR];
+  int aid[AR], aih[AR], aiw[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int r = m0 + arow + 32 * i;
+    if (r < p.M) {
+      const int gw = r % p.Gw;
+      int q = r / p.Gw;
+      const int gh = q % p.Gh;
+      q /= p.Gh;
+      const int gd = q % p.Gd;
+      const int n = q / p.Gd;
+      aid[i] = gd * p.sD;
+      aih[i] = gh * p.sH;
+      aiw[i] = gw * p.sW;
+      abase[i] = ((((long long)n * p.Di + aid[i]) * p.Hi + aih[i]) * p.Wi + aiw[i]) * p.in_ld;
+    } else {
+      aid[i] = -(1 << 20);  // every tap out of bounds
+      aih[i] = 0;
+      aiw[i] = 0;
+      abase[i] = 0;
+    }
+  }
+  const float* wrow[BR];
+  bool wok[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int co = n0 + arow + 32 * i;
+    wok[i] = co < p.Cout;
+    wrow[i] = p.w + (long long)(wok[i] ? co : 0) * p.Kld;
+  }
+  __syncthreads();  // tap table ready
+
+  floatx4 areg[AR], breg[BR];
+
+  auto load_chunk = [&](int kc) {
+    const int k = kc * BK + kcol;
+    // weights
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wok[i] && k < p.Kld) v = *reinterpret_cast<const floatx4*>(wrow[i] + k);
+      breg[i] = v;
+    }
+    // activations
+    if (VEC == 4) {
+      int4 tt = make_int4(0, 0, 0, 0);
+      int ci = 0;
+      const bool kok = k < p.K;
+      if (kok) {
+        const int tap = k / p.Cin;
+        ci = k - tap * p.Cin;
+        tt = taptab[tap];
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
+        if (kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+          v = *reinterpret_cast<const floatx4*>(p.x + abase[i] + tt.w + ci);
+        areg[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) areg[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ke = k + e;
+        if (ke < p.K) {
+          const int tap = ke / p.Cin;
+          const int ci = ke - tap * p.Cin;
+          const int4 tt = taptab[tap];
+#pragma unroll
+          for (int i = 0; i < AR; ++i) {
+            const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
+            if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+              areg[i][e] = p.x[abase[i] + tt.w + ci];
+          }
+        }
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* a = As + buf * BM * LDK;
+    float* b = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<floatx4*>(a + (arow + 32 * i) * LDK + kcol) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<floatx4*>(b + (arow + 32 * i) * LDK + kcol) = breg[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kc_begin < kc_end) {
+    load_chunk(kc_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const bool more = kc + 1 < kc_end;
+    if (more) load_chunk(kc + 1);  // global loads in flight under this chunk's MFMAs
+
+    const float* a = As + buf * BM * LDK + (wm * WM + l32) * LDK + h * 16;
+    const float* b = Bs + buf * BN * LDK + (wn * WN + l32) * LDK + h * 16;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      floatx4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const floatx4*>(a + i * 32 * LDK + kk * 4);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const floatx4*>(b + j * 32 * LDK + kk * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------
+  // row -> output address table (general affine mapping: identity for forward, strided class grid for dgrad)
+  if (t < BM) {
+    const int r = m0 + t;
+    long long addr = -1;
+    if (r < p.M) {
+      if (p.partial) {
+        addr = ((long long)z * p.M + r) * p.Cout;
+      } else {
+        const int gw = r % p.Gw;
+        int q = r / p.Gw;
+        const int gh = q % p.Gh;
+        q /= p.Gh;
+        const int gd = q % p.Gd;
+        const int n = q / p.Gd;
+        addr = ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw +
+                p.oOw) * p.out_ld;
+      }
+    }
+    rowaddr[t] = addr;
+  }
+  __syncthreads();
+
+  float* dst = p.partial ? p.partial : p.y;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WN + j * 32 + l32;
+    if (col < p.Cout) {
+      const float bv = (p.bias && !p.partial) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
+          const long long addr = rowaddr[rl];
+          if (addr >= 0) dst[addr + col] = acc[i][j][e] + bv;
+        }
+    }
+  }
+
+  if (p.stat && !p.partial) {
+    // per-channel (sum, sumsq) of the bias-free conv output over this tile's rows; rows >= M contributed zeros.
+    float* red = As;  // [WAVES_M][BN][2]  (all LDS reads of the main loop are done: barrier above)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][j][e];
+          s += v;
+          ss = fmaf(v, v, ss);
+        }
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (h == 0) {
+        const int c = wn * WN + j * 32 + l32;
+        red[(wm * BN + c) * 2 + 0] = s;
+        red[(wm * BN + c) * 2 + 1] = ss;
+      }
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < p.Cout) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        s += red[(w * BN + t) * 2 + 0];
+        ss += red[(w * BN + t) * 2 + 1];
+      }
+      float* o = p.stat + ((long long)m_tile * p.Cout + n0 + t) * 2;
+      o[0] = s;
+      o[1] = ss;
+    }
+  }
+}
+
+// split-K reduction: y[row] = sum_z partial[z][row] + bias, stats per 128-row tile.
+struct ReduceParams {
+  const float* __restrict__ partial;
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  float* __restrict__ stat;
+  int M, Cout, splitk;
+  int Gd, Gh, Gw, oDm, oHm, oWm, oSd, oSh, oSw, oOd, oOh, oOw, out_ld;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
+  // block = one 128-row tile x 64 channels; thread = (row group of 4 lanes.., channel)
+  __shared__ float red[4][64][2];
+  const int m_tile = blockIdx.x, c0 = blockIdx.y * 64;
+  const int c = c0 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;  // 0..3 -> rows rg, rg+4, ...
+  float s = 0.f, ss = 0.f;
+  if (c < p.Cout) {
+    const float bv = p.bias ? p.bias[c] : 0.f;
+    for (int rl = rg; rl < 128; rl += 4) {
+      const int r = m_tile * 128 + rl;
+      if (r >= p.M) break;
+      float v = 0.f;
+      for (int z = 0; z < p.splitk; ++z) v += p.partial[((long long)z * p.M + r) * p.Cout + c];
+      const int gw = r % p.Gw;
+      int q = r / p.Gw;
+      const int gh = q % p.Gh;
+      q /= p.Gh;
+      const int gd = q % p.Gd;
+      const int n = q / p.Gd;
+      const long long addr =
+          ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw + p.oOw) *
+          p.out_ld;
+      p.y[addr + c] = v + bv;
+      s += v;
+      ss = fmaf(v, v, ss);
+    }
+  }
+  if (p.stat) {
+    red[rg][threadIdx.x & 63][0] = s;
+    red[rg][threadIdx.x & 63][1] = ss;
+    __syncthreads();
+    if (rg == 0 && c < p.Cout) {
+      float a = 0.f, b = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        a += red[w][threadIdx.x][0];
+        b += red[w][threadIdx.x][1];
+      }
+      p.stat[((long long)m_tile * p.Cout + c) * 2 + 0] = a;
+      p.stat[((long long)m_tile * p.Cout + c) * 2 + 1] = b;
+    }
+  }
+}
+
+// Weight re-pack: out[o][tapidx*C + c] (row pitch Kld, zero padded) from the reference layout (Cout,Cin,kT,kH,kW).
+struct PackParams {
+  const float* __restrict__ w;
+  float* __restrict__ out;
+  int Cout, Cin, kT, kH, kW;
+  int transpose;  // 0: o=co,c=ci (forward)   1: o=ci,c=co (dgrad)
+  int O, C, Kld;
+  int nTd, nTh, nTw;     // taps enumerated per dim
+  int k0d, k0h, k0w;     // first kernel index per dim
+  int kstepd, ksteph, kstepw;
+};
+
+__global__ void pack_weight_kernel(const PackParams p) {
+  const long long total = (long long)p.O * p.Kld;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(i / p.Kld);
+    const int k = (int)(i - (long long)o * p.Kld);
+    float v = 0.f;
+    const int ntaps = p.nTd * p.nTh * p.nTw;
+    if (k < ntaps * p.C) {
+      const int tap = k / p.C, c = k - tap * p.C;
+      const int aw = tap % p.nTw, q = tap / p.nTw;
+      const int ah = q % p.nTh, ad = q / p.nTh;
+      const int kt = p.k0d + ad * p.kstepd, kh = p.k0h + ah * p.ksteph, kw = p.k0w + aw * p.kstepw;
+      const int co = p.transpose ? c : o, ci = p.transpose ? o : c;
+      v = p.w[((((long long)co * p.Cin + ci) * p.kT + kt) * p.kH + kh) * p.kW + kw];
+    }
+    p.out[i] = v;
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC>
+int launch_cfg(const IgemmParams& p, hipStream_t s) {
+  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) + BM * sizeof(long long);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.m_tiles * p.n_tiles, p.splitk);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC>), grid, dim3(256), lds, s, p);
+  return rsp_check_launch("igemm_kernel");
+}
+
+int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
+  // BM is fixed at 128 (stat partials are defined on 128-row tiles); BN follows Cout.
+  int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
+  p.m_tiles = rsp_cdiv(p.M, 128);
+  p.n_tiles = rsp_cdiv(p.Cout, bn);
+  if (bn == 128) return vec4 ? launch_cfg<128, 128, 2, 2, 4>(p, s) : launch_cfg<128, 128, 2, 2, 1>(p, s);
+  if (bn == 64) return vec4 ? launch_cfg<128, 64, 2, 2, 4>(p, s) : launch_cfg<128, 64, 2, 2, 1>(p, s);
+  return vec4 ? launch_cfg<128, 32, 4, 1, 4>(p, s) : launch_cfg<128, 32, 4, 1, 1>(p, s);
+}
+
+// Heuristic split-K: only when the tile grid cannot fill 256 CUs x 2 workgroups.
+int choose_splitk(int tiles, int nchunks) {
+  if (tiles >= 384 || nchunks < 16) return 1;
+  int sk = rsp_cdiv(1024, tiles);
+  sk = sk > 16 ? 16 : sk;
+  while (sk > 1 && nchunks / sk < 8) --sk;
+  return sk < 1 ? 1 : sk;
+}
+
+bool desc_ok(const rsp_conv3d_desc* d) {
+  if (!d) return false;
+  if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return false;
+  if (d->kT * d->kH * d->kW > MAX_TAPS || d->kT <= 0 || d->kH <= 0 || d->kW <= 0) return false;
+  if (d->sT <= 0 || d->sH <= 0 || d->sW <= 0 || d->pT < 0 || d->pH < 0 || d->pW < 0) return false;
+  if (d->Do != (d->Di + 2 * d->pT - d->kT) / d->sT + 1) return false;
+  if (d->Ho != (d->Hi + 2 * d->pH - d->kH) / d->sH + 1) return false;
+  if (d->Wo != (d->Wi + 2 * d->pW - d->kW) / d->sW + 1) return false;
+  if (d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) return false;
+  if (d->in_ld < d->Cin || d->out_ld < d->Cout) return false;
+  if ((long long)d->N * d->Do * d->Ho * d->Wo >= (1ll << 31)) return false;
+  if ((long long)d->N * d->Di * d->Hi * d->Wi >= (1ll << 31)) return false;
+  return true;
+}
+
+void fill_reduce(ReduceParams& r, const IgemmParams& p) {
+  r.partial = p.partial;
+  r.bias = p.bias;
+  r.y = p.y;
+  r.stat = p.stat;
+  r.M = p.M;
+  r.Cout = p.Cout;
+  r.splitk = p.splitk;
+  r.Gd = p.Gd; r.Gh = p.Gh; r.Gw = p.Gw;
+  r.oDm = p.oDm; r.oHm = p.oHm; r.oWm = p.oWm;
+  r.oSd = p.oSd; r.oSh = p.oSh; r.oSw = p.oSw;
+  r.oOd = p.oOd; r.oOh = p.oOh; r.oOw = p.oOw;
+  r.out_ld = p.out_ld;
+}
+
+int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
+  p.nchunks = rsp_cdiv(p.K, BK);
+  const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
+  const int tiles = rsp_cdiv(p.M, 128) * rsp_cdiv(p.Cout, bn);
+  int sk = choose_splitk(tiles, p.nchunks);
+  if (sk > 1) {
+    const size_t need = (size_t)sk * p.M * p.Cout * sizeof(float);
+    if (!workspace || ws_bytes < need) sk = 1;  // degrade gracefully: still correct
+  }
+  p.chunks_per_split = rsp_cdiv(p.nchunks, sk);
+  p.splitk = rsp_cdiv(p.nchunks, p.chunks_per_split);
+  p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+  int rc = launch_igemm(p, vec4, s);
+  if (rc != RSP_OK) return rc;
+  if (p.splitk > 1) {
+    ReduceParams r;
+    fill_reduce(r, p);
+    dim3 grid(rsp_cdiv(p.M, 128), rsp_cdiv(p.Cout, 64));
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, r);
+    rc = rsp_check_launch("splitk_reduce_kernel");
+  }
+  return rc;
+}
+
+size_t igemm_partial_bytes(long long M, int Cout, int K) {
+  const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+  const int sk = choose_splitk(rsp_cdiv(M, 128) * rsp_cdiv(Cout, bn), rsp_cdiv(K, BK));
+  return sk > 1 ? (size_t)sk * M * Cout * sizeof(float) : 0;
+}
+
+static inline int mod_pos(int a, int m) { return ((a % m) + m) % m; }
+
+// One stride-parity class of the input-gradient problem.
+struct DgradClass {
+  int rt, rh, rw;     // residues
+  int k0t, k0h, k0w;  // first kernel index per dim
+  int nt, nh, nw;     // taps per dim
+  int Gd, Gh, Gw;     // class grid
+};
+
+DgradClass dgrad_class(const rsp_conv3d_desc* d, int c) {
+  DgradClass g;
+  g.rw = c % d->sW; g.rh = (c / d->sW) % d->sH; g.rt = c / (d->sW * d->sH);
+  g.k0t = mod_pos(g.rt + d->pT, d->sT); g.k0h = mod_pos(g.rh + d->pH, d->sH); g.k0w = mod_pos(g.rw + d->pW, d->sW);
+  g.nt = g.k0t < d->kT ? (d->kT - 1 - g.k0t) / d->sT + 1 : 0;
+  g.nh = g.k0h < d->kH ? (d->kH - 1 - g.k0h) / d->sH + 1 : 0;
+  g.nw = g.k0w < d->kW ? (d->kW - 1 - g.k0w) / d->sW + 1 : 0;
+  g.Gd = g.rt < d->Di ? (d->Di - 1 - g.rt) / d->sT + 1 : 0;
+  g.Gh = g.rh < d->Hi ? (d->Hi - 1 - g.rh) / d->sH + 1 : 0;
+  g.Gw = g.rw < d->Wi ? (d->Wi - 1 - g.rw) / d->sW + 1 : 0;
+  return g;
+}
+
+size_t dgrad_wpack_bytes(const rsp_conv3d_desc* d) {
+  const int nclass = d->sT * d->sH * d->sW;
+  return rsp_align_up(((size_t)d->kT * d->kH * d->kW * d->Cout + 4 * (size_t)nclass) * d->Cin * sizeof(float), 256);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rsp_conv3d_packed_fwd_elems(const rsp_conv3d_desc* d) {
+  if (!desc_ok(d)) return 0;
+  const size_t K = (size_t)d->kT * d->kH * d->kW * d->Cin;
+  return (size_t)d->Cout * rsp_align_up(K, 4);
+}
+
+int rsp_conv3d_pack_fwd(const rsp_conv3d_desc* d, const float* w_ref, float* w_packed, void* stream) {
+  RSP_REQUIRE(desc_ok(d), "rsp_conv3d_pack_fwd: bad descriptor");
+  RSP_REQUIRE(w_ref && w_packed, "rsp_conv3d_pack_fwd: null pointer");
+  PackParams p;
+  p.w = w_ref; p.out = w_packed;
+  p.Cout = d->Cout; p.Cin = d->Cin; p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
+  p.transpose = 0; p.O = d->Cout; p.C = d->Cin;
+  p.Kld = (int)rsp_align_up((size_t)d->kT * d->kH * d->kW * d->Cin, 4);
+  p.nTd = d->kT; p.nTh = d->kH; p.nTw = d->kW;
+  p.k0d = p.k0h = p.k0w = 0;
+  p.kstepd = p.ksteph = p.kstepw = 1;
+  const long long total = (long long)p.O * p.Kld;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return rsp_check_launch("pack_weight_kernel");
+}
+
+int32_t rsp_conv3d_stat_tiles(const rsp_conv3d_desc* d) {
+  if (!desc_ok(d)) return 0;
+  return rsp_cdiv((long long)d->N * d->Do * d->Ho * d->Wo, 128);
+}
+
+size_t rsp_conv3d_fwd_workspace(const rsp_conv3d_desc* d) {
+  if (!desc_ok(d)) return 0;
+  return igemm_partial_bytes((long long)d->N * d->Do * d->Ho * d->Wo, d->Cout, d->kT * d->kH * d->kW * d->Cin);
+}
+
+int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                   float* stat_partials, void* workspace, size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(desc_ok(d), "rsp_conv3d_fwd: bad descriptor");
+  RSP_REQUIRE(x && w_packed && y, "rsp_conv3d_fwd: null pointer");
+  RSP_REQUIRE(rsp_aligned16(w_packed), "rsp_conv3d_fwd: packed weight must be 16-byte aligned");
+  IgemmParams p;
+  memset(&p, 0, sizeof p);
+  p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.stat = stat_partials;
+  p.M = d->N * d->Do * d->Ho * d->Wo;
+  p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
+  p.oDm = d->Do; p.oHm = d->Ho; p.oWm = d->Wo;
+  p.oSd = p.oSh = p.oSw = 1;
+  p.oOd = p.oOh = p.oOw = 0;
+  p.out_ld = d->out_ld; p.Cout = d->Cout;
+  p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.in_ld = d->in_ld; p.Cin = d->Cin;
+  p.sD = d->sT; p.sH = d->sH; p.sW = d->sW;
+  p.nTd = d->kT; p.nTh = d->kH; p.nTw = d->kW;
+  p.off0d = -d->pT; p.off0h = -d->pH; p.off0w = -d->pW;
+  p.offstep = 1;
+  p.K = d->kT * d->kH * d->kW * d->Cin;
+  p.Kld = (int)rsp_align_up((size_t)p.K, 4);
+  const bool vec4 = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x);
+  return run_igemm(p, vec4, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- dgrad ----------------------------------------------------------------------------------------------------
+// dx[i] = sum_{k : (i + p - k) % s == 0} dy[(i + p - k)/s] * w[k]; positions are split into s^3 parity classes,
+// each a dense stride-1 "conv" over dy with its own tap subset; class c writes the strided sub-grid i = s*g + r.
+size_t rsp_conv3d_dgrad_workspace(const rsp_conv3d_desc* d) {
+  if (!desc_ok(d)) return 0;
+  size_t part = 0;
+  const int nclass = d->sT * d->sH * d->sW;
+  for (int c = 0; c < nclass; ++c) {
+    const DgradClass g = dgrad_class(d, c);
+    if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+    const size_t b = igemm_partial_bytes((long long)d->N * g.Gd * g.Gh * g.Gw, d->Cin, g.nt * g.nh * g.nw * d->Cout);
+    part = b > part ? b : part;
+  }
+  return dgrad_wpack_bytes(d) + part;
+}
+
+int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_ref, float* dx, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(desc_ok(d), "rsp_conv3d_dgrad: bad descriptor");
+  RSP_REQUIRE(dy && w_ref && dx && workspace, "rsp_conv3d_dgrad: null pointer");
+  RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_dgrad: workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nclass = d->sT * d->sH * d->sW;
+  unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
+  const size_t wp_bytes = dgrad_wpack_bytes(d);
+  if (workspace_bytes < wp_bytes) {
+    rsp_set_error("rsp_conv3d_dgrad: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  float* wpk = reinterpret_cast<float*>(wsp);
+  void* part = wsp + wp_bytes;
+  const size_t part_bytes = workspace_bytes - wp_bytes;
+
+  bool any_empty = false;
+  for (int c = 0; c < nclass; ++c) {
+    const DgradClass g = dgrad_class(d, c);
+    if (g.Gd * g.Gh * g.Gw != 0 && g.nt * g.nh * g.nw == 0) any_empty = true;
+  }
+  if (any_empty) {
+    // some input positions receive no gradient at all (kernel smaller than stride, e.g. 1x1x1 stride 2)
+    const size_t rows = (size_t)d->N * d->Di * d->Hi * d->Wi;
+    if (d->in_ld == d->Cin) {
+      hipMemsetAsync(dx, 0, rows * d->Cin * sizeof(float), s);
+    } else {
+      hipMemset2DAsync(dx, (size_t)d->in_ld * 4, 0, (size_t)d->Cin * 4, rows, s);
+    }
+  }
+
+  size_t woff = 0;
+  for (int c = 0; c < nclass; ++c) {
+    const DgradClass g = dgrad_class(d, c);
+    if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+
+    PackParams pk;
+    pk.w = w_ref; pk.out = wpk + woff;
+    pk.Cout = d->Cout; pk.Cin = d->Cin; pk.kT = d->kT; pk.kH = d->kH; pk.kW = d->kW;
+    pk.transpose = 1; pk.O = d->Cin; pk.C = d->Cout;
+    pk.Kld = (int)rsp_align_up((size_t)g.nt * g.nh * g.nw * d->Cout, 4);
+    pk.nTd = g.nt; pk.nTh = g.nh; pk.nTw = g.nw;
+    pk.k0d = g.k0t; pk.k0h = g.k0h; pk.k0w = g.k0w;
+    pk.kstepd = d->sT; pk.ksteph = d->sH; pk.kstepw = d->sW;
+    {
+      const long long total = (long long)pk.O * pk.Kld;
+      const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+      hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, pk);
+      int rc = rsp_check_launch("pack_weight_kernel(dgrad)");
+      if (rc != RSP_OK) return rc;
+    }
+
+    IgemmParams p;
+    memset(&p, 0, sizeof p);
+    p.x = dy; p.w = pk.out; p.bias = nullptr; p.y = dx; p.stat = nullptr;
+    p.M = d->N * g.Gd * g.Gh * g.Gw;
+    p.Gd = g.Gd; p.Gh = g.Gh; p.Gw = g.Gw;
+    p.oDm = d->Di; p.oHm = d->Hi; p.oWm = d->Wi;
+    p.oSd = d->sT; p.oSh = d->sH; p.oSw = d->sW;
+    p.oOd = g.rt; p.oOh = g.rh; p.oOw = g.rw;
+    p.out_ld = d->in_ld; p.Cout = d->Cin;
+    p.Di = d->Do; p.Hi = d->Ho; p.Wi = d->Wo; p.in_ld = d->out_ld; p.Cin = d->Cout;
+    p.sD = p.sH = p.sW = 1;
+    p.nTd = g.nt; p.nTh = g.nh; p.nTw = g.nw;
+    // tap a (kernel index k = k0 + a*s) reads dy at  g + (r + p - k)/s  =  g + off0 - a
+    p.off0d = (g.rt + d->pT - g.k0t) / d->sT;
+    p.off0h = (g.rh + d->pH - g.k0h) / d->sH;
+    p.off0w = (g.rw + d->pW - g.k0w) / d->sW;
+    p.offstep = -1;
+    p.K = g.nt * g.nh * g.nw * d->Cout;
+    p.Kld = pk.Kld;
+    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy);
+    int rc = run_igemm(p, vec4, part, part_bytes, s);
+    if (rc != RSP_OK) return rc;
+    woff += (size_t)pk.O * pk.Kld;
+  }
+  return RSP_OK;
+}
+
+}  // extern "C"

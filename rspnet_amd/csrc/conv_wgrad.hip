@@ -1,0 +1,391 @@
+// Weight gradient of nn.Conv3d on the exact-fp32 matrix pipe (autograd conv backward-weight for every conv of
+// the query encoder; reference trigger: loss.backward(), pretrain.py:164).
+//
+//   dW[co, k] = sum_rows dy[row, co] * im2col(x)[row, k],   k = tap*Cin + ci
+//
+// GEMM view: M' = Cout, N' = K = taps*Cin, reduction over rows = N*Do*Ho*Wo output positions.  Both operands have
+// the reduction index as their slow (row) dimension, so LDS tiles are [row][co] and [row][k]; an MFMA fragment is
+// a ds_read_b32 with 32 consecutive lanes on 32 consecutive floats (conflict-free).
+// The row range is split over grid.y; slabs [split][Cout][Kld] are summed in a fixed order by a second kernel
+// that also transposes to the reference layout (Cout,Cin,kT,kH,kW) => bitwise run-to-run reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr int RK = 32;  // rows per chunk
+constexpr int MAX_TAPS = 343;
+
+struct WgradParams {
+  const float* __restrict__ x;
+  const float* __restrict__ dy;
+  float* __restrict__ partial;  // [splitm][Cout][Kld]
+  int M, Gd, Gh, Gw;            // output grid (rows)
+  int Di, Hi, Wi, in_ld, Cin;
+  int sD, sH, sW;
+  int kT, kH, kW, pT, pH, pW;
+  int dy_ld, Cout;
+  int K, Kld;
+  int rows_per_split, splitm;
+  int co_tiles, k_tiles;
+};
+
+struct RowPos {
+  int n, gd, gh, gw;
+};
+
+__device__ __forceinline__ void advance(RowPos& r, int step, int Gd, int Gh, int Gw) {
+  r.gw += step;
+  while (r.gw >= Gw) {
+    r.gw -= Gw;
+    if (++r.gh >= Gh) {
+      r.gh = 0;
+      if (++r.gd >= Gd) {
+        r.gd = 0;
+        ++r.n;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VECA, bool VECB>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int ACOLS = BM / 4, BCOLS = BN / 4;            // float4 columns per tile row
+  constexpr int AROWS_PER_PASS = 256 / ACOLS, BROWS_PER_PASS = 256 / BCOLS;
+  constexpr int AR = RK / AROWS_PER_PASS, BR = RK / BROWS_PER_PASS;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* At = reinterpret_cast<float*>(smem_raw);  // [2][RK][BM]
+  float* Bt = At + 2 * RK * BM;                    // [2][RK][BN]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tile = rsp_xcd_remap(blockIdx.x, gridDim.x);
+  const int co_tile = tile / p.k_tiles, k_tile = tile - co_tile * p.k_tiles;
+  const int co0 = co_tile * BM, k0 = k_tile * BN;
+  const int z = blockIdx.y;
+  const int row_begin = z * p.rows_per_split;
+  const int row_end = min(p.M, row_begin + p.rows_per_split);
+
+  // ---- A side (dy): thread -> 4 consecutive co, AR rows --------------------------------------------------------
+  const int acol = (t % ACOLS) * 4, arow = t / ACOLS;
+  const int aco = co0 + acol;
+  // ---- B side (im2col x): thread -> 4 consecutive k, BR rows ----------------------------------------------------
+  const int bcol = (t % BCOLS) * 4, brow = t / BCOLS;
+  int boffd[VECB ? 1 : 4], boffh[VECB ? 1 : 4], boffw[VECB ? 1 : 4], bdelta[VECB ? 1 : 4];
+  bool bok[VECB ? 1 : 4];
+#pragma unroll
+  for (int e = 0; e < (VECB ? 1 : 4); ++e) {
+    const int k = k0 + bcol + e;
+    bok[e] = k < p.K;
+    const int kk = bok[e] ? k : 0;
+    const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
+    const int kw = tap % p.kW, q = tap / p.kW;
+    const int kh = q % p.kH, kt = q / p.kH;
+    boffd[e] = kt - p.pT;
+    boffh[e] = kh - p.pH;
+    boffw[e] = kw - p.pW;
+    bdelta[e] = ((boffd[e] * p.Hi + boffh[e]) * p.Wi + boffw[e]) * p.in_ld + ci;
+  }
+  RowPos bpos[BR];
+  {
+    const int r = row_begin + brow;
+    RowPos r0;
+    r0.gw = r % p.Gw;
+    int q = r / p.Gw;
+    r0.gh = q % p.Gh;
+    q /= p.Gh;
+    r0.gd = q % p.Gd;
+    r0.n = q / p.Gd;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      bpos[i] = r0;
+      advance(r0, BROWS_PER_PASS, p.Gd, p.Gh, p.Gw);
+    }
+  }
+
+  floatx4 areg[AR], breg[BR];
+
+  auto load_chunk = [&](int rbase) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int r = rbase + arow + i * AROWS_PER_PASS;
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < row_end) {
+        const float* src = p.dy + (long long)r * p.dy_ld + aco;
+        if (VECA) {
+          if (aco < p.Cout) v = *reinterpret_cast<const floatx4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (aco + e < p.Cout) v[e] = src[e];
+        }
+      }
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int r = rbase + brow + i * BROWS_PER_PASS;
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < row_end) {
+        const RowPos& rp = bpos[i];
+        const int id0 = rp.gd * p.sD, ih0 = rp.gh * p.sH, iw0 = rp.gw * p.sW;
+        const long long base = ((((long long)rp.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0) * p.in_ld;
+        if (VECB) {
+          const int id = id0 + boffd[0], ih = ih0 + boffh[0], iw = iw0 + boffw[0];
+          if (bok[0] && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+            v = *reinterpret_cast<const floatx4*>(p.x + base + bdelta[0]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int id = id0 + boffd[e], ih = ih0 + boffh[e], iw = iw0 + boffw[e];
+            if (bok[e] && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+              v[e] = p.x[base + bdelta[e]];
+          }
+        }
+      }
+      breg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) advance(bpos[i], RK, p.Gd, p.Gh, p.Gw);
+  };
+  auto store_chunk = [&](int buf) {
+    float* a = At + buf * RK * BM;
+    float* b = Bt + buf * RK * BN;
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      *reinterpret_cast<floatx4*>(a + (arow + i * AROWS_PER_PASS) * BM + acol) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      *reinterpret_cast<floatx4*>(b + (brow + i * BROWS_PER_PASS) * BN + bcol) = breg[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (row_begin < row_end) {
+    load_chunk(row_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int rb = row_begin; rb < row_end; rb += RK) {
+    const bool more = rb + RK < row_end;
+    if (more) load_chunk(rb + RK);
+    const float* a = At + buf * RK * BM + wm * WM + l32;
+    const float* b = Bt + buf * RK * BN + wn * WN + l32;
+#pragma unroll
+    for (int s = 0; s < RK / 2; ++s) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = a[(2 * s + h) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = b[(2 * s + h) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  float* dst = p.partial + (long long)z * p.Cout * p.Kld;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int k = k0 + wn * WN + j * 32 + l32;
+    if (k < p.Kld) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = co0 + wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
+          if (co < p.Cout) dst[(long long)co * p.Kld + k] = acc[i][j][e];
+        }
+    }
+  }
+}
+
+// dw_ref[co][ci][tap] = sum_z partial[z][co][tap*Cin + ci]   (fixed summation order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int splitm, int Cout,
+                                    int Cin, int taps, int Kld) {
+  const long long total = (long long)Cout * taps * Cin;
+  const long long slab = (long long)Cout * Kld;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int K = taps * Cin;
+    const int co = (int)(i / K);
+    const int k = (int)(i - (long long)co * K);
+    const int tap = k / Cin, ci = k - tap * Cin;
+    const float* src = partial + (long long)co * Kld + k;
+    float s = 0.f;
+    for (int z = 0; z < splitm; ++z) s += src[z * slab];
+    dw[((long long)co * Cin + ci) * taps + tap] = s;
+  }
+}
+
+// Column sums of a [rows][C] (pitch ld) matrix, two deterministic stages.
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a, long long rows, int C, int ld,
+                                                     float* __restrict__ part, int rows_per_block) {
+  // block (bx = row slab, by = 64-channel group); thread = (row lane 0..3, channel 0..63)
+  __shared__ float red[4][64];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  if (c < C)
+    for (long long r = r0 + rl; r < r1; r += 4) s += a[r * ld + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) part[(long long)blockIdx.x * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_stage2(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * C + c];
+  out[c] = (float)s;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VECA, bool VECB>
+int launch_w(const WgradParams& p, hipStream_t s) {
+  const size_t lds = (size_t)2 * RK * (BM + BN) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, WAVES_M, WAVES_N, VECA, VECB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.co_tiles * p.k_tiles, p.splitm);
+  hipLaunchKernelGGL((wgrad_kernel<BM, BN, WAVES_M, WAVES_N, VECA, VECB>), grid, dim3(256), lds, s, p);
+  return rsp_check_launch("wgrad_kernel");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_w_vec(const WgradParams& p, bool va, bool vb, hipStream_t s) {
+  if (va && vb) return launch_w<BM, BN, WAVES_M, WAVES_N, true, true>(p, s);
+  if (va) return launch_w<BM, BN, WAVES_M, WAVES_N, true, false>(p, s);
+  if (vb) return launch_w<BM, BN, WAVES_M, WAVES_N, false, true>(p, s);
+  return launch_w<BM, BN, WAVES_M, WAVES_N, false, false>(p, s);
+}
+
+bool wdesc_ok(const rsp_conv3d_desc* d) {
+  if (!d) return false;
+  if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return false;
+  if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->kT * d->kH * d->kW > MAX_TAPS) return false;
+  if (d->sT <= 0 || d->sH <= 0 || d->sW <= 0 || d->pT < 0 || d->pH < 0 || d->pW < 0) return false;
+  if (d->Do != (d->Di + 2 * d->pT - d->kT) / d->sT + 1) return false;
+  if (d->Ho != (d->Hi + 2 * d->pH - d->kH) / d->sH + 1) return false;
+  if (d->Wo != (d->Wi + 2 * d->pW - d->kW) / d->sW + 1) return false;
+  if (d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) return false;
+  if (d->in_ld < d->Cin || d->out_ld < d->Cout) return false;
+  if ((long long)d->N * d->Do * d->Ho * d->Wo >= (1ll << 31)) return false;
+  return true;
+}
+
+struct WPlan {
+  int bm, bn, co_tiles, k_tiles, splitm, rows_per_split, Kld;
+  size_t partial_bytes, colsum_bytes;
+};
+
+WPlan wplan(const rsp_conv3d_desc* d) {
+  WPlan w;
+  const long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
+  const int K = d->kT * d->kH * d->kW * d->Cin;
+  w.Kld = (int)rsp_align_up((size_t)K, 4);
+  w.bm = d->Cout > 64 ? 128 : 64;
+  w.bn = K > 64 ? 128 : 64;
+  w.co_tiles = rsp_cdiv(d->Cout, w.bm);
+  w.k_tiles = rsp_cdiv(K, w.bn);
+  const int tiles = w.co_tiles * w.k_tiles;
+  long long sp = rsp_cdiv(1536, tiles);
+  const long long max_sp = M / 256 > 0 ? M / 256 : 1;
+  if (sp > max_sp) sp = max_sp;
+  if (sp < 1) sp = 1;
+  long long rps = (M + sp - 1) / sp;
+  rps = (rps + RK - 1) / RK * RK;
+  w.rows_per_split = (int)rps;
+  w.splitm = (int)((M + rps - 1) / rps);
+  w.partial_bytes = rsp_align_up((size_t)w.splitm * d->Cout * w.Kld * sizeof(float), 256);
+  w.colsum_bytes = rsp_align_up((size_t)rsp_cdiv(M, 1024) * d->Cout * sizeof(float), 256);
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d) {
+  if (!wdesc_ok(d)) return 0;
+  const WPlan w = wplan(d);
+  return w.partial_bytes + w.colsum_bytes;
+}
+
+int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(wdesc_ok(d), "rsp_conv3d_wgrad: bad descriptor");
+  RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad: null pointer");
+  RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_wgrad: workspace must be 16-byte aligned");
+  const WPlan w = wplan(d);
+  if (workspace_bytes < w.partial_bytes + w.colsum_bytes) {
+    rsp_set_error("rsp_conv3d_wgrad: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  WgradParams p;
+  memset(&p, 0, sizeof p);
+  p.x = x; p.dy = dy; p.partial = reinterpret_cast<float*>(workspace);
+  p.M = d->N * d->Do * d->Ho * d->Wo;
+  p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
+  p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.in_ld = d->in_ld; p.Cin = d->Cin;
+  p.sD = d->sT; p.sH = d->sH; p.sW = d->sW;
+  p.kT = d->kT; p.kH = d->kH; p.kW = d->kW; p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
+  p.dy_ld = d->out_ld; p.Cout = d->Cout;
+  p.K = d->kT * d->kH * d->kW * d->Cin;
+  p.Kld = w.Kld;
+  p.rows_per_split = w.rows_per_split; p.splitm = w.splitm;
+  p.co_tiles = w.co_tiles; p.k_tiles = w.k_tiles;
+  const bool va = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy);
+  const bool vb = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x);
+  int rc;
+  if (w.bm == 128 && w.bn == 128) rc = launch_w_vec<128, 128, 2, 2>(p, va, vb, s);
+  else if (w.bm == 128) rc = launch_w_vec<128, 64, 2, 2>(p, va, vb, s);
+  else if (w.bn == 128) rc = launch_w_vec<64, 128, 2, 2>(p, va, vb, s);
+  else rc = launch_w_vec<64, 64, 2, 2>(p, va, vb, s);
+  if (rc != RSP_OK) return rc;
+  {
+    const long long total = (long long)d->Cout * p.K;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, dw_ref, p.splitm, d->Cout, d->Cin,
+                       d->kT * d->kH * d->kW, p.Kld);
+    rc = rsp_check_launch("wgrad_reduce_kernel");
+    if (rc != RSP_OK) return rc;
+  }
+  if (dbias) {
+    float* part = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + w.partial_bytes);
+    const int nblk = rsp_cdiv(p.M, 1024);
+    hipLaunchKernelGGL(colsum_stage1, dim3(nblk, rsp_cdiv(d->Cout, 64)), dim3(256), 0, s, dy, (long long)p.M, d->Cout,
+                       d->out_ld, part, 1024);
+    rc = rsp_check_launch("colsum_stage1");
+    if (rc != RSP_OK) return rc;
+    hipLaunchKernelGGL(colsum_stage2, dim3(rsp_cdiv(d->Cout, 256)), dim3(256), 0, s, part, nblk, d->Cout, dbias);
+    rc = rsp_check_launch("colsum_stage2");
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// Step glue: clip speed sub-sampling + layout change, momentum update, SGD, row gather.
+// Reference call sites: moco/builder_diffspeed_diffloss.py:421-443 (_diff_speed), :384-387 (shuffle select),
+// :337-343 (momentum), :389-406 (un-shuffle), pretrain.py:65-72,165 (torch.optim.SGD).  All HBM-bound streaming kernels.
+#include "common.h"
+
+namespace {
+
+// out[j][t][h][w][c] = im[src[j]][c][t*step[j]][h][w]      (NCDHW in, NDHWC out)
+__global__ __launch_bounds__(256) void clip_gather_kernel(const float* __restrict__ im, int C, int T_in, int H, int W,
+                                                          const int* __restrict__ src, const int* __restrict__ step,
+                                                          int B_out, int T_out, float* __restrict__ out) {
+  const long long hw = (long long)H * W;
+  const long long total = (long long)B_out * T_out * hw;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const long long p = i % hw;
+    const long long q = i / hw;
+    const int t = (int)(q % T_out);
+    const int j = (int)(q / T_out);
+    const int b = src[j];
+    const int tin = t * step[j];
+    const float* s = im + (((long long)b * C) * T_in + tin) * hw + p;
+    float* o = out + i * C;
+    for (int c = 0; c < C; ++c) o[c] = s[(long long)c * T_in * hw];
+  }
+}
+
+__global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ k, const float* __restrict__ q, long long n,
+                                                       float m) {
+  const float om = 1.f - m;
+  const long long n4 = n >> 2;
+  floatx4* k4 = reinterpret_cast<floatx4*>(k);
+  const floatx4* q4 = reinterpret_cast<const floatx4*>(q);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += 256ll * gridDim.x) {
+    floatx4 a = k4[i];
+    const floatx4 b = q4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = a[e] * m + b[e] * om;   // param_k*m + param_q*(1-m): two roundings, as the reference
+    k4[i] = a;
+  }
+  for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x)
+    k[i] = k[i] * m + q[i] * om;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, long long n, float lr, float mu, float wd,
+                                                  float gscale, int first) {
+  const long long n4 = n >> 2;
+  floatx4* p4 = reinterpret_cast<floatx4*>(p);
+  const floatx4* g4 = reinterpret_cast<const floatx4*>(g);
+  floatx4* b4 = reinterpret_cast<floatx4*>(buf);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += 256ll * gridDim.x) {
+    floatx4 pp = p4[i];
+    const floatx4 gg = g4[i];
+    floatx4 bb = first ? floatx4{0.f, 0.f, 0.f, 0.f} : b4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = gg[e] * gscale + wd * pp[e];
+      bb[e] = first ? d : bb[e] * mu + d;
+      pp[e] = pp[e] - lr * bb[e];
+    }
+    b4[i] = bb;
+    p4[i] = pp;
+  }
+  for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+    const float d = g[i] * gscale + wd * p[i];
+    const float b = first ? d : buf[i] * mu + d;
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+  }
+}
+
+__global__ void rows_gather_kernel(const float* __restrict__ in, const int* __restrict__ idx, int n, int width,
+                                   float* __restrict__ out) {
+  const long long total = (long long)n * width;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / width), c = (int)(i - (long long)j * width);
+    out[i] = in[(long long)idx[j] * width + c];
+  }
+}
+
+int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsp_clip_gather(const float* im, int32_t B_in, int32_t C, int32_t T_in, int32_t H, int32_t W, const int32_t* src,
+                    const int32_t* step, int32_t B_out, int32_t T_out, float* out, void* stream) {
+  RSP_REQUIRE(im && src && step && out, "rsp_clip_gather: null pointer");
+  RSP_REQUIRE(B_in > 0 && C > 0 && T_in > 0 && H > 0 && W > 0 && B_out > 0 && T_out > 0, "rsp_clip_gather: bad size");
+  const long long total = (long long)B_out * T_out * H * W;
+  hipLaunchKernelGGL(clip_gather_kernel, dim3(grid_for(total) * 2), dim3(256), 0, (hipStream_t)stream, im, C, T_in, H, W, src,
+                     step, B_out, T_out, out);
+  return rsp_check_launch("clip_gather_kernel");
+}
+
+int rsp_momentum_update(float* k, const float* q, int64_t n, float m, void* stream) {
+  RSP_REQUIRE(k && q && n > 0, "rsp_momentum_update: bad argument");
+  RSP_REQUIRE(rsp_aligned16(k) && rsp_aligned16(q), "rsp_momentum_update: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, k, q, (long long)n, m);
+  return rsp_check_launch("momentum_kernel");
+}
+
+int rsp_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float wd, float gscale, int first,
+                 void* stream) {
+  RSP_REQUIRE(p && g && buf && n > 0, "rsp_sgd_step: bad argument");
+  RSP_REQUIRE(rsp_aligned16(p) && rsp_aligned16(g) && rsp_aligned16(buf), "rsp_sgd_step: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long long)n, lr, mu,
+                     wd, gscale, first);
+  return rsp_check_launch("sgd_kernel");
+}
+
+int rsp_rows_gather(const float* in, const int32_t* idx, int32_t n, int32_t width, float* out, void* stream) {
+  RSP_REQUIRE(in && idx && out && n > 0 && width > 0, "rsp_rows_gather: bad argument");
+  hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for((long long)n * width)), dim3(256), 0, (hipStream_t)stream, in, idx, n,
+                     width, out);
+  return rsp_check_launch("rows_gather_kernel");
+}
+
+}  // extern "C"

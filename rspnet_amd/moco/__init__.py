@@ -1,0 +1,67 @@
+"""ModelFactory for the pretext model — same config keys as /root/reference/moco/__init__.py:14-55."""
+import torch
+from torch import distributed as dist
+from torch import nn
+
+from ..models import get_model_class
+from .builder_diffspeed_diffloss import Loss, MoCoDiffLossTwoFc
+from .split_wrapper import MultiTaskWrapper
+
+
+def _get(cfg, dotted, default=None):
+    """Read 'a.b' from a pyhocon ConfigTree (get) or a plain nested dict (the build ships resolved JSON)."""
+    if hasattr(cfg, "get_config") or hasattr(cfg, "get_string"):
+        return cfg.get(dotted, default)
+    cur = cfg
+    for part in dotted.split("."):
+        if not isinstance(cur, dict) or part not in cur:
+            return default
+        cur = cur[part]
+    return cur
+
+
+class DataParallelPretext(nn.Module):
+    """Stands where the reference wraps the model in DistributedDataParallel (moco/__init__.py:49-53): exposes
+    `.module`, forwards calls, and makes rank 0's initial parameters/buffers global (DDP constructor broadcast).
+    Gradient averaging happens inside the model's own backward (bucketed RCCL all-reduce over the flat gradient
+    buffer); BN running statistics stay rank-local and rank 0's are what checkpoints see, as in the reference."""
+
+    def __init__(self, module: MoCoDiffLossTwoFc):
+        super().__init__()
+        self.module = module
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            module._prepare()
+            with torch.no_grad():
+                dist.broadcast(module._flat.q_flat, src=0)
+                dist.broadcast(module._flat.k_flat, src=0)
+                for b in module.buffers():
+                    dist.broadcast(b, src=0)
+            module._state_loaded()
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+class ModelFactory:
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def build_moco_diffloss(self, device=None):
+        moco_dim = int(_get(self.cfg, "moco.dim"))
+        moco_t = float(_get(self.cfg, "moco.t"))
+        moco_k = int(_get(self.cfg, "moco.k"))
+        moco_m = float(_get(self.cfg, "moco.m"))
+        moco_fc_type = str(_get(self.cfg, "moco.fc_type"))
+        moco_diff_speed = list(_get(self.cfg, "moco.diff_speed"))
+        base_model_class = get_model_class(**dict(_get(self.cfg, "model")))
+
+        def model_class(num_classes=128):
+            return MultiTaskWrapper(base_model_class, num_classes=num_classes, fc_type=moco_fc_type, finetune=False,
+                                    groups=1)
+
+        model = MoCoDiffLossTwoFc(model_class, dim=moco_dim, K=moco_k, m=moco_m, T=moco_t, diff_speed=moco_diff_speed)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if device is not None:
+            model.to(device)
+        return DataParallelPretext(model)

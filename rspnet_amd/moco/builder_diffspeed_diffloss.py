@@ -1,0 +1,304 @@
+"""MoCo-style two-branch pretext model with relative-speed + appearance heads (RSPNet), MI355X-native.
+
+Same module surface as /root/reference/moco/builder_diffspeed_diffloss.py:263-547 (`Loss`, `MoCoDiffLossTwoFc`):
+constructor arguments, forward signature / return structure, state-dict keys, side effects (momentum update before
+the key passes, two train-mode key passes, queue enqueue of k_neg_A).  What differs is the machinery:
+
+* one autograd node wraps the whole query encoder; its backward walks the layer plan with HIP kernels and writes
+  straight into a flat gradient buffer (rspnet_amd/flat.py), launching bucketed RCCL all-reduces as it goes;
+* shuffle-BN is a clip all-to-all over xGMI (each clip has exactly one destination rank) instead of the reference's
+  all-gather + select (:361-387); the permutation travels host-side, so no device sync is needed;
+* the feature un-shuffle (:389-406) and the queue's key all-gather (:348) share ONE small all-gather per key pass;
+* queue_ptr is mirrored on the host (the reference reads it back with int(), :352, every step).
+"""
+from __future__ import annotations
+
+import random
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .. import ops as _ops
+from ..flat import FlatEncoderPair
+
+BUCKET_FLOATS = 8 << 20  # 32 MiB gradient buckets: few large xGMI collectives
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, l1, l2, lp, ln, margin, A, M):
+        losses, d1, d2, dp, dn = _ops.backend().loss_fwd_bwd(l1.contiguous(), l2.contiguous(), lp.contiguous(),
+                                                             ln.contiguous(), margin, A, M)
+        ctx.save_for_backward(d1, d2, dp, dn)
+        return losses[0], losses[1], losses[2]
+
+    @staticmethod
+    def backward(ctx, g, gA, gM):
+        d1, d2, dp, dn = ctx.saved_tensors
+        # loss_A / loss_M are reporting outputs (pretrain.py:160-195 only logs them); gradients flow through `loss`.
+        return d1 * g, d2 * g, dp * g, dn * g, None, None, None
+
+
+class Loss(nn.Module):
+    """A*(CE(logits1,0)+CE(logits2,0)) + M*MarginRanking(l_pos_M, l_neg_M; margin)  (reference :263-283).
+
+    The reference passes (B,1),(B,1) inputs with a (B,) target to nn.MarginRankingLoss; under its pinned torch 1.6 that
+    evaluates to mean_i max(0, margin - (l_pos_M[i] - l_neg_M[i])) — that value and gradient are
+    what the kernel computes.  `target` must be all zeros and `ranking_target` all ones, as the model produces them.
+    """
+
+    def __init__(self, margin=1.0, A: float = 1.0, M: float = 1.0):
+        super().__init__()
+        self.margin, self.A, self.M = float(margin), float(A), float(M)
+
+    def forward(self, output: Tuple[Tensor, Tensor], target: Tensor, ranking_logits: Tuple[Tensor, Tensor],
+                ranking_target: Tensor):
+        loss, ce, ranking = _LossFn.apply(output[0], output[1], ranking_logits[0], ranking_logits[1], self.margin,
+                                          self.A, self.M)
+        return loss, ce.detach(), ranking.detach()
+
+
+class _PretextFn(torch.autograd.Function):
+    """Query-encoder forward + logits as one autograd node (parameters are listed as inputs only so that autograd
+    routes the backward call here; their gradients are written directly into the flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, model: "MoCoDiffLossTwoFc", x_q: Tensor, keys, *params):
+        be = _ops.backend()
+        with torch.no_grad():
+            q_A, q_M, ectx = model.encoder_q.forward_ndhwc(x_q, keep=True)
+            k_A, k_M, kneg_A, kneg_M = keys
+            queue = model.queue
+            l1, l2, lp, ln = be.logits_fwd(q_A, q_M, k_A, k_M, kneg_A, kneg_M, queue, 1.0 / model.T)
+        ctx.model, ctx.ectx = model, ectx
+        # the queue is overwritten by the enqueue right after forward: backward needs this step's copy (the reference
+        # clones it too, :525)
+        ctx.keys = (k_A, k_M, kneg_A, kneg_M, queue.clone())
+        model._last_q = (q_A, q_M)
+        return l1, l2, lp, ln
+
+    @staticmethod
+    def backward(ctx, dl1, dl2, dlp, dln):
+        model = ctx.model
+        be = _ops.backend()
+        k_A, k_M, kneg_A, kneg_M, queue = ctx.keys
+        dev = queue.device
+
+        def z(g, like_shape):
+            return torch.zeros(like_shape, dtype=torch.float32, device=dev) if g is None else g.contiguous()
+
+        B, K = k_A.shape[0], queue.shape[1]
+        dqA, dqM = be.logits_bwd(z(dl1, (B, K + 1)), z(dl2, (B, K + 1)), z(dlp, (B, 1)), z(dln, (B, 1)), k_A, k_M,
+                                 kneg_A, kneg_M, queue, 1.0 / model.T)
+        model._backward_encoder_q(ctx.ectx, dqA, dqM)
+        ctx.ectx = None
+        return (None, None, None) + (None,) * len(model._q_params)
+
+
+class MoCoDiffLossTwoFc(nn.Module):
+    def __init__(self, base_encoder, dim=128, K=65536, m=0.999, T=0.07, mlp=False,
+                 diff_speed: Optional[List[int]] = None):
+        super().__init__()
+        self.K, self.m, self.T = K, m, T
+        self.diff_speed = diff_speed
+        self.encoder_q = base_encoder(num_classes=dim)
+        self.encoder_k = base_encoder(num_classes=dim)
+        if mlp:
+            raise NotImplementedError("mlp=True: never set by ModelFactory (moco/__init__.py:39-46)")
+        for param_q, param_k in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            param_k.data.copy_(param_q.data)
+            param_k.requires_grad = False
+        self.register_buffer("queue", nn.functional.normalize(torch.randn(dim, K), dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.alpha = 0.5
+        assert self.diff_speed is not None, "This branch is for diff speed"
+
+        self._flat: Optional[FlatEncoderPair] = None
+        self._q_params: List[nn.Parameter] = []
+        self._ptr_host: Optional[int] = None
+        self._cpu_group = None
+        self._last_q = None
+        self._pending = []
+        self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
+
+    # ---- state ----------------------------------------------------------------------------------------------------
+    def _state_loaded(self):
+        self._ptr_host = None
+        self.encoder_q.weights_changed()
+        self.encoder_k.weights_changed()
+
+    def _prepare(self):
+        if self._flat is None:
+            self._flat = FlatEncoderPair(self.encoder_q, self.encoder_k, self.encoder_q.untrained_prefixes())
+            self._q_params = list(self.encoder_q.parameters())
+        self._flat.ensure()
+        self._tie_num_batches_tracked()
+
+    def _tie_num_batches_tracked(self):
+        """All BN step counters of one encoder share one int64 buffer so a key/query pass bumps them with one add."""
+        for enc, attr in ((self.encoder_q, "_nbt_q"), (self.encoder_k, "_nbt_k")):
+            bns = [mod for mod in enc.modules() if isinstance(mod, nn.modules.batchnorm._BatchNorm)]
+            flat = getattr(self, attr, None)
+            dev = self.queue.device
+            ok = flat is not None and flat.device == dev and all(
+                b.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, b in enumerate(bns))
+            if ok:
+                continue
+            flat = torch.stack([b.num_batches_tracked.to(dev) for b in bns]) if bns else torch.zeros(0, dtype=torch.long,
+                                                                                                      device=dev)
+            for i, b in enumerate(bns):
+                b._buffers["num_batches_tracked"] = flat[i]
+            object.__setattr__(self, attr, flat)
+
+    # ---- reference-named pieces -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        """:337-343 on the flat buffers (params only; BN buffers of encoder_k evolve by its own forwards)."""
+        _ops.backend().momentum_update(self._flat.k_flat, self._flat.q_flat, self.m)
+        self.encoder_k.weights_changed()
+
+    def _cpu_pg(self):
+        if self._cpu_group is None:
+            backend = dist.get_backend()
+            self._cpu_group = dist.new_group(backend="gloo") if backend != "gloo" else dist.group.WORLD
+        return self._cpu_group
+
+    def _draw_shuffle(self, n: int) -> np.ndarray:
+        """idx_shuffle: drawn on the CPU by every rank, rank 0's wins (:372-378) — exchanged host-side."""
+        idx = torch.randperm(n)
+        rank, ws = _world()
+        if ws > 1:
+            dist.broadcast(idx, src=0, group=self._cpu_pg())
+        return idx.numpy().astype(np.int64)
+
+    @torch.no_grad()
+    def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int):
+        """Key pass with shuffle-BN (:408-419).  Returns (features of my samples in my order (B,2*dim),
+        features of ALL samples in global order (B*ws, 2*dim))."""
+        be = _ops.backend()
+        rank, ws = _world()
+        B = im.shape[0]
+        dev = im.device
+        idx = self._draw_shuffle(B * ws)
+        G = idx.reshape(ws, B)
+        owner = G // B
+        if ws == 1:
+            src = torch.from_numpy(idx.astype(np.int32)).to(dev, non_blocking=True)
+            x = be.clip_gather(im, src, step[src.long()].contiguous(), T_out)
+        else:
+            send_src, in_splits = [], []
+            for r in range(ws):
+                mine = G[r][owner[r] == rank] - rank * B
+                send_src.append(mine)
+                in_splits.append(int(mine.size))
+            send_src = np.concatenate(send_src).astype(np.int32)
+            out_splits = [int((owner[rank] == s).sum()) for s in range(ws)]
+            src = torch.from_numpy(send_src).to(dev, non_blocking=True)
+            xs = be.clip_gather(im, src, step[src.long()].contiguous(), T_out)
+            x = torch.empty_like(xs)
+            dist.all_to_all_single(x, xs, out_splits, in_splits)
+        self._nbt_k += 1
+        a, m, _ = self.encoder_k.forward_ndhwc(x, keep=False)
+        feats = torch.cat([a, m], dim=1)
+        # where does global sample g end up?  rank r = position(g)//B; inside r's batch, clips arrive ordered by
+        # source rank, then by their order in G[r]
+        loc = np.empty(B * ws, dtype=np.int64)
+        for r in range(ws):
+            order = np.argsort(owner[r], kind="stable")
+            loc[G[r][order]] = r * B + np.arange(B)
+        if ws > 1:
+            gathered = torch.empty((B * ws, feats.shape[1]), dtype=feats.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, feats)
+        else:
+            gathered = feats
+        loc_t = torch.from_numpy(loc.astype(np.int32)).to(dev, non_blocking=True)
+        all_feats = be.rows_gather(gathered, loc_t)
+        return all_feats[rank * B:(rank + 1) * B], all_feats
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys_all: Tensor):
+        """:345-359 — keys_all is already the rank-ordered concat of k_neg_A over all ranks."""
+        n = keys_all.shape[0]
+        if self._ptr_host is None:
+            self._ptr_host = int(self.queue_ptr)
+        ptr = self._ptr_host
+        assert self.K % n == 0  # for simplicity (reference :353)
+        _ops.backend().queue_enqueue(self.queue, ptr, keys_all.contiguous())
+        ptr = (ptr + n) % self.K
+        self._ptr_host = ptr
+        self.queue_ptr.fill_(ptr)
+
+    # ---- backward of the query encoder -------------------------------------------------------------------------------
+    def _backward_encoder_q(self, ectx, dqA, dqM):
+        """Backward of encoder_q into the flat gradient buffer; with >1 rank, each 32 MiB bucket's all-reduce is
+        launched as soon as the layer that completes it has run (RCCL works on its own stream under the rest of the
+        backward), then gradients are averaged as DDP does (moco/__init__.py:49-53)."""
+        flat = self._flat
+        _, ws = _world()
+        buckets = flat.buckets(BUCKET_FLOATS) if ws > 1 else []
+        handed_out, launched, handles = set(), set(), []
+
+        def grad_of(p):
+            handed_out.add(id(p))
+            return flat.grad_of(p)
+
+        def after(_node_index):
+            # runs after each plan node: every gradient view handed out so far has been written (same stream)
+            for bi, (s, e, ids) in enumerate(buckets):
+                if bi not in launched and all(pid in handed_out for pid in ids):
+                    launched.add(bi)
+                    handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
+
+        self.encoder_q.backward_ndhwc(ectx, dqA, dqM, grad_of, after)
+        for bi, (s, e, ids) in enumerate(buckets):
+            if bi not in launched:
+                handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
+        for h in handles:
+            h.wait()
+        if ws > 1:
+            flat.g_flat.mul_(1.0 / ws)
+        flat.attach_grads()
+
+    # ---- forward ------------------------------------------------------------------------------------------------------
+    def forward(self, im_q: Tensor, im_k: Tensor):
+        """im_q, im_k: (B, 3, T=speed*16, H, W) fp32 on this rank's device.  Returns
+        ((logits1, logits2), labels_A, (l_pos_M, l_neg_M), labels_M) exactly as the reference (:492-547)."""
+        be = _ops.backend()
+        self._prepare()
+        dev = im_q.device
+        B, C, T, H, W = im_q.shape
+        im_q, im_k = im_q.contiguous(), im_k.contiguous()
+        with torch.no_grad():
+            self._momentum_update_key_encoder()
+            # _diff_speed (:421-447)
+            random_indices = torch.randperm(B, device=dev)
+            n1 = int(B * self.alpha)
+            speed = random.choice(self.diff_speed)
+            T_real = T // speed
+            step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
+            step_q[random_indices[:n1].to(dev)] = 1                      # s1 rows play q,k at normal speed
+            step_kn = (1 + speed) - step_q if speed != 1 else step_q.clone()   # k_negative swaps the speeds
+            kneg_mine, kneg_all = self._forward_encoder_k(im_k, step_kn, T_real)
+            k_mine, _ = self._forward_encoder_k(im_k, step_q, T_real)
+            dim = kneg_mine.shape[1] // 2
+            k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
+            kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
+            src = torch.arange(B, dtype=torch.int32, device=dev)
+            x_q = be.clip_gather(im_q, src, step_q, T_real)
+            self._nbt_q += 1
+
+        l1, l2, lp, ln = _PretextFn.apply(self, x_q, (k_A, k_M, kneg_A, kneg_M), *self._q_params)
+
+        labels_A = torch.zeros(B, dtype=torch.long, device=dev)
+        labels_M = torch.ones_like(labels_A)
+        self._dequeue_and_enqueue(kneg_all[:, :dim])
+        return (l1, l2), labels_A, (lp, ln), labels_M

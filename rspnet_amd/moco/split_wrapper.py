@@ -1,0 +1,108 @@
+"""MultiTaskWrapper: backbone + two projection heads (A-VID, RSP), L2-normalised outputs.
+
+Mirror of /root/reference/moco/split_wrapper.py:66-190 for the pretext configuration (finetune=False, groups=1,
+fc_type 'linear').  Heads keep the reference's Sequential(pool, Flatten, Linear) container so the state-dict keys are
+``fc1.2.weight`` etc.; the pool+linear+normalize arithmetic is one HIP kernel (rsp_head_fwd).
+"""
+from typing import Callable
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops as _ops
+from ..engine import PackedWeights, run_backward, run_forward
+
+
+class Flatten(nn.Module):
+    def forward(self, x: Tensor):
+        return x.flatten(1)
+
+
+class MultiTaskWrapper(nn.Module):
+    def __init__(self, base_encoder: Callable[[int], nn.Module], num_classes: int = 128, finetune: bool = False,
+                 fc_type: str = "linear", groups: int = 1):
+        super().__init__()
+        if finetune:
+            raise NotImplementedError("finetune=True is the downstream path (finetune.py), outside the pretext hot path")
+        if groups != 1:
+            raise NotImplementedError("groups != 1 is not used by any shipped pretext config")
+        if fc_type != "linear":
+            raise NotImplementedError(f"fc_type '{fc_type}': only 'linear' (config/pretrain/moco-train-base.jsonnet:35)")
+        self.finetune = finetune
+        self.moco_dim = num_classes
+        self.num_classes = num_classes
+        self.groups = groups
+        self.fc_type = fc_type
+        self.feat = None
+
+        self.encoder = base_encoder(num_classes=1)
+        feat_dim = self._get_feat_dim(self.encoder)
+        self.fc1 = self._get_linear_fc(feat_dim, self.moco_dim)
+        self.fc2 = self._get_linear_fc(feat_dim, self.moco_dim)
+
+        self._plan = None
+        self._packed = PackedWeights()
+
+    # ---- reference surface -------------------------------------------------------------------------------------
+    @staticmethod
+    def _get_linear_fc(feat_dim: int, moco_dim: int):
+        return nn.Sequential(nn.AdaptiveAvgPool3d((1, 1, 1)), Flatten(), nn.Linear(feat_dim, moco_dim))
+
+    @staticmethod
+    def _get_feat_dim(encoder):
+        # split_wrapper.py:181-190: looks for fc / new_fc / classifier, else 512
+        for fc_name in ("fc", "new_fc", "classifier"):
+            if hasattr(encoder, fc_name):
+                return getattr(encoder, fc_name).in_features
+        return 512
+
+    def _get_last_feature(self):
+        return self.feat
+
+    def _get_fc_weight(self):
+        return self.fc1[2].weight.data, self.fc2[2].weight.data
+
+    def untrained_prefixes(self):
+        return tuple("encoder." + n + "." for n in getattr(self.encoder, "classifier_names", ()))
+
+    # ---- execution ---------------------------------------------------------------------------------------------
+    def plan(self):
+        if self._plan is None:
+            self._plan = self.encoder.plan()
+        return self._plan
+
+    def weights_changed(self):
+        self._packed.invalidate()
+
+    def forward_ndhwc(self, x: Tensor, keep: bool):
+        """x: (N,T,H,W,C).  Returns (x1, x2, ctx) — ctx is what backward_ndhwc needs (None when keep=False)."""
+        be = _ops.backend()
+        feat, ctx = run_forward(self.plan(), x, self._packed, keep)
+        self.feat = feat
+        l1, l2 = self.fc1[2], self.fc2[2]
+        x1, x2, pooled, raw = be.head_fwd(feat, l1.weight.data, l1.bias.data, l2.weight.data, l2.bias.data)
+        if keep:
+            ctx.head = (pooled, raw)
+        return x1, x2, ctx
+
+    def backward_ndhwc(self, ctx, d1: Tensor, d2: Tensor, grad_of, after_param_grads=None):
+        be = _ops.backend()
+        l1, l2 = self.fc1[2], self.fc2[2]
+        pooled, raw = ctx.head
+        dfeat = be.head_bwd(d1.contiguous(), d2.contiguous(), pooled, raw, l1.weight.data, l2.weight.data, ctx.feat_shape,
+                            grad_of(l1.weight), grad_of(l1.bias), grad_of(l2.weight), grad_of(l2.bias))
+        if after_param_grads is not None:
+            after_param_grads(-1)
+        run_backward(self.plan(), ctx, dfeat, grad_of, after_param_grads)
+
+    def forward(self, x: Tensor):
+        """Reference signature: x is NCDHW (B,3,T,H,W); returns the two unit-norm embeddings (no autograd here —
+        inside the pretext model gradients flow through MoCoDiffLossTwoFc's own autograd node)."""
+        be = _ops.backend()
+        B = x.shape[0]
+        src = torch.arange(B, dtype=torch.int32, device=x.device)
+        step = torch.ones(B, dtype=torch.int32, device=x.device)
+        xn = be.clip_gather(x.contiguous(), src, step, x.shape[2])
+        with torch.no_grad():
+            x1, x2, _ = self.forward_ndhwc(xn, keep=False)
+        return x1, x2

@@ -1,0 +1,314 @@
+"""Tensor-level gateway to the HIP kernels (one method per C-ABI entry point family).
+
+Activations are torch tensors of shape (N, D, H, W, C) (NDHWC, contiguous, fp32); torch is used only as the
+owner of device memory and of the current stream.  ``HipOps`` is the only product backend: it requires CUDA/HIP
+tensors and the built ``librspnet_hip.so`` and raises otherwise.  ``set_backend`` exists so that the host logic
+(graph executor, DDP exchange, optimizer) can be exercised by CPU tests with a checker backend living under
+``tests/``; nothing in this package ever selects another backend by itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    """Geometry of one nn.Conv3d application (groups=1, dilation=1)."""
+    N: int
+    Di: int
+    Hi: int
+    Wi: int
+    Cin: int
+    Cout: int
+    k: Tuple[int, int, int]
+    s: Tuple[int, int, int]
+    p: Tuple[int, int, int]
+
+    @property
+    def out_dims(self):
+        return tuple((i + 2 * p - k) // s + 1 for i, k, s, p in zip((self.Di, self.Hi, self.Wi), self.k, self.s, self.p))
+
+    @property
+    def rows(self):
+        d, h, w = self.out_dims
+        return self.N * d * h * w
+
+    def desc(self, in_ld=None, out_ld=None) -> _lib.ConvDesc:
+        do, ho, wo = self.out_dims
+        return _lib.ConvDesc(self.N, self.Di, self.Hi, self.Wi, self.Cin, do, ho, wo, self.Cout, *self.k, *self.s, *self.p,
+                             in_ld or self.Cin, out_ld or self.Cout)
+
+
+@dataclass(frozen=True)
+class PoolGeom:
+    """Geometry of the (optional) MaxPool3d fused behind BN+ReLU. k=s=(1,1,1), p=0 means no pooling."""
+    N: int
+    Di: int
+    Hi: int
+    Wi: int
+    C: int
+    k: Tuple[int, int, int] = (1, 1, 1)
+    s: Tuple[int, int, int] = (1, 1, 1)
+    p: Tuple[int, int, int] = (0, 0, 0)
+
+    @property
+    def out_dims(self):
+        return tuple((i + 2 * p - k) // s + 1 for i, k, s, p in zip((self.Di, self.Hi, self.Wi), self.k, self.s, self.p))
+
+    def desc(self, in_ld=None, out_ld=None, res_ld=None) -> _lib.PoolDesc:
+        do, ho, wo = self.out_dims
+        return _lib.PoolDesc(self.N, self.Di, self.Hi, self.Wi, self.C, do, ho, wo, *self.k, *self.s, *self.p,
+                             in_ld or self.C, out_ld or self.C, res_ld or self.C)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.RspError(f"{name}: expected a HIP device tensor (rspnet_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise _lib.RspError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.RspError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+class HipOps:
+    """Calls into librspnet_hip.so on the current HIP stream of the current device."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self._ws = {}
+
+    # one grow-only scratch buffer per device; kernels on one stream are serialised so it can be shared
+    def _workspace(self, dev, nbytes: int) -> torch.Tensor:
+        buf = self._ws.get(dev)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                buf.record_stream(torch.cuda.current_stream(dev))
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+            self._ws[dev] = buf
+        return buf
+
+    # ---- conv -------------------------------------------------------------------------------------------------
+    def conv_pack_fwd(self, g: ConvGeom, w_ref: torch.Tensor) -> torch.Tensor:
+        _chk(w_ref, "w_ref")
+        d = g.desc()
+        n = self.lib.rsp_conv3d_packed_fwd_elems(C.byref(d))
+        out = torch.empty(n, dtype=torch.float32, device=w_ref.device)
+        _lib.check(self.lib.rsp_conv3d_pack_fwd(C.byref(d), _ptr(w_ref), _ptr(out), _stream()), "rsp_conv3d_pack_fwd")
+        return out
+
+    def conv_fwd(self, g: ConvGeom, x, w_packed, bias, want_stats: bool, out: Optional[torch.Tensor] = None,
+                 out_ld: Optional[int] = None, in_ld: Optional[int] = None):
+        _chk(x, "x")
+        d = g.desc(in_ld=in_ld, out_ld=out_ld)
+        do, ho, wo = g.out_dims
+        if out is None:
+            out = torch.empty((g.N, do, ho, wo, g.Cout), dtype=torch.float32, device=x.device)
+        stats = None
+        if want_stats:
+            tiles = self.lib.rsp_conv3d_stat_tiles(C.byref(d))
+            stats = torch.empty((tiles, g.Cout, 2), dtype=torch.float32, device=x.device)
+        wsb = self.lib.rsp_conv3d_fwd_workspace(C.byref(d))
+        ws = self._workspace(x.device, wsb) if wsb else None
+        _lib.check(self.lib.rsp_conv3d_fwd(C.byref(d), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
+                                           _ptr(ws), wsb, _stream()), "rsp_conv3d_fwd")
+        return out, stats
+
+    def conv_dgrad(self, g: ConvGeom, dy, w_ref):
+        _chk(dy, "dy")
+        _chk(w_ref, "w_ref")
+        d = g.desc()
+        dx = torch.empty((g.N, g.Di, g.Hi, g.Wi, g.Cin), dtype=torch.float32, device=dy.device)
+        wsb = self.lib.rsp_conv3d_dgrad_workspace(C.byref(d))
+        ws = self._workspace(dy.device, wsb)
+        _lib.check(self.lib.rsp_conv3d_dgrad(C.byref(d), _ptr(dy), _ptr(w_ref), _ptr(dx), _ptr(ws), wsb, _stream()),
+                   "rsp_conv3d_dgrad")
+        return dx
+
+    def conv_wgrad(self, g: ConvGeom, x, dy, dw_out: torch.Tensor, dbias_out: Optional[torch.Tensor] = None):
+        """dw_out (Cout,Cin,kT,kH,kW) and dbias_out are written in place (they are views of the flat grad buffer)."""
+        _chk(x, "x")
+        _chk(dy, "dy")
+        _chk(dw_out, "dw_out")
+        d = g.desc()
+        wsb = self.lib.rsp_conv3d_wgrad_workspace(C.byref(d))
+        ws = self._workspace(x.device, wsb)
+        _lib.check(self.lib.rsp_conv3d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
+                                             _stream()), "rsp_conv3d_wgrad")
+
+    # ---- batch norm -------------------------------------------------------------------------------------------
+    def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,
+                    running_var):
+        _chk(stats, "stats")
+        tiles, Cc, _ = stats.shape
+        mi = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
+        ss = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
+        wsb = self.lib.rsp_bn_finalize_workspace(tiles, Cc)
+        ws = self._workspace(stats.device, wsb)
+        _lib.check(self.lib.rsp_bn_finalize(_ptr(stats), tiles, Cc, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta), eps,
+                                            momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi), _ptr(ss), _ptr(ws),
+                                            wsb, _stream()), "rsp_bn_finalize")
+        return mi, ss
+
+    def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu: bool):
+        _chk(y, "y")
+        do, ho, wo = pg.out_dims
+        out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
+        d = pg.desc()
+        _lib.check(self.lib.rsp_bn_act_pool_fwd(C.byref(d), _ptr(y), _ptr(scale_shift), _ptr(residual), int(relu), _ptr(out),
+                                                _stream()), "rsp_bn_act_pool_fwd")
+        return out
+
+    def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu: bool,
+                        want_dres: bool, dgamma_out, dbeta_out):
+        _chk(y, "y")
+        _chk(dout, "dout")
+        d = pg.desc()
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if want_dres else None
+        wsb = self.lib.rsp_bn_bwd_workspace(C.byref(d))
+        ws = self._workspace(y.device, wsb)
+        _lib.check(self.lib.rsp_bn_act_pool_bwd(C.byref(d), _ptr(y), _ptr(residual), _ptr(dout), _ptr(gamma),
+                                                _ptr(mean_invstd), _ptr(scale_shift), int(relu), _ptr(dy), _ptr(dres),
+                                                _ptr(dgamma_out), _ptr(dbeta_out), _ptr(ws), wsb, _stream()),
+                   "rsp_bn_act_pool_bwd")
+        return dy, dres
+
+    # ---- heads / contrastive ----------------------------------------------------------------------------------
+    def head_fwd(self, feat, w1, b1, w2, b2):
+        _chk(feat, "feat")
+        N, D, H, W, Cc = feat.shape
+        P = D * H * W
+        dim = w1.shape[0]
+        dev = feat.device
+        o1 = torch.empty((N, dim), dtype=torch.float32, device=dev)
+        o2 = torch.empty((N, dim), dtype=torch.float32, device=dev)
+        pooled = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+        raw = torch.empty((2, N, dim), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.rsp_head_fwd(_ptr(feat), N, P, Cc, Cc, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), dim, _ptr(o1),
+                                         _ptr(o2), _ptr(pooled), _ptr(raw), _stream()), "rsp_head_fwd")
+        return o1, o2, pooled, raw
+
+    def head_bwd(self, d1, d2, pooled, raw, w1, w2, feat_shape, dw1, db1, dw2, db2):
+        N, D, H, W, Cc = feat_shape
+        P = D * H * W
+        dim = w1.shape[0]
+        dfeat = torch.empty(feat_shape, dtype=torch.float32, device=d1.device)
+        wsb = self.lib.rsp_head_bwd_workspace(N, dim)
+        ws = self._workspace(d1.device, wsb)
+        _lib.check(self.lib.rsp_head_bwd(_ptr(_chk(d1, "d1")), _ptr(_chk(d2, "d2")), _ptr(pooled), _ptr(raw), _ptr(w1),
+                                         _ptr(w2), N, P, Cc, Cc, dim, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                                         _ptr(dfeat), _ptr(ws), wsb, _stream()), "rsp_head_bwd")
+        return dfeat
+
+    def logits_fwd(self, qA, qM, kA, kM, knegA, knegM, queue, inv_T: float):
+        B, dim = qA.shape
+        K = queue.shape[1]
+        dev = qA.device
+        for n, t in (("qA", qA), ("qM", qM), ("kA", kA), ("kM", kM), ("knegA", knegA), ("knegM", knegM), ("queue", queue)):
+            _chk(t, n)
+        l1 = torch.empty((B, K + 1), dtype=torch.float32, device=dev)
+        l2 = torch.empty((B, K + 1), dtype=torch.float32, device=dev)
+        lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        ln = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.rsp_logits_fwd(_ptr(qA), _ptr(qM), _ptr(kA), _ptr(kM), _ptr(knegA), _ptr(knegM), _ptr(queue), B,
+                                           dim, K, inv_T, _ptr(l1), _ptr(l2), _ptr(lp), _ptr(ln), _stream()),
+                   "rsp_logits_fwd")
+        return l1, l2, lp, ln
+
+    def logits_bwd(self, dl1, dl2, dlp, dln, kA, kM, knegA, knegM, queue, inv_T: float):
+        B, dim = kA.shape
+        K = queue.shape[1]
+        dev = kA.device
+        dqA = torch.empty((B, dim), dtype=torch.float32, device=dev)
+        dqM = torch.empty((B, dim), dtype=torch.float32, device=dev)
+        wsb = self.lib.rsp_logits_bwd_workspace(B, dim, K)
+        ws = self._workspace(dev, wsb)
+        _lib.check(self.lib.rsp_logits_bwd(_ptr(_chk(dl1, "dl1")), _ptr(_chk(dl2, "dl2")), _ptr(_chk(dlp, "dlp")),
+                                           _ptr(_chk(dln, "dln")), _ptr(kA), _ptr(kM), _ptr(knegA), _ptr(knegM), _ptr(queue),
+                                           B, dim, K, inv_T, _ptr(dqA), _ptr(dqM), _ptr(ws), wsb, _stream()),
+                   "rsp_logits_bwd")
+        return dqA, dqM
+
+    def loss_fwd_bwd(self, l1, l2, lp, ln, margin: float, A: float, M: float):
+        B, K1 = l1.shape
+        dev = l1.device
+        for n, t in (("logits1", l1), ("logits2", l2), ("l_pos_M", lp), ("l_neg_M", ln)):
+            _chk(t, n)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        d1 = torch.empty_like(l1)
+        d2 = torch.empty_like(l2)
+        dp = torch.empty_like(lp)
+        dn = torch.empty_like(ln)
+        scratch = torch.empty(2 * B, dtype=torch.float32, device=dev)
+        _lib.check(self.lib.rsp_loss_fwd_bwd(_ptr(l1), _ptr(l2), _ptr(lp), _ptr(ln), B, K1, margin, A, M, _ptr(losses),
+                                             _ptr(d1), _ptr(d2), _ptr(dp), _ptr(dn), _ptr(scratch), _stream()),
+                   "rsp_loss_fwd_bwd")
+        return losses, d1, d2, dp, dn
+
+    def queue_enqueue(self, queue, ptr: int, keys):
+        dim, K = queue.shape
+        _lib.check(self.lib.rsp_queue_enqueue(_ptr(_chk(queue, "queue")), dim, K, ptr, _ptr(_chk(keys, "keys")),
+                                              keys.shape[0], _stream()), "rsp_queue_enqueue")
+
+    # ---- glue -------------------------------------------------------------------------------------------------
+    def clip_gather(self, im, src, step, T_out: int):
+        _chk(im, "im")
+        _chk(src, "src", torch.int32)
+        _chk(step, "step", torch.int32)
+        B_in, Cc, T_in, H, W = im.shape
+        B_out = src.shape[0]
+        out = torch.empty((B_out, T_out, H, W, Cc), dtype=torch.float32, device=im.device)
+        _lib.check(self.lib.rsp_clip_gather(_ptr(im), B_in, Cc, T_in, H, W, _ptr(src), _ptr(step), B_out, T_out, _ptr(out),
+                                            _stream()), "rsp_clip_gather")
+        return out
+
+    def momentum_update(self, k_flat, q_flat, m: float):
+        _lib.check(self.lib.rsp_momentum_update(_ptr(_chk(k_flat, "k")), _ptr(_chk(q_flat, "q")), k_flat.numel(), m,
+                                                _stream()), "rsp_momentum_update")
+
+    def sgd_step(self, p, g, buf, lr: float, mu: float, wd: float, gscale: float, first: bool):
+        _lib.check(self.lib.rsp_sgd_step(_ptr(_chk(p, "p")), _ptr(_chk(g, "g")), _ptr(_chk(buf, "buf")), p.numel(), lr, mu,
+                                         wd, gscale, int(first), _stream()), "rsp_sgd_step")
+
+    def rows_gather(self, x, idx):
+        _chk(x, "x")
+        _chk(idx, "idx", torch.int32)
+        n, width = idx.shape[0], x.shape[1]
+        out = torch.empty((n, width), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.rsp_rows_gather(_ptr(x), _ptr(idx), n, width, _ptr(out), _stream()), "rsp_rows_gather")
+        return out
+
+
+_backend = None
+
+
+def backend():
+    """The active op backend; instantiates HipOps (and therefore requires the built library) on first use."""
+    global _backend
+    if _backend is None:
+        _backend = HipOps()
+    return _backend
+
+
+def set_backend(b):
+    """TEST HOOK ONLY: swap the op backend (tests/cpu_ops.py).  Returns the previous one."""
+    global _backend
+    prev, _backend = _backend, b
+    return prev

@@ -1,0 +1,173 @@
+"""TEST-ONLY op backend: every method of rspnet_amd.ops.HipOps restated with plain torch CPU ops.
+
+Two uses: (1) `-m "not gpu"` tests run the *host logic* of rspnet_amd (layer-plan executor, flat parameters,
+shuffle-BN exchange, optimizer, checkpoint surface) against the golden fixtures without a GPU; (2) `-m gpu` tests
+use the same functions as the per-kernel contract when comparing HIP kernels with torch fp32 references.
+Never imported by the product.
+"""
+import torch
+import torch.nn.functional as F
+
+from rspnet_amd.ops import ConvGeom, PoolGeom
+
+
+def _ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3)
+
+
+def _ndhwc(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class CpuOps:
+    name = "cpu-checker"
+
+    def conv_pack_fwd(self, g: ConvGeom, w_ref):
+        return w_ref.detach().clone()
+
+    def conv_fwd(self, g: ConvGeom, x, w_packed, bias, want_stats, out=None, out_ld=None, in_ld=None):
+        y0 = F.conv3d(_ncdhw(x), w_packed, None, stride=g.s, padding=g.p)
+        stats = None
+        if want_stats:
+            s = y0.double().sum(dim=(0, 2, 3, 4))
+            ss = (y0.double() ** 2).sum(dim=(0, 2, 3, 4))
+            stats = torch.stack([s, ss], dim=1).float().unsqueeze(0).contiguous()   # one "tile"
+            stats = stats.double()  # keep precision of the single tile
+        if bias is not None:
+            y0 = y0 + bias.view(1, -1, 1, 1, 1)
+        return _ndhwc(y0), stats
+
+    def conv_dgrad(self, g: ConvGeom, dy, w_ref):
+        x_shape = (g.N, g.Cin, g.Di, g.Hi, g.Wi)
+        dx = torch.nn.grad.conv3d_input(x_shape, w_ref, _ncdhw(dy).contiguous(), stride=g.s, padding=g.p)
+        return _ndhwc(dx)
+
+    def conv_wgrad(self, g: ConvGeom, x, dy, dw_out, dbias_out=None):
+        dw = torch.nn.grad.conv3d_weight(_ncdhw(x).contiguous(), tuple(dw_out.shape), _ncdhw(dy).contiguous(),
+                                         stride=g.s, padding=g.p)
+        dw_out.copy_(dw)
+        if dbias_out is not None:
+            dbias_out.copy_(dy.sum(dim=(0, 1, 2, 3)))
+
+    def bn_finalize(self, stats, count, conv_bias, gamma, beta, eps, momentum, running_mean, running_var):
+        s = stats.double().sum(dim=0)
+        mean0 = s[:, 0] / count
+        var = (s[:, 1] / count - mean0 * mean0).clamp_min(0)
+        mean = mean0 + (conv_bias.double() if conv_bias is not None else 0)
+        invstd = (1.0 / torch.sqrt(var + eps)).float()
+        mi = torch.stack([mean.float(), invstd])
+        sc = gamma * invstd
+        ss = torch.stack([sc, beta - mean.float() * sc])
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+        if running_var is not None:
+            unb = var * count / (count - 1) if count > 1 else var
+            running_var.mul_(1 - momentum).add_(momentum * unb.float())
+        return mi, ss
+
+    def _act(self, pg, y, ss, residual, relu):
+        z = y * ss[0] + ss[1]
+        if residual is not None:
+            z = z + residual
+        return z
+
+    def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu):
+        z = self._act(pg, y, scale_shift, residual, relu)
+        if relu:
+            z = F.relu(z)
+        if pg.k != (1, 1, 1) or pg.s != (1, 1, 1):
+            z = _ndhwc(F.max_pool3d(_ncdhw(z), pg.k, pg.s, pg.p))
+        return z.contiguous()
+
+    @torch.enable_grad()
+    def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu, want_dres,
+                        dgamma_out, dbeta_out):
+        z = self._act(pg, y, scale_shift, residual, relu).detach().requires_grad_(True)
+        a = F.relu(z) if relu else z
+        if pg.k != (1, 1, 1) or pg.s != (1, 1, 1):
+            a = _ndhwc(F.max_pool3d(_ncdhw(a), pg.k, pg.s, pg.p))
+        (dz,) = torch.autograd.grad(a, z, dout)
+        mean, invstd = mean_invstd[0], mean_invstd[1]
+        xhat = (y - mean) * invstd
+        n = y.numel() // y.shape[-1]
+        s1 = dz.double().sum(dim=(0, 1, 2, 3))
+        s2 = (dz.double() * xhat.double()).sum(dim=(0, 1, 2, 3))
+        dy = gamma * invstd * (dz - (s1 / n).float() - xhat * (s2 / n).float())
+        if dgamma_out is not None:
+            dgamma_out.copy_(s2.float())
+        if dbeta_out is not None:
+            dbeta_out.copy_(s1.float())
+        return dy.contiguous(), (dz.contiguous() if want_dres else None)
+
+    def head_fwd(self, feat, w1, b1, w2, b2):
+        pooled = feat.mean(dim=(1, 2, 3))
+        r1 = F.linear(pooled, w1, b1)
+        r2 = F.linear(pooled, w2, b2)
+        return F.normalize(r1, dim=1), F.normalize(r2, dim=1), pooled, torch.stack([r1, r2])
+
+    @torch.enable_grad()
+    def head_bwd(self, d1, d2, pooled, raw, w1, w2, feat_shape, dw1, db1, dw2, db2):
+        P = feat_shape[1] * feat_shape[2] * feat_shape[3]
+        p = pooled.detach().requires_grad_(True)
+        W1 = w1.detach().requires_grad_(True)
+        W2 = w2.detach().requires_grad_(True)
+        B1 = torch.zeros(w1.shape[0], requires_grad=True)
+        B2 = torch.zeros(w2.shape[0], requires_grad=True)
+        r1 = F.linear(p, W1) + B1 + (raw[0] - F.linear(pooled, w1)).detach()
+        r2 = F.linear(p, W2) + B2 + (raw[1] - F.linear(pooled, w2)).detach()
+        o = (F.normalize(r1, dim=1) * d1).sum() + (F.normalize(r2, dim=1) * d2).sum()
+        gp, g1, g2, gb1, gb2 = torch.autograd.grad(o, [p, W1, W2, B1, B2])
+        dw1.copy_(g1)
+        dw2.copy_(g2)
+        db1.copy_(gb1)
+        db2.copy_(gb2)
+        return (gp / P).view(feat_shape[0], 1, 1, 1, -1).expand(feat_shape).contiguous()
+
+    def logits_fwd(self, qA, qM, kA, kM, knegA, knegM, queue, inv_T):
+        lneg = (qA @ queue) * inv_T
+        l1 = torch.cat([(qA * kA).sum(1, keepdim=True) * inv_T, lneg], 1)
+        l2 = torch.cat([(qA * knegA).sum(1, keepdim=True) * inv_T, lneg], 1)
+        return l1, l2, (qM * kM).sum(1, keepdim=True) * inv_T, (qM * knegM).sum(1, keepdim=True) * inv_T
+
+    def logits_bwd(self, dl1, dl2, dlp, dln, kA, kM, knegA, knegM, queue, inv_T):
+        dqA = inv_T * (dl1[:, :1] * kA + dl2[:, :1] * knegA + (dl1[:, 1:] + dl2[:, 1:]) @ queue.t())
+        dqM = inv_T * (dlp * kM + dln * knegM)
+        return dqA, dqM
+
+    @torch.enable_grad()
+    def loss_fwd_bwd(self, l1, l2, lp, ln, margin, A, M):
+        a = l1.detach().requires_grad_(True)
+        b = l2.detach().requires_grad_(True)
+        p = lp.detach().requires_grad_(True)
+        n = ln.detach().requires_grad_(True)
+        tgt = torch.zeros(a.shape[0], dtype=torch.long)
+        ce = F.cross_entropy(a, tgt) + F.cross_entropy(b, tgt)
+        rk = torch.clamp(margin - (p - n), min=0).mean()
+        loss = A * ce + M * rk
+        d1, d2, dp, dn = torch.autograd.grad(loss, [a, b, p, n])
+        return torch.stack([loss.detach(), ce.detach(), rk.detach()]), d1, d2, dp, dn
+
+    def queue_enqueue(self, queue, ptr, keys):
+        queue[:, ptr:ptr + keys.shape[0]] = keys.t()
+
+    def clip_gather(self, im, src, step, T_out):
+        out = torch.empty((src.shape[0], T_out, im.shape[3], im.shape[4], im.shape[1]), dtype=im.dtype)
+        for j in range(src.shape[0]):
+            s = int(step[j])
+            frames = im[int(src[j])][:, 0:T_out * s:s][:, :T_out]
+            out[j] = frames.permute(1, 2, 3, 0)
+        return out
+
+    def momentum_update(self, k_flat, q_flat, m):
+        k_flat.copy_(k_flat * m + q_flat * (1.0 - m))
+
+    def sgd_step(self, p, g, buf, lr, mu, wd, gscale, first):
+        d = g * gscale + wd * p
+        if first:
+            buf.copy_(d)
+        else:
+            buf.mul_(mu).add_(d)
+        p.sub_(lr * buf)
+
+    def rows_gather(self, x, idx):
+        return x[idx.long()].contiguous()

@@ -1,0 +1,81 @@
+"""Run rspnet_amd's pretext model on a golden case (any device / op backend) and return comparable results."""
+import random
+
+import numpy as np
+import torch
+
+from rspnet_amd.moco import Loss, ModelFactory
+
+
+def make_cfg(arch, K, fc_type="linear", dim=128, m=0.999, T=0.07, speeds=(2,)):
+    return {"model": {"arch": arch}, "moco": {"dim": dim, "k": K, "m": m, "t": T, "fc_type": fc_type,
+                                               "diff_speed": list(speeds)}}
+
+
+class ReplayRNG:
+    """Replays torch.randperm / random.choice in call order (same trick as oracle/ref_harness.py)."""
+
+    def __init__(self, perms, speed):
+        self.perms = [torch.from_numpy(np.asarray(p, dtype=np.int64)) for p in perms]
+        self.speed = speed
+        self.n = 0
+
+    def __enter__(self):
+        self._rp, self._ch = torch.randperm, random.choice
+
+        def randperm(n, *a, **k):
+            p = self.perms[self.n]
+            assert p.numel() == n, (p.numel(), n)
+            self.n += 1
+            out = p.clone()
+            dev = k.get("device")
+            return out.to(dev) if dev is not None else out
+
+        torch.randperm = randperm
+        random.choice = lambda seq: self.speed
+        return self
+
+    def __exit__(self, *exc):
+        torch.randperm, random.choice = self._rp, self._ch
+
+
+def run_model_step(arch, meta, inputs, rank, device, optimizer="fused"):
+    """One teacher-forced step of rspnet_amd on `device`.  Returns (out dict, post state dict, momentum_post dict)."""
+    from rspnet_amd.optim import SGD
+    state, mom, clips, perms_B, sh = inputs
+    wrapped = ModelFactory(make_cfg(arch, meta["K"], m=meta["m"], T=meta["T"])).build_moco_diffloss(device=device)
+    model = wrapped.module
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    model.train()
+    params = list(wrapped.parameters())
+    params = [p for p in params if p.requires_grad]
+    cls = SGD if optimizer == "fused" else torch.optim.SGD
+    opt = cls(params, lr=meta["lr"], momentum=meta["sgd_momentum"], dampening=0.0,
+              weight_decay=meta["weight_decay"], nesterov=False)
+    names = {id(p): n for n, p in model.named_parameters()}
+    for p in params:
+        n = names[id(p)]
+        if n in mom:
+            opt.state[p]["momentum_buffer"] = torch.from_numpy(mom[n].copy()).to(device)
+    crit = Loss(margin=meta["margin"], A=meta["A"], M=meta["M"])
+    im_q = torch.from_numpy(clips[rank][0]).to(device)
+    im_k = torch.from_numpy(clips[rank][1]).to(device)
+    with ReplayRNG([perms_B[rank], sh[0], sh[1]], meta["speed"]):
+        out, tgt, rl, rt = wrapped(im_q, im_k)
+    loss, loss_A, loss_M = crit(out, tgt, rl, rt)
+    opt.zero_grad()
+    loss.backward()
+    grads = {names[id(p)]: (None if p.grad is None else p.grad.detach().cpu().numpy().copy()) for p in params}
+    opt.step()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    q_A, q_M = model._last_q
+    res = {"loss": loss, "loss_A": loss_A, "loss_M": loss_M, "logits1": out[0], "logits2": out[1], "l_pos_M": rl[0],
+           "l_neg_M": rl[1], "q_A": q_A, "q_M": q_M}
+    res = {k: v.detach().cpu().numpy() for k, v in res.items()}
+    assert tgt.dtype == torch.long and int(tgt.abs().sum()) == 0
+    assert rt.dtype == torch.long and int((rt - 1).abs().sum()) == 0
+    post = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    mom_post = {names[id(p)]: opt.state[p]["momentum_buffer"].detach().cpu().numpy()
+                for p in params if "momentum_buffer" in opt.state[p]}
+    return res, post, mom_post, grads

@@ -1,0 +1,37 @@
+"""CPU: rspnet_amd's host logic (plan executor, flat params, MoCo forward/backward orchestration, fused-SGD
+bookkeeping) reproduces the golden fixtures when its HIP ops are replaced by the torch checker backend.
+The kernels themselves are tested on the GPU (tests/test_kernels_gpu.py, tests/test_step_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from cpu_ops import CpuOps
+from golden_util import build_inputs, compare_to_golden, load_case, summary_err
+from model_util import run_model_step
+from rspnet_amd import ops
+
+
+@pytest.fixture()
+def cpu_backend():
+    prev = ops.set_backend(CpuOps())
+    yield
+    ops.set_backend(prev)
+
+
+@pytest.mark.parametrize("arch,seed,optimizer", [("c3d", 1, "fused"), ("c3d", 2, "torch")])
+def test_step_matches_golden_ws1(cpu_backend, arch, seed, optimizer):
+    z, meta = load_case(arch, 1, seed)
+    spec, inputs = build_inputs(arch, meta)
+    res, post, mom_post, grads = run_model_step(arch, meta, inputs, 0, torch.device("cpu"), optimizer)
+    # state-dict contract: same keys, shapes, dtypes as the reference
+    assert list(post.keys()) == list(spec.keys())
+    for k, (shape, dtype) in spec.items():
+        assert tuple(post[k].shape) == shape and str(post[k].dtype) == dtype, k
+    compare_to_golden(z, 0, res, post, mom_post, tol=5e-5, tol_grad=5e-4)
+    for name in z.files:
+        if name.startswith("r0.gradsum."):
+            key = name[len("r0.gradsum."):]
+            if z[name].size == 0:
+                assert grads[key] is None, key
+            else:
+                assert summary_err(key, grads[key], z[name]) <= 5e-4, key
