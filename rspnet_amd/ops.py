@@ -39,6 +39,11 @@ class ConvGeom:
         d, h, w = self.out_dims
         return self.N * d * h * w
 
+    @property
+    def flops(self):
+        """Algorithmic FLOPs of one pass (2*MACs, padded taps included — SURVEY.md §8d)."""
+        return 2 * self.rows * self.Cout * self.Cin * self.k[0] * self.k[1] * self.k[2]
+
     def desc(self, in_ld=None, out_ld=None) -> _lib.ConvDesc:
         do, ho, wo = self.out_dims
         return _lib.ConvDesc(self.N, self.Di, self.Hi, self.Wi, self.Cin, do, ho, wo, self.Cout, *self.k, *self.s, *self.p,
@@ -93,6 +98,22 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
+        # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event) per MFMA launch
+        # group, recorded on the stream the kernels run on (torch's current stream).
+        self.event_log = None
+
+    def _ev(self):
+        if self.event_log is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _log(self, kind, flops, e0):
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.event_log.append((kind, flops, e0, e1))
 
     # one grow-only scratch buffer per device; kernels on one stream are serialised so it can be shared
     def _workspace(self, dev, nbytes: int) -> torch.Tensor:
@@ -126,8 +147,10 @@ class HipOps:
             stats = torch.empty((tiles, g.Cout, 2), dtype=torch.float32, device=x.device)
         wsb = self.lib.rsp_conv3d_fwd_workspace(C.byref(d))
         ws = self._workspace(x.device, wsb) if wsb else None
+        e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_fwd(C.byref(d), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
                                            _ptr(ws), wsb, _stream()), "rsp_conv3d_fwd")
+        self._log("conv_fwd", g.flops, e0)
         return out, stats
 
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):
@@ -137,8 +160,10 @@ class HipOps:
         dx = torch.empty((g.N, g.Di, g.Hi, g.Wi, g.Cin), dtype=torch.float32, device=dy.device)
         wsb = self.lib.rsp_conv3d_dgrad_workspace(C.byref(d))
         ws = self._workspace(dy.device, wsb)
+        e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_dgrad(C.byref(d), _ptr(dy), _ptr(w_ref), _ptr(dx), _ptr(ws), wsb, _stream()),
                    "rsp_conv3d_dgrad")
+        self._log("conv_dgrad", g.flops, e0)
         return dx
 
     def conv_wgrad(self, g: ConvGeom, x, dy, dw_out: torch.Tensor, dbias_out: Optional[torch.Tensor] = None):
@@ -149,8 +174,10 @@ class HipOps:
         d = g.desc()
         wsb = self.lib.rsp_conv3d_wgrad_workspace(C.byref(d))
         ws = self._workspace(x.device, wsb)
+        e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
                                              _stream()), "rsp_conv3d_wgrad")
+        self._log("conv_wgrad", g.flops, e0)
 
     # ---- batch norm -------------------------------------------------------------------------------------------
     def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,

@@ -1,0 +1,270 @@
+"""GPU: every HIP kernel (through the C ABI, via rspnet_amd.ops.HipOps) against the torch-fp32 contract in
+tests/cpu_ops.py on identical seeded inputs.  Tolerances are written per test; convs run on the exact-fp32 MFMA pipe
+(fmaf chains), so they agree with the CPU reference to summation-order rounding (~1e-6 relative to |a|.|b|)."""
+import numpy as np
+import pytest
+import torch
+
+from cpu_ops import CpuOps
+from rspnet_amd.ops import ConvGeom, PoolGeom
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+CPU = CpuOps()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rspnet_amd import ops
+    assert ops.backend().name == "hip"
+    return ops.backend()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(a, b, rtol, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = max(b.abs().max().item(), 1e-6)
+    assert err <= rtol * ref, f"{what}: max err {err:.3e} vs ref max {ref:.3e} (rel {err / ref:.3e} > {rtol})"
+
+
+# (N, D, H, W, Cin, Cout, k, s, p)
+CONV_CASES = [
+    (2, 4, 12, 12, 3, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # C3D conv1: Cin=3 scalar gather, BN=64 tile
+    (2, 4, 10, 10, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # C3D conv2: vec4, 128x128 tile
+    (1, 2, 7, 7, 256, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # C3D conv4a/5: small M, big K -> split-K
+    (2, 4, 16, 16, 3, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),        # R3D-18 stem
+    (2, 4, 8, 8, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),        # R3D-18 strided 3x3x3
+    (2, 4, 8, 8, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),        # R3D-18 downsample 1x1x1 s2
+    (2, 3, 9, 9, 3, 83, (1, 7, 7), (1, 2, 2), (0, 3, 3)),          # R(2+1)D stem spatial: Cout=83 (odd)
+    (2, 5, 6, 6, 83, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),         # R(2+1)D temporal: Cin=83 (scalar gather)
+    (2, 5, 6, 6, 230, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),       # R(2+1)D temporal stride 2, Cin%4==2
+    (1, 4, 9, 9, 3, 64, (1, 7, 7), (2, 2, 2), (0, 3, 3)),          # S3D-G stem: (1,7,7) stride 2 in T too
+    (2, 4, 7, 7, 192, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # S3D-G pointwise to 16 ch (BN=32 tile)
+    (2, 4, 7, 7, 16, 48, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # S3D-G (1,3,3), Cout=48
+    (1, 1, 5, 5, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # tiny: M=25 < one tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:6])) + f"k{c[6]}s{c[7]}")
+def test_conv_fwd_dgrad_wgrad(hip, case):
+    N, D, H, W, Cin, Cout, k, s, p = case
+    g = ConvGeom(N, D, H, W, Cin, Cout, k, s, p)
+    x = rnd(N, D, H, W, Cin, seed=1)
+    w = rnd(Cout, Cin, *k, seed=2, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    b = rnd(Cout, seed=3)
+    # forward (+ bias, + stat partials)
+    y_ref, st_ref = CPU.conv_fwd(g, x, w, b, True)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y, st = hip.conv_fwd(g, xd, hip.conv_pack_fwd(g, wd), bd, True)
+    close(y, y_ref, 2e-5, "conv fwd")
+    close(st.double().sum(0), st_ref.double().sum(0), 2e-5, "stat partials")
+    # forward without bias / stats
+    y2, st2 = hip.conv_fwd(g, xd, hip.conv_pack_fwd(g, wd), None, False)
+    assert st2 is None
+    close(y2, y_ref - b, 2e-5, "conv fwd nobias")
+    # dgrad
+    dy = rnd(*y_ref.shape, seed=4)
+    dx_ref = CPU.conv_dgrad(g, dy, w)
+    dx = hip.conv_dgrad(g, dy.to(DEV), wd)
+    close(dx, dx_ref, 2e-5, "dgrad")
+    # wgrad (+ dbias)
+    dw_ref = torch.empty_like(w)
+    db_ref = torch.empty_like(b)
+    CPU.conv_wgrad(g, x, dy, dw_ref, db_ref)
+    dw = torch.empty_like(wd)
+    db = torch.empty_like(bd)
+    hip.conv_wgrad(g, xd, dy.to(DEV), dw, db)
+    close(dw, dw_ref, 2e-5, "wgrad")
+    close(db, db_ref, 2e-5, "dbias")
+
+
+def test_conv_is_run_to_run_deterministic(hip):
+    g = ConvGeom(1, 2, 7, 7, 256, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1))   # split-K path
+    x, w = rnd(1, 2, 7, 7, 256, seed=5).to(DEV), rnd(512, 256, 3, 3, 3, seed=6).to(DEV)
+    wp = hip.conv_pack_fwd(g, w)
+    y1, s1 = hip.conv_fwd(g, x, wp, None, True)
+    y2, s2 = hip.conv_fwd(g, x, wp, None, True)
+    assert torch.equal(y1, y2) and torch.equal(s1, s2)
+    dy = rnd(*y1.shape, seed=7).to(DEV)
+    a, b = torch.empty_like(w), torch.empty_like(w)
+    hip.conv_wgrad(g, x, dy, a)
+    hip.conv_wgrad(g, x, dy, b)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,tiles_rows", [(64, 5000), (83, 130), (512, 98)])
+def test_bn_finalize(hip, C, tiles_rows):
+    rows = tiles_rows
+    y = rnd(rows, C, seed=1) * 2 + 0.5
+    bias = rnd(C, seed=2)
+    gamma, beta = rnd(C, seed=3) + 1.5, rnd(C, seed=4)
+    rm, rv = rnd(C, seed=5), rnd(C, seed=6) + 1.5
+    tiles = (rows + 127) // 128
+    part = torch.zeros(tiles, C, 2)
+    for t in range(tiles):
+        blk = y[t * 128:(t + 1) * 128].double()
+        part[t, :, 0] = blk.sum(0).float()
+        part[t, :, 1] = (blk * blk).sum(0).float()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    mi_ref, ss_ref = CPU.bn_finalize(part, rows, bias, gamma, beta, 1e-5, 0.1, rm_ref, rv_ref)
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    mi, ss = hip.bn_finalize(part.to(DEV), rows, bias.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm_d, rv_d)
+    close(mi, mi_ref, 1e-5, "mean/invstd")
+    close(ss, ss_ref, 1e-5, "scale/shift")
+    close(rm_d, rm_ref, 1e-5, "running_mean")
+    close(rv_d, rv_ref, 1e-5, "running_var")
+    # F.batch_norm agreement (the reference's op): running stats after one train-mode call
+    rm2, rv2 = rm.clone(), rv.clone()
+    torch.nn.functional.batch_norm((y + bias).t().reshape(1, C, rows), rm2, rv2, gamma, beta, True, 0.1, 1e-5)
+    close(rm_d, rm2, 2e-5, "running_mean vs F.batch_norm")
+    close(rv_d, rv2, 2e-5, "running_var vs F.batch_norm")
+
+
+POOL_CASES = [
+    # N, D, H, W, C, k, s, relu, residual
+    (2, 4, 8, 8, 64, (1, 2, 2), (1, 2, 2), True, False),
+    (2, 4, 8, 8, 128, (2, 2, 2), (2, 2, 2), True, False),
+    (2, 3, 7, 7, 256, (1, 1, 1), (1, 1, 1), True, False),
+    (2, 5, 7, 7, 64, (2, 2, 2), (2, 2, 2), True, False),     # odd sizes: floor mode drops the tail, dy must still be written
+    (2, 3, 5, 5, 83, (1, 1, 1), (1, 1, 1), True, False),     # odd channel count -> scalar path
+    (2, 3, 5, 5, 64, (1, 1, 1), (1, 1, 1), True, True),      # residual add before ReLU
+    (2, 3, 5, 5, 64, (1, 1, 1), (1, 1, 1), False, False),    # BN only (shortcut branch)
+    (1, 2, 4, 4, 1152, (1, 1, 1), (1, 1, 1), True, False),   # > 1024 channels
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "x".join(map(str, c[:5])) + f"k{c[5]}r{int(c[7])}{int(c[8])}")
+def test_bn_act_pool_fwd_bwd(hip, case):
+    N, D, H, W, C, k, s, relu, use_res = case
+    pg = PoolGeom(N, D, H, W, C, k, s, (0, 0, 0))
+    y = rnd(N, D, H, W, C, seed=1) * 2
+    res = rnd(N, D, H, W, C, seed=2) if use_res else None
+    gamma, beta = rnd(C, seed=3) + 1.5, rnd(C, seed=4) * 0.5
+    # stats the way the conv epilogue would give them (single tile here)
+    rows = N * D * H * W
+    yy = y.reshape(rows, C).double()
+    part = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1).float().unsqueeze(0)
+    mi, ss = CPU.bn_finalize(part, rows, None, gamma, beta, 1e-5, 0.1, None, None)
+    out_ref = CPU.bn_act_pool_fwd(pg, y, ss, res, relu)
+    yd, ssd, mid = y.to(DEV), ss.to(DEV), mi.to(DEV)
+    resd = res.to(DEV) if use_res else None
+    out = hip.bn_act_pool_fwd(pg, yd, ssd, resd, relu)
+    close(out, out_ref, 1e-6, "bn_act_pool fwd")
+    dout = rnd(*out_ref.shape, seed=5)
+    dg_ref, db_ref = torch.empty(C), torch.empty(C)
+    dy_ref, dres_ref = CPU.bn_act_pool_bwd(pg, y, res, dout, gamma, mi, ss, relu, use_res, dg_ref, db_ref)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dy, dres = hip.bn_act_pool_bwd(pg, yd, resd, dout.to(DEV), gamma.to(DEV), mid, ssd, relu, use_res, dg, db)
+    close(dy, dy_ref, 2e-5, "bn bwd dy")
+    close(dg, dg_ref, 2e-5, "dgamma")
+    close(db, db_ref, 2e-5, "dbeta")
+    if use_res:
+        close(dres, dres_ref, 1e-6, "dres")
+
+
+@pytest.mark.parametrize("B,P,C", [(4, 8, 512), (3, 98, 512), (2, 16, 1024)])
+def test_head_fwd_bwd(hip, B, P, C):
+    feat = rnd(B, P, 1, 1, C, seed=1)
+    w1, w2 = rnd(128, C, seed=2, scale=C ** -0.5), rnd(128, C, seed=3, scale=C ** -0.5)
+    b1, b2 = rnd(128, seed=4) * 0.1, rnd(128, seed=5) * 0.1
+    o1r, o2r, pr, rr = CPU.head_fwd(feat, w1, b1, w2, b2)
+    d = [t.to(DEV) for t in (feat, w1, b1, w2, b2)]
+    o1, o2, pooled, raw = hip.head_fwd(*d)
+    close(o1, o1r, 1e-5, "head out1")
+    close(o2, o2r, 1e-5, "head out2")
+    close(pooled, pr, 1e-5, "pooled")
+    close(raw, rr, 1e-5, "raw")
+    g1, g2 = rnd(B, 128, seed=6), rnd(B, 128, seed=7)
+    ref = [torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2)]
+    dfeat_ref = CPU.head_bwd(g1, g2, pr, rr, w1, w2, tuple(feat.shape), *ref)
+    out = [torch.empty_like(t, device=DEV) for t in ref]
+    dfeat = hip.head_bwd(g1.to(DEV), g2.to(DEV), pooled, raw, d[1], d[3], tuple(feat.shape), *out)
+    close(dfeat, dfeat_ref, 2e-5, "dfeat")
+    for a, b, n in zip(out, ref, ("dw1", "db1", "dw2", "db2")):
+        close(a, b, 2e-5, n)
+
+
+@pytest.mark.parametrize("B,K", [(4, 64), (32, 16384), (40, 1000)])
+def test_logits_and_loss(hip, B, K):
+    dim = 128
+    f = [torch.nn.functional.normalize(rnd(B, dim, seed=i), dim=1) for i in range(6)]
+    queue = torch.nn.functional.normalize(rnd(dim, K, seed=9), dim=0)
+    ref = CPU.logits_fwd(*f, queue, 1 / 0.07)
+    fd = [t.to(DEV) for t in f]
+    qd = queue.to(DEV)
+    out = hip.logits_fwd(*fd, qd, 1 / 0.07)
+    for a, b, n in zip(out, ref, ("logits1", "logits2", "l_pos_M", "l_neg_M")):
+        close(a, b, 1e-5, n)
+    lr = CPU.loss_fwd_bwd(*ref, 2.0, 1.0, 1.0)
+    lo = hip.loss_fwd_bwd(*out, 2.0, 1.0, 1.0)
+    close(lo[0], lr[0], 1e-5, "losses")
+    for a, b, n in zip(lo[1:], lr[1:], ("dlogits1", "dlogits2", "dlpos", "dlneg")):
+        close(a, b, 2e-5, n)
+    dq_ref = CPU.logits_bwd(*lr[1:], f[2], f[3], f[4], f[5], queue, 1 / 0.07)
+    dq = hip.logits_bwd(*lo[1:], fd[2], fd[3], fd[4], fd[5], qd, 1 / 0.07)
+    close(dq[0], dq_ref[0], 2e-5, "dqA")
+    close(dq[1], dq_ref[1], 2e-5, "dqM")
+
+
+def test_loss_weights_and_inactive_margin(hip):
+    B, K1 = 6, 33
+    l1, l2 = rnd(B, K1, seed=1) * 5, rnd(B, K1, seed=2) * 5
+    lp = torch.tensor([[5.0], [0.1], [3.0], [-1.0], [2.0], [9.0]])
+    ln = torch.tensor([[1.0], [0.2], [1.0], [1.0], [2.0], [0.0]])   # rows 0 and 5 are beyond the margin
+    ref = CPU.loss_fwd_bwd(l1, l2, lp, ln, 2.0, 0.7, 1.3)
+    out = hip.loss_fwd_bwd(l1.to(DEV), l2.to(DEV), lp.to(DEV), ln.to(DEV), 2.0, 0.7, 1.3)
+    for a, b in zip(out, ref):
+        close(a, b, 1e-5, "weighted loss")
+
+
+def test_queue_enqueue_and_rows_gather(hip):
+    q = rnd(128, 64, seed=1)
+    keys = rnd(8, 128, seed=2)
+    qd = q.to(DEV)
+    hip.queue_enqueue(qd, 24, keys.to(DEV))
+    CPU.queue_enqueue(q, 24, keys)
+    assert torch.equal(qd.cpu(), q)
+    x = rnd(16, 256, seed=3)
+    idx = torch.tensor([3, 3, 0, 15, 7], dtype=torch.int32)
+    assert torch.equal(hip.rows_gather(x.to(DEV), idx.to(DEV)).cpu(), CPU.rows_gather(x, idx))
+
+
+def test_clip_gather(hip):
+    im = rnd(4, 3, 32, 10, 12, seed=1)
+    src = torch.tensor([2, 0, 3, 1, 2], dtype=torch.int32)
+    step = torch.tensor([1, 2, 2, 1, 2], dtype=torch.int32)
+    out = hip.clip_gather(im.to(DEV), src.to(DEV), step.to(DEV), 16)
+    assert torch.equal(out.cpu(), CPU.clip_gather(im, src, step, 16))
+
+
+@pytest.mark.parametrize("n", [4096, 1000003])
+def test_momentum_and_sgd(hip, n):
+    k, q = rnd(n, seed=1), rnd(n, seed=2)
+    kd = k.to(DEV)
+    hip.momentum_update(kd, q.to(DEV), 0.999)
+    CPU.momentum_update(k, q, 0.999)
+    close(kd, k, 1e-7, "momentum")
+    p, g, buf = rnd(n, seed=3), rnd(n, seed=4), rnd(n, seed=5)
+    for first in (True, False):
+        pd, bd = p.to(DEV), buf.to(DEV)
+        hip.sgd_step(pd, g.to(DEV), bd, 0.05, 0.9, 1e-4, 1.0, first)
+        p2, b2 = p.clone(), buf.clone()
+        CPU.sgd_step(p2, g, b2, 0.05, 0.9, 1e-4, 1.0, first)
+        close(pd, p2, 1e-6, "sgd p")
+        close(bd, b2, 1e-6, "sgd buf")
+
+
+def test_c_abi_rejects_bad_arguments(hip):
+    from rspnet_amd._lib import RspError
+    g = ConvGeom(1, 2, 4, 4, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    with pytest.raises(RspError):
+        hip.conv_fwd(g, torch.zeros(1, 2, 4, 4, 8), torch.zeros(8 * 216, device=DEV), None, False)   # CPU tensor
+    with pytest.raises(RspError):
+        hip.queue_enqueue(torch.zeros(128, 64, device=DEV), 60, torch.zeros(8, 128, device=DEV))      # slab past K
