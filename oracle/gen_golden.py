@@ -25,11 +25,14 @@ from oracle import portable as P  # noqa: E402
 
 # (arch, B per rank, H=W, K, world sizes, seeds)
 CASES = [
-    ("c3d", 4, 32, 64, (1, 2), (1, 2)),
-    ("resnet18", 8, 64, 64, (1, 2), (1,)),
-    ("r2plus1d-vcop", 4, 32, 64, (1, 2), (1,)),
-    ("s3dg", 4, 64, 64, (1, 2), (1,)),
+    ("c3d", 4, 32, 64, (1, 2), 2),
+    ("resnet18", 8, 64, 64, (1, 2), 1),
+    ("r2plus1d-vcop", 4, 32, 64, (1, 2), 1),
+    ("s3dg", 4, 64, 64, (1, 2), 1),
 ]
+# see ref_harness.run_reference_step "knife-edge guard"; the wide (921/1152-channel) R(2+1)D and S3D-G late layers
+# have too many elements for 1e-5 to be findable, 3e-6 is still > the ~1e-6 rounding band of z.
+MIN_RELU_MARGIN = {"c3d": 3e-6, "resnet18": 3e-6, "r2plus1d-vcop": 3e-6, "s3dg": 3e-6}
 LR = 0.05
 SPEED = 2
 T_IN = 32
@@ -84,6 +87,7 @@ def _worker(rank, ws, arch, B, HW, K, seed, port, tmpdir):
                                SPEED, lr=LR, momentum_buffers=mom, ddp=(ws > 1))
     out: Dict[str, np.ndarray] = {}
     pack(res, rank, out)
+    out[f"r{rank}.relu_margin"] = np.array(res["relu_margin"])
     np.savez(os.path.join(tmpdir, f"r{rank}.npz"), **out)
     if rank == 0:
         with open(os.path.join(tmpdir, "spec.json"), "w") as f:
@@ -111,17 +115,34 @@ def run_case(arch, B, HW, K, ws, seed):
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     only = sys.argv[1:] or None
-    for arch, B, HW, K, wss, seeds in CASES:
+    index_path = os.path.join(GOLDEN, "index.json")
+    index = json.load(open(index_path)) if os.path.exists(index_path) else []
+    for arch, B, HW, K, wss, nseeds in CASES:
         if only and arch not in only:
             continue
+        index = [e for e in index if e[0] != arch]
         for ws in wss:
-            for seed in seeds:
+            seed, kept = 0, 0
+            while kept < nseeds:
+                seed += 1
+                assert seed <= 24, "no knife-edge-free seed found"
                 out, spec = run_case(arch, B, HW, K, ws, seed)
+                margin = min(float(out[f"r{r}.relu_margin"]) for r in range(ws))
+                # S3D-G at 2 ranks has ~150 small ReLU'd layers per rank: no seed clears the guard, so its fixture is kept
+                # unguarded and its gradient checks use a looser, per-arch tolerance (tests/golden_util.py)
+                guard = 0.0 if (arch == "s3dg" and ws > 1) else MIN_RELU_MARGIN[arch]
+                if margin < guard:
+                    print(f"skip {arch} ws{ws} seed {seed}: ReLU knife-edge |z|min = {margin:.2e}", flush=True)
+                    continue
                 name = case_name(arch, ws, seed)
                 np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
                 with open(os.path.join(GOLDEN, f"state_spec_{arch.replace('-', '_')}.json"), "w") as f:
                     json.dump(spec, f, indent=0)
-                print("wrote", name, "loss", out["r0.loss"], flush=True)
+                index.append([arch, ws, seed])
+                kept += 1
+                print("wrote", name, "loss", out["r0.loss"], "relu margin", margin, flush=True)
+                with open(index_path, "w") as f:
+                    json.dump(sorted(index), f)
 
 
 if __name__ == "__main__":

@@ -155,6 +155,34 @@ def run_reference_step(model, state: Dict[str, np.ndarray], im_q: np.ndarray, im
             feats.setdefault(tag, []).append([o.detach().clone() for o in out])
         return fn
 
+    # knife-edge guard: |ReLU input| minima of the small late layers.  An element with |z| ~ 1e-7 there gets its
+    # mask decided by summation-order rounding, and with only a few dozen elements per channel one flipped mask
+    # moves that channel's BN gradient by tens of percent — fixtures with such an element are not comparable across
+    # implementations, so gen_golden.py skips seeds whose margin is too small.
+    margins = []
+
+    def relu_hook(_mod, inp):          # pre-hook: several reference ReLUs are inplace
+        x = inp[0]
+        if x.dim() == 5 and x.numel() // x.shape[1] <= 256:
+            margins.append(float(x.detach().abs().min()))
+
+    def pool_hook(mod, inp):           # same guard for the arg-max of small pooled layers: top-2 gap per window
+        x = inp[0].detach()
+        ks = mod.kernel_size if isinstance(mod.kernel_size, tuple) else (mod.kernel_size,) * 3
+        st = mod.stride if isinstance(mod.stride, tuple) else (mod.stride,) * 3
+        if x.dim() == 5 and x.numel() // x.shape[1] <= 256 and tuple(ks) == tuple(st):   # disjoint windows only
+            import torch.nn.functional as F
+            m1, idx = F.max_pool3d(x, mod.kernel_size, mod.stride, mod.padding, return_indices=True)
+            x2 = x.flatten(2).scatter(2, idx.flatten(2), float("-inf")).view_as(x)
+            m2 = F.max_pool3d(x2, mod.kernel_size, mod.stride, mod.padding)
+            gap = (m1 - m2)[m1 > 0]
+            if gap.numel():
+                margins.append(float(gap.min()))
+
+    relu_handles = [m_.register_forward_pre_hook(relu_hook) for m_ in model.encoder_q.modules()
+                    if isinstance(m_, torch.nn.ReLU)]
+    relu_handles += [m_.register_forward_pre_hook(pool_hook) for m_ in model.encoder_q.modules()
+                     if isinstance(m_, torch.nn.MaxPool3d)]
     h1 = model.encoder_q.register_forward_hook(hook("q"))
     h2 = model.encoder_k.register_forward_hook(hook("k"))
     crit = Loss(margin=margin, A=A, M=M)
@@ -167,6 +195,8 @@ def run_reference_step(model, state: Dict[str, np.ndarray], im_q: np.ndarray, im
     opt.step()
     h1.remove()
     h2.remove()
+    for h in relu_handles:
+        h.remove()
 
     res: Dict[str, np.ndarray] = {
         "loss": loss.detach().numpy(), "loss_A": loss_A.detach().numpy(), "loss_M": loss_M.detach().numpy(),
@@ -180,6 +210,7 @@ def run_reference_step(model, state: Dict[str, np.ndarray], im_q: np.ndarray, im
         "q_A": feats["q"][0][0].numpy(), "q_M": feats["q"][0][1].numpy(),
     }
     post = model.state_dict()
+    res["relu_margin"] = min(margins) if margins else 1.0
     res["post_state"] = {k: v.detach().numpy().copy() for k, v in post.items()}
     res["grads"] = {k: (None if g is None else g.numpy()) for k, g in grads.items()}
     res["momentum_post"] = {names[id(p)]: opt.state[p]["momentum_buffer"].numpy().copy()

@@ -284,20 +284,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
   }
 }
 
-// sums[c] = (sum dz, sum dz*xhat) in double; also dgamma / dbeta.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// sums[c] = (sum dz, sum dz*xhat) in double; also dgamma / dbeta.  Block = 64 channels x 16 partial-row lanes.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                               double* __restrict__ sums, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+  __shared__ double red[16][64][2];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nblocks; ++i) {
-    a += (double)partial[((long long)i * C + c) * 2 + 0];
-    b += (double)partial[((long long)i * C + c) * 2 + 1];
+  if (c < C)
+    for (int i = rl; i < nblocks; i += 16) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)i * C + c) * 2);
+      a += (double)v.x;
+      b += (double)v.y;
+    }
+  red[rl][cl][0] = a;
+  red[rl][cl][1] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    a = 0.0; b = 0.0;
+    for (int l = 0; l < 16; ++l) { a += red[l][cl][0]; b += red[l][cl][1]; }
+    sums[2 * c] = a;
+    sums[2 * c + 1] = b;
+    if (dbeta) dbeta[c] = (float)a;
+    if (dgamma) dgamma[c] = (float)b;
   }
-  sums[2 * c] = a;
-  sums[2 * c + 1] = b;
-  if (dbeta) dbeta[c] = (float)a;
-  if (dgamma) dgamma[c] = (float)b;
 }
 
 // pass 2: input-centric.  dy = gamma*invstd*(dz_in - mean(dz) - xhat*mean(dz*xhat)); dz_in = dout*mask if this position
@@ -491,7 +502,7 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, rgrid, dim3(256), 0, s, p);
   int rc = rsp_check_launch("bn_bwd_reduce_kernel");
   if (rc != RSP_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, 128)), dim3(128), 0, s, p.partial, p.nblocks, d->C, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, 64)), dim3(1024), 0, s, p.partial, p.nblocks, d->C, sums,
                      dgamma, dbeta);
   rc = rsp_check_launch("bn_bwd_finalize_kernel");
   if (rc != RSP_OK) return rc;

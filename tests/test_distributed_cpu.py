@@ -1,0 +1,54 @@
+"""CPU, world_size 2 over gloo: the multi-rank host logic (host-side permutation exchange, clip all-to-all for
+shuffle-BN, fused key all-gather + un-shuffle map, global-queue ordering, bucketed gradient all-reduce + averaging)
+reproduces the 2-rank golden fixtures generated from the reference under DDP.  Kernels are replaced by the torch
+checker backend (tests/cpu_ops.py); the collectives are the real torch.distributed ones."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, ws, arch, seed, port, tmp):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from cpu_ops import CpuOps
+    from golden_util import build_inputs, compare_to_golden, load_case, summary_err, GRAD_TOL
+    from model_util import run_model_step
+    from rspnet_amd import ops
+    torch.set_num_threads(4)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    ops.set_backend(CpuOps())
+    z, meta = load_case(arch, ws, seed)
+    spec, inputs = build_inputs(arch, meta)
+    res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, torch.device("cpu"), "fused")
+    errs = compare_to_golden(z, rank, res, post, mom_post, tol=5e-5, tol_grad=GRAD_TOL)
+    worst = 0.0
+    for name in z.files:
+        if name.startswith(f"r{rank}.gradsum."):
+            key = name[len(f"r{rank}.gradsum."):]
+            if z[name].size:
+                worst = max(worst, summary_err(key, grads[key], z[name]))
+    assert worst <= GRAD_TOL, worst
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([worst]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+from golden_util import cases_for
+
+
+@pytest.mark.parametrize("arch,seed", [(a, s) for a, w, s in cases_for("c3d", 2)])
+def test_two_rank_step_matches_golden(arch, seed):
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, arch, seed, _free_port(), tmp), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
