@@ -113,6 +113,20 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
                         float* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* Stand-alone MaxPool3d, any window/stride/padding (models/resnet.py:139, models/s3dg.py:90,107-119).
+ * argmax (nullable in forward when no backward is needed): [N,Do,Ho,Wo,C] int32, linear input position per sample. */
+int rsp_maxpool3d_fwd(const rsp_pool3d_desc* d, const float* x, float* out, int32_t* argmax, void* stream);
+int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t* argmax, float* dx, void* stream);
+
+/* S3D-G self-gating (models/s3dg.py:63-72): out = x * sigmoid(W·mean_p(x) + b); x:[N][P][C] (pitch in_ld), W (C,C)
+ * = excitation.weight viewed (C,C,1,1,1), b (C).  Saves mean [N][C] and gate [N][C] for backward. */
+int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* w, const float* b,
+                 float* out, int32_t out_ld, float* mean, float* gate, void* stream);
+size_t rsp_gate_bwd_workspace(int32_t N, int32_t C);
+int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_t C, int32_t x_ld, int32_t dout_ld,
+                 const float* w, const float* mean, const float* gate, float* dx, int32_t dx_ld, float* dw, float* db,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Projection heads: AdaptiveAvgPool3d(1) -> Flatten -> Linear x2 -> F.normalize (moco/split_wrapper.py:138-152,163-169)
  * feat: [B][P][C] (ld = feat_ld).  w1,w2: (dim, C) row-major (nn.Linear.weight), b1,b2: (dim).

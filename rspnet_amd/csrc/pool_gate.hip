@@ -1,0 +1,265 @@
+// Stand-alone MaxPool3d with arbitrary (overlapping / padded) windows, and S3D-G self-gating.
+// Reference call sites: models/resnet.py:139 (MaxPool3d(3, stride 2, pad 1)), models/s3dg.py:90 (3,1,1), :107-119
+// ((1,3,3)/(1,2,2), (3,3,3)/2, (2,2,2)/2); gating: models/s3dg.py:63-72  x * sigmoid(Conv1x1x1(mean_{T,H,W}(x))).
+// HBM-bound streaming kernels; backward is input-centric over saved arg-max indices (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+struct MPParams {
+  rsp_pool3d_desc d;
+  const float* __restrict__ x;
+  float* __restrict__ out;
+  int* __restrict__ idx;         // arg-max as linear input position (d*Hi+h)*Wi+w within the sample
+  const float* __restrict__ dout;
+  float* __restrict__ dx;
+};
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const MPParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  const long long total = (long long)d.N * d.Do * d.Ho * d.Wo * d.C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % d.C);
+    long long q = i / d.C;
+    const int ow = (int)(q % d.Wo); q /= d.Wo;
+    const int oh = (int)(q % d.Ho); q /= d.Ho;
+    const int od = (int)(q % d.Do);
+    const int n = (int)(q / d.Do);
+    float best = -INFINITY;
+    int bi = -1;
+    for (int kt = 0; kt < d.kT; ++kt) {
+      const int id = od * d.sT - d.pT + kt;
+      if ((unsigned)id >= (unsigned)d.Di) continue;
+      for (int kh = 0; kh < d.kH; ++kh) {
+        const int ih = oh * d.sH - d.pH + kh;
+        if ((unsigned)ih >= (unsigned)d.Hi) continue;
+        for (int kw = 0; kw < d.kW; ++kw) {
+          const int iw = ow * d.sW - d.pW + kw;
+          if ((unsigned)iw >= (unsigned)d.Wi) continue;
+          const int lin = (id * d.Hi + ih) * d.Wi + iw;
+          const float v = p.x[((long long)n * d.Di * d.Hi * d.Wi + lin) * d.in_ld + c];
+          if (v > best || bi < 0) { best = v; bi = lin; }   // first maximum in scan order, like max_pool3d
+        }
+      }
+    }
+    const long long o = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
+    p.out[o * d.out_ld + c] = best;
+    if (p.idx) p.idx[o * d.C + c] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const MPParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  const long long total = (long long)d.N * d.Di * d.Hi * d.Wi * d.C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % d.C);
+    long long q = i / d.C;
+    const int iw = (int)(q % d.Wi); q /= d.Wi;
+    const int ih = (int)(q % d.Hi); q /= d.Hi;
+    const int id = (int)(q % d.Di);
+    const int n = (int)(q / d.Di);
+    const int lin = (id * d.Hi + ih) * d.Wi + iw;
+    float g = 0.f;
+    // output positions whose window contains this input position: o*s - p <= i <= o*s - p + k - 1
+    const int od0 = max(0, (id + d.pT - d.kT + d.sT) / d.sT), od1 = min(d.Do - 1, (id + d.pT) / d.sT);
+    const int oh0 = max(0, (ih + d.pH - d.kH + d.sH) / d.sH), oh1 = min(d.Ho - 1, (ih + d.pH) / d.sH);
+    const int ow0 = max(0, (iw + d.pW - d.kW + d.sW) / d.sW), ow1 = min(d.Wo - 1, (iw + d.pW) / d.sW);
+    for (int od = od0; od <= od1; ++od)
+      for (int oh = oh0; oh <= oh1; ++oh)
+        for (int ow = ow0; ow <= ow1; ++ow) {
+          const long long o = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
+          if (p.idx[o * d.C + c] == lin) g += p.dout[o * d.out_ld + c];
+        }
+    p.dx[((long long)n * d.Di * d.Hi * d.Wi + lin) * d.in_ld + c] = g;
+  }
+}
+
+// ---- S3D-G gating ---------------------------------------------------------------------------------------------------
+// mean over positions per (sample, channel): block = (sample, 64-channel group), 4 position lanes
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const float* __restrict__ x, int P, int C, int ld,
+                                                           float* __restrict__ mean) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int pp = pl; pp < P; pp += 4) s += x[((long long)n * P + pp) * ld + c];
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x;
+    mean[(long long)n * C + c] = (red[0][l] + red[1][l] + red[2][l] + red[3][l]) / (float)P;
+  }
+}
+
+// gate[n][co] = sigmoid(b[co] + sum_ci w[co][ci] * mean[n][ci]) ; one wave per output
+__global__ __launch_bounds__(256) void gate_fc_kernel(const float* __restrict__ mean, const float* __restrict__ w,
+                                                      const float* __restrict__ b, int N, int C,
+                                                      float* __restrict__ gate) {
+  const int lane = threadIdx.x & 63;
+  const long long o = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (o >= (long long)N * C) return;
+  const int n = (int)(o / C), co = (int)(o % C);
+  float s = 0.f;
+  for (int ci = lane; ci < C; ci += 64) s = fmaf(w[(long long)co * C + ci], mean[(long long)n * C + ci], s);
+  s = rsp_wave_sum(s);
+  if (lane == 0) gate[o] = 1.f / (1.f + expf(-(s + b[co])));
+}
+
+// out = x * gate[n][c]
+__global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                         int P, int C, int in_ld, int out_ld, long long total,
+                                                         float* __restrict__ out) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % C);
+    const long long row = i / C;
+    const int n = (int)(row / P);
+    out[row * out_ld + c] = x[row * in_ld + c] * gate[(long long)n * C + c];
+  }
+}
+
+// backward: dx = dout*gate + (dmean/P) ; dmean[n][ci] = sum_co dpre[n][co] w[co][ci];
+//           dpre[n][c] = (sum_p dout*x) * gate*(1-gate)
+__global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                              const float* __restrict__ gate, int P, int C, int x_ld,
+                                                              int dout_ld, float* __restrict__ dpre) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int pp = pl; pp < P; pp += 4) {
+      const long long row = (long long)n * P + pp;
+      s = fmaf(dout[row * dout_ld + c], x[row * x_ld + c], s);
+    }
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x;
+    const float g = gate[(long long)n * C + c];
+    dpre[(long long)n * C + c] = (red[0][l] + red[1][l] + red[2][l] + red[3][l]) * g * (1.f - g);
+  }
+}
+
+// dw[co][ci] = sum_n dpre[n][co]*mean[n][ci]; db[co] = sum_n dpre[n][co]; dmean[n][ci] = sum_co dpre[n][co] w[co][ci]
+__global__ void gate_bwd_param_kernel(const float* __restrict__ dpre, const float* __restrict__ mean, int N, int C,
+                                      float* __restrict__ dw, float* __restrict__ db) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)C * C) return;
+  const int co = (int)(i / C), ci = (int)(i % C);
+  float s = 0.f, sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float d = dpre[(long long)n * C + co];
+    s = fmaf(d, mean[(long long)n * C + ci], s);
+    sb += d;
+  }
+  dw[i] = s;
+  if (ci == 0) db[co] = sb;
+}
+__global__ void gate_bwd_dmean_kernel(const float* __restrict__ dpre, const float* __restrict__ w, int N, int C,
+                                      float* __restrict__ dmean) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)N * C) return;
+  const int n = (int)(i / C), ci = (int)(i % C);
+  float s = 0.f;
+  for (int co = 0; co < C; ++co) s = fmaf(dpre[(long long)n * C + co], w[(long long)co * C + ci], s);
+  dmean[i] = s;
+}
+__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ gate,
+                                                             const float* __restrict__ dmean, int P, int C, int dout_ld,
+                                                             int dx_ld, long long total, float* __restrict__ dx) {
+  const float invP = 1.f / (float)P;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % C);
+    const long long row = i / C;
+    const int n = (int)(row / P);
+    dx[row * dx_ld + c] = fmaf(dout[row * dout_ld + c], gate[(long long)n * C + c], dmean[(long long)n * C + c] * invP);
+  }
+}
+
+bool mp_ok(const rsp_pool3d_desc* d) {
+  if (!d) return false;
+  if (d->N <= 0 || d->C <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0) return false;
+  if (d->sT <= 0 || d->sH <= 0 || d->sW <= 0 || d->pT < 0 || d->pH < 0 || d->pW < 0) return false;
+  if (d->Do != (d->Di + 2 * d->pT - d->kT) / d->sT + 1) return false;
+  if (d->Ho != (d->Hi + 2 * d->pH - d->kH) / d->sH + 1) return false;
+  if (d->Wo != (d->Wi + 2 * d->pW - d->kW) / d->sW + 1) return false;
+  if (d->in_ld < d->C || d->out_ld < d->C) return false;
+  if ((long long)d->Di * d->Hi * d->Wi >= (1ll << 31)) return false;
+  return true;
+}
+int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsp_maxpool3d_fwd(const rsp_pool3d_desc* d, const float* x, float* out, int32_t* argmax, void* stream) {
+  RSP_REQUIRE(mp_ok(d), "rsp_maxpool3d_fwd: bad descriptor");
+  RSP_REQUIRE(x && out, "rsp_maxpool3d_fwd: null pointer");
+  MPParams p;
+  memset(&p, 0, sizeof p);
+  p.d = *d; p.x = x; p.out = out; p.idx = argmax;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * d->C)), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  return rsp_check_launch("maxpool_fwd_kernel");
+}
+
+int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t* argmax, float* dx, void* stream) {
+  RSP_REQUIRE(mp_ok(d), "rsp_maxpool3d_bwd: bad descriptor");
+  RSP_REQUIRE(dout && argmax && dx, "rsp_maxpool3d_bwd: null pointer");
+  MPParams p;
+  memset(&p, 0, sizeof p);
+  p.d = *d; p.dout = dout; p.idx = const_cast<int*>(argmax); p.dx = dx;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)d->N * d->Di * d->Hi * d->Wi * d->C)), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  return rsp_check_launch("maxpool_bwd_kernel");
+}
+
+int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* w, const float* b,
+                 float* out, int32_t out_ld, float* mean, float* gate, void* stream) {
+  RSP_REQUIRE(x && w && b && out && mean && gate, "rsp_gate_fwd: null pointer");
+  RSP_REQUIRE(N > 0 && P > 0 && C > 0 && in_ld >= C && out_ld >= C, "rsp_gate_fwd: bad size");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(spatial_mean_kernel, dim3(N, rsp_cdiv(C, 64)), dim3(256), 0, s, x, P, C, in_ld, mean);
+  int rc = rsp_check_launch("spatial_mean_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(gate_fc_kernel, dim3(rsp_cdiv((long long)N * C, 4)), dim3(256), 0, s, mean, w, b, N, C, gate);
+  rc = rsp_check_launch("gate_fc_kernel");
+  if (rc != RSP_OK) return rc;
+  const long long total = (long long)N * P * C;
+  hipLaunchKernelGGL(gate_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, gate, P, C, in_ld, out_ld, total, out);
+  return rsp_check_launch("gate_apply_kernel");
+}
+
+size_t rsp_gate_bwd_workspace(int32_t N, int32_t C) { return (size_t)2 * N * C * sizeof(float); }
+
+int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_t C, int32_t x_ld, int32_t dout_ld,
+                 const float* w, const float* mean, const float* gate, float* dx, int32_t dx_ld, float* dw, float* db,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(x && dout && w && mean && gate && dx && dw && db && workspace, "rsp_gate_bwd: null pointer");
+  RSP_REQUIRE(N > 0 && P > 0 && C > 0 && x_ld >= C && dout_ld >= C && dx_ld >= C, "rsp_gate_bwd: bad size");
+  if (workspace_bytes < rsp_gate_bwd_workspace(N, C)) {
+    rsp_set_error("rsp_gate_bwd: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* dpre = reinterpret_cast<float*>(workspace);
+  float* dmean = dpre + (size_t)N * C;
+  hipLaunchKernelGGL(gate_bwd_reduce_kernel, dim3(N, rsp_cdiv(C, 64)), dim3(256), 0, s, x, dout, gate, P, C, x_ld, dout_ld, dpre);
+  int rc = rsp_check_launch("gate_bwd_reduce_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(gate_bwd_param_kernel, dim3(rsp_cdiv((long long)C * C, 256)), dim3(256), 0, s, dpre, mean, N, C, dw, db);
+  rc = rsp_check_launch("gate_bwd_param_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(gate_bwd_dmean_kernel, dim3(rsp_cdiv((long long)N * C, 256)), dim3(256), 0, s, dpre, w, N, C, dmean);
+  rc = rsp_check_launch("gate_bwd_dmean_kernel");
+  if (rc != RSP_OK) return rc;
+  const long long total = (long long)N * P * C;
+  hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dout, gate, dmean, P, C, dout_ld, dx_ld,
+                     total, dx);
+  return rsp_check_launch("gate_bwd_apply_kernel");
+}
+
+}  // extern "C"

@@ -38,6 +38,26 @@ class ConvBN:
     relu: bool = True
     pool: Optional[Tuple[Triple, Triple]] = None   # (kernel, stride), disjoint windows only
     residual: Optional[int] = None                 # slot added before the ReLU
+    into: Optional[Tuple[int, int, int]] = None    # (concat slot, channel offset, total channels): write a slice
+
+
+@dataclass
+class Pool:
+    """Stand-alone MaxPool3d (overlapping / padded windows allowed)."""
+    src: int
+    dst: int
+    k: Triple
+    s: Triple
+    p: Triple = (0, 0, 0)
+
+
+@dataclass
+class Gate:
+    """S3D-G self-gating: x * sigmoid(conv1x1x1(mean(x)))   (models/s3dg.py:63-72)."""
+    conv: nn.Module                                # excitation: weight (C,C,1,1,1), bias (C)
+    src: int
+    dst: int
+    into: Optional[Tuple[int, int, int]] = None
 
 
 @dataclass
@@ -82,6 +102,18 @@ class PackedWeights:
         return w
 
 
+def _slice_of(slots, into, lead_shape, device):
+    """Channel-slice view of a concat tensor, allocating the tensor on first use."""
+    slot, off, total = into
+    if slot not in slots:
+        slots[slot] = torch.empty(tuple(lead_shape) + (total,), dtype=torch.float32, device=device)
+    return slots[slot]
+
+
+def _view(t, into, C):
+    return t if into is None else t[..., into[1]:into[1] + C]
+
+
 def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool) -> Tuple[torch.Tensor, Optional[ForwardCtx]]:
     """Execute `plan` on x (N,D,H,W,C).  keep=True records what backward needs.  BN is always in train mode
     (the pretext step never runs eval-mode BN: pretrain.py:225)."""
@@ -103,9 +135,30 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool) 
             pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
             pg = PoolGeom(N, do, ho, wo, cg.Cout, pk, ps, (0, 0, 0))
             res = slots[node.residual] if node.residual is not None else None
-            slots[node.dst] = be.bn_act_pool_fwd(pg, y, ss, res, node.relu)
+            if node.into is not None:
+                pdo, pho, pwo = pg.out_dims
+                out = _view(_slice_of(slots, node.into, (N, pdo, pho, pwo), xin.device), node.into, cg.Cout)
+                be.bn_act_pool_fwd(pg, y, ss, res, node.relu, out=out)
+            else:
+                slots[node.dst] = be.bn_act_pool_fwd(pg, y, ss, res, node.relu)
             if keep:
                 ctx.saved[ni] = _Saved(xin, y, mi, ss, cg, pg, res)
+        elif isinstance(node, Pool):
+            xin = slots[node.src]
+            N, D, H, W, Cc = xin.shape
+            pg = PoolGeom(N, D, H, W, Cc, node.k, node.s, node.p)
+            slots[node.dst], idx = be.maxpool_fwd(pg, xin, keep)
+            if keep:
+                ctx.saved[ni] = (pg, idx)
+        elif isinstance(node, Gate):
+            xin = slots[node.src]
+            out = (_view(_slice_of(slots, node.into, tuple(xin.shape[:4]), xin.device), node.into, xin.shape[4])
+                   if node.into is not None else None)
+            o, mean, gate = be.gate_fwd(xin, node.conv.weight.data, node.conv.bias.data, out=out)
+            if node.into is None:
+                slots[node.dst] = o
+            if keep:
+                ctx.saved[ni] = (xin, mean, gate)
         else:
             raise NotImplementedError(f"plan node {type(node).__name__}")
     out = slots[plan.output_slot]
@@ -133,7 +186,10 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
         node = plan.nodes[ni]
         if isinstance(node, ConvBN):
             sv = ctx.saved.pop(ni)
-            dout = dslots.pop(node.dst)
+            if node.into is not None:
+                dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout)
+            else:
+                dout = dslots.pop(node.dst)
             bn = node.bn
             dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
                                           node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
@@ -152,5 +208,16 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             if node.src != plan.input_slot:
                 add_grad(node.src, be.conv_dgrad(sv.cg, dy, node.conv.weight.data))
             del dy, dout, sv
+        elif isinstance(node, Pool):
+            pg, idx = ctx.saved.pop(ni)
+            add_grad(node.src, be.maxpool_bwd(pg, dslots.pop(node.dst), idx))
+        elif isinstance(node, Gate):
+            xin, mean, gate = ctx.saved.pop(ni)
+            dout = (_view(dslots[node.into[0]], node.into, xin.shape[4]) if node.into is not None
+                    else dslots.pop(node.dst))
+            add_grad(node.src, be.gate_bwd(xin, dout, node.conv.weight.data, mean, gate, grad_of(node.conv.weight),
+                                           grad_of(node.conv.bias)))
+            if after_param_grads is not None:
+                after_param_grads(ni)
         else:
             raise NotImplementedError(f"plan node {type(node).__name__}")

@@ -90,6 +90,22 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32):
     return t
 
 
+def _rows_ld(t: torch.Tensor, name: str) -> int:
+    """Channel pitch of an NDHWC tensor that is either contiguous or a channel slice of a contiguous one."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.RspError(f"{name}: expected a float32 HIP device tensor (rspnet_amd has no CPU path)")
+    if t.is_contiguous():
+        return t.shape[-1]
+    ld = t.stride(-2)
+    exp, ok = ld, t.stride(-1) == 1
+    for dim in range(t.dim() - 2, -1, -1):
+        ok = ok and (t.stride(dim) == exp or t.shape[dim] == 1)
+        exp *= t.shape[dim]
+    if not ok:
+        raise _lib.RspError(f"{name}: expected a dense NDHWC tensor or a channel slice of one")
+    return ld
+
+
 class HipOps:
     """Calls into librspnet_hip.so on the current HIP stream of the current device."""
 
@@ -193,11 +209,12 @@ class HipOps:
                                             wsb, _stream()), "rsp_bn_finalize")
         return mi, ss
 
-    def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu: bool):
+    def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu: bool, out=None):
         _chk(y, "y")
         do, ho, wo = pg.out_dims
-        out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
-        d = pg.desc()
+        if out is None:
+            out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
+        d = pg.desc(out_ld=_rows_ld(out, "out"), res_ld=None if residual is None else _rows_ld(residual, "residual"))
         _lib.check(self.lib.rsp_bn_act_pool_fwd(C.byref(d), _ptr(y), _ptr(scale_shift), _ptr(residual), int(relu), _ptr(out),
                                                 _stream()), "rsp_bn_act_pool_fwd")
         return out
@@ -205,8 +222,7 @@ class HipOps:
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu: bool,
                         want_dres: bool, dgamma_out, dbeta_out):
         _chk(y, "y")
-        _chk(dout, "dout")
-        d = pg.desc()
+        d = pg.desc(out_ld=_rows_ld(dout, "dout"), res_ld=None if residual is None else _rows_ld(residual, "residual"))
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if want_dres else None
         wsb = self.lib.rsp_bn_bwd_workspace(C.byref(d))
@@ -216,6 +232,45 @@ class HipOps:
                                                 _ptr(dgamma_out), _ptr(dbeta_out), _ptr(ws), wsb, _stream()),
                    "rsp_bn_act_pool_bwd")
         return dy, dres
+
+    # ---- stand-alone pooling / gating --------------------------------------------------------------------------
+    def maxpool_fwd(self, pg: PoolGeom, x, keep: bool):
+        do, ho, wo = pg.out_dims
+        out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=x.device)
+        idx = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.int32, device=x.device) if keep else None
+        d = pg.desc(in_ld=_rows_ld(x, "x"))
+        _lib.check(self.lib.rsp_maxpool3d_fwd(C.byref(d), _ptr(x), _ptr(out), _ptr(idx), _stream()), "rsp_maxpool3d_fwd")
+        return out, idx
+
+    def maxpool_bwd(self, pg: PoolGeom, dout, idx):
+        dx = torch.empty((pg.N, pg.Di, pg.Hi, pg.Wi, pg.C), dtype=torch.float32, device=dout.device)
+        d = pg.desc(out_ld=_rows_ld(dout, "dout"))
+        _lib.check(self.lib.rsp_maxpool3d_bwd(C.byref(d), _ptr(dout), _ptr(idx), _ptr(dx), _stream()), "rsp_maxpool3d_bwd")
+        return dx
+
+    def gate_fwd(self, x, w, b, out=None):
+        _chk(x, "x")
+        N, D, H, W, Cc = x.shape
+        P = D * H * W
+        if out is None:
+            out = torch.empty_like(x)
+        mean = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        gate = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.rsp_gate_fwd(_ptr(x), N, P, Cc, Cc, _ptr(_chk(w, "w")), _ptr(_chk(b, "b")), _ptr(out),
+                                         _rows_ld(out, "out"), _ptr(mean), _ptr(gate), _stream()), "rsp_gate_fwd")
+        return out, mean, gate
+
+    def gate_bwd(self, x, dout, w, mean, gate, dw_out, db_out):
+        _chk(x, "x")
+        N, D, H, W, Cc = x.shape
+        P = D * H * W
+        dx = torch.empty_like(x)
+        wsb = self.lib.rsp_gate_bwd_workspace(N, Cc)
+        ws = self._workspace(x.device, wsb)
+        _lib.check(self.lib.rsp_gate_bwd(_ptr(x), _ptr(dout), N, P, Cc, Cc, _rows_ld(dout, "dout"), _ptr(w), _ptr(mean),
+                                         _ptr(gate), _ptr(dx), Cc, _ptr(dw_out), _ptr(db_out), _ptr(ws), wsb, _stream()),
+                   "rsp_gate_bwd")
+        return dx
 
     # ---- heads / contrastive ----------------------------------------------------------------------------------
     def head_fwd(self, feat, w1, b1, w2, b2):

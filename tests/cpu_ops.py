@@ -71,13 +71,47 @@ class CpuOps:
             z = z + residual
         return z
 
-    def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu):
+    def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu, out=None):
         z = self._act(pg, y, scale_shift, residual, relu)
         if relu:
             z = F.relu(z)
         if pg.k != (1, 1, 1) or pg.s != (1, 1, 1):
             z = _ndhwc(F.max_pool3d(_ncdhw(z), pg.k, pg.s, pg.p))
+        if out is not None:
+            out.copy_(z)
+            return out
         return z.contiguous()
+
+    def maxpool_fwd(self, pg: PoolGeom, x, keep):
+        o, idx = F.max_pool3d(_ncdhw(x), pg.k, pg.s, pg.p, return_indices=True)
+        return _ndhwc(o), (_ndhwc(idx).to(torch.int32) if keep else None)
+
+    def maxpool_bwd(self, pg: PoolGeom, dout, idx):
+        N, C = pg.N, pg.C
+        dx = torch.zeros(N, C, pg.Di * pg.Hi * pg.Wi)
+        dx.scatter_add_(2, _ncdhw(idx).reshape(N, C, -1).long(), _ncdhw(dout).reshape(N, C, -1))
+        return _ndhwc(dx.view(N, C, pg.Di, pg.Hi, pg.Wi))
+
+    def gate_fwd(self, x, w, b, out=None):
+        mean = x.mean(dim=(1, 2, 3))
+        gate = torch.sigmoid(F.linear(mean, w.view(w.shape[0], -1), b))
+        o = x * gate.view(x.shape[0], 1, 1, 1, -1)
+        if out is not None:
+            out.copy_(o)
+            return out, mean, gate
+        return o, mean, gate
+
+    @torch.enable_grad()
+    def gate_bwd(self, x, dout, w, mean, gate, dw_out, db_out):
+        xx = x.detach().requires_grad_(True)
+        W = w.detach().view(w.shape[0], -1).requires_grad_(True)
+        B = torch.zeros(w.shape[0], requires_grad=True)
+        pre = F.linear(xx.mean(dim=(1, 2, 3)), W) + B + (torch.logit(gate) - F.linear(mean, W)).detach()
+        o = xx * torch.sigmoid(pre).view(x.shape[0], 1, 1, 1, -1)
+        gx, gw, gb = torch.autograd.grad(o, [xx, W, B], dout)
+        dw_out.copy_(gw.view_as(dw_out))
+        db_out.copy_(gb)
+        return gx.contiguous()
 
     @torch.enable_grad()
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu, want_dres,

@@ -268,3 +268,73 @@ def test_c_abi_rejects_bad_arguments(hip):
         hip.conv_fwd(g, torch.zeros(1, 2, 4, 4, 8), torch.zeros(8 * 216, device=DEV), None, False)   # CPU tensor
     with pytest.raises(RspError):
         hip.queue_enqueue(torch.zeros(128, 64, device=DEV), 60, torch.zeros(8, 128, device=DEV))      # slab past K
+
+
+MAXPOOL_CASES = [
+    (2, 4, 9, 9, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # R3D-18 stem pool
+    (2, 3, 8, 8, 192, (1, 3, 3), (1, 2, 2), (0, 1, 1)),    # S3D-G maxPool1/2
+    (2, 4, 6, 6, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # S3D-G inception branch3 (stride 1)
+    (2, 4, 6, 6, 83, (2, 2, 2), (2, 2, 2), (0, 0, 0)),     # disjoint, odd channels
+]
+
+
+@pytest.mark.parametrize("case", MAXPOOL_CASES, ids=lambda c: "x".join(map(str, c[:5])) + f"k{c[5]}s{c[6]}")
+def test_maxpool_fwd_bwd(hip, case):
+    N, D, H, W, C, k, s, p = case
+    pg = PoolGeom(N, D, H, W, C, k, s, p)
+    x = torch.relu(rnd(N, D, H, W, C, seed=1))          # post-ReLU input: exact-zero ties exercise "first maximum"
+    o_ref, i_ref = CPU.maxpool_fwd(pg, x, True)
+    o, idx = hip.maxpool_fwd(pg, x.to(DEV), True)
+    assert torch.equal(o.cpu(), o_ref)
+    assert torch.equal(idx.cpu(), i_ref)
+    dout = rnd(*o_ref.shape, seed=2)
+    close(hip.maxpool_bwd(pg, dout.to(DEV), idx), CPU.maxpool_bwd(pg, dout, i_ref), 1e-6, "maxpool bwd")
+    o2, none = hip.maxpool_fwd(pg, x.to(DEV), False)
+    assert none is None and torch.equal(o2.cpu(), o_ref)
+
+
+@pytest.mark.parametrize("N,P,C", [(2, 32, 64), (3, 18, 192), (2, 8, 48)])
+def test_gate_fwd_bwd_and_channel_slices(hip, N, P, C):
+    x = torch.relu(rnd(N, P, 1, 1, C, seed=1))
+    w, b = rnd(C, C, 1, 1, 1, seed=2, scale=C ** -0.5), rnd(C, seed=3)
+    o_ref, m_ref, g_ref = CPU.gate_fwd(x, w, b)
+    # write into a channel slice of a wider tensor, as the inception concat does
+    wide = torch.zeros(N, P, 1, 1, C + 40, device=DEV)
+    view = wide[..., 24:24 + C]
+    o, mean, gate = hip.gate_fwd(x.to(DEV), w.to(DEV), b.to(DEV), out=view)
+    close(view, o_ref, 1e-5, "gate out (slice)")
+    assert float(wide[..., :24].abs().max()) == 0 and float(wide[..., 24 + C:].abs().max()) == 0
+    close(mean, m_ref, 1e-5, "gate mean")
+    close(gate, g_ref, 1e-5, "gate")
+    dwide = rnd(N, P, 1, 1, C + 40, seed=4)
+    dw_ref, db_ref = torch.empty_like(w), torch.empty_like(b)
+    dx_ref = CPU.gate_bwd(x, dwide[..., 24:24 + C], w, m_ref, g_ref, dw_ref, db_ref)
+    dw, db = torch.empty_like(w, device=DEV), torch.empty_like(b, device=DEV)
+    dx = hip.gate_bwd(x.to(DEV), dwide.to(DEV)[..., 24:24 + C], w.to(DEV), mean, gate, dw, db)
+    close(dx, dx_ref, 2e-5, "gate dx")
+    close(dw, dw_ref, 2e-5, "gate dw")
+    close(db, db_ref, 2e-5, "gate db")
+
+
+def test_bn_act_pool_channel_slices(hip):
+    N, D, H, W, C = 2, 3, 5, 5, 64
+    pg = PoolGeom(N, D, H, W, C)
+    y = rnd(N, D, H, W, C, seed=1) * 2
+    gamma, beta = rnd(C, seed=3) + 1.5, rnd(C, seed=4) * 0.5
+    rows = N * D * H * W
+    yy = y.reshape(rows, C).double()
+    part = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1).float().unsqueeze(0)
+    mi, ss = CPU.bn_finalize(part, rows, None, gamma, beta, 1e-3, 0.001, None, None)
+    out_ref = CPU.bn_act_pool_fwd(pg, y, ss, None, True)
+    wide = torch.zeros(N, D, H, W, C + 16, device=DEV)
+    hip.bn_act_pool_fwd(pg, y.to(DEV), ss.to(DEV), None, True, out=wide[..., 16:])
+    close(wide[..., 16:], out_ref, 1e-6, "sliced fwd")
+    assert float(wide[..., :16].abs().max()) == 0
+    dwide = rnd(N, D, H, W, C + 16, seed=5)
+    dg_ref, db_ref = torch.empty(C), torch.empty(C)
+    dy_ref, _ = CPU.bn_act_pool_bwd(pg, y, None, dwide[..., 16:], gamma, mi, ss, True, False, dg_ref, db_ref)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dy, _ = hip.bn_act_pool_bwd(pg, y.to(DEV), None, dwide.to(DEV)[..., 16:], gamma.to(DEV), mi.to(DEV), ss.to(DEV), True,
+                                False, dg, db)
+    close(dy, dy_ref, 2e-5, "sliced bwd dy")
+    close(dg, dg_ref, 2e-5, "sliced dgamma")
