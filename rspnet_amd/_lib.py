@@ -12,7 +12,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librspnet_hip.so")
+LIB_PATH = os.environ.get("RSPNET_HIP_LIB") or os.path.join(_HERE, "librspnet_hip.so")   # override: tuning builds only
 
 c_f32p = C.c_void_p
 c_i32p = C.c_void_p

@@ -22,6 +22,9 @@ constexpr int BK = 32;         // K-chunk (floats)
 constexpr int LDK = BK + 4;    // LDS row pitch: 36 floats => ds_read_b128 conflict-free (9r mod 16 distinct)
 constexpr int MAX_TAPS = 343;  // 7x7x7
 
+// 64 B of zeros: out-of-bounds taps / rows / K-tail lanes load from here instead of branching around the load
+__device__ __attribute__((aligned(64))) float g_zero[16];
+
 struct IgemmParams {
   const float* __restrict__ x;
   const float* __restrict__ w;     // packed [Cout][Kld]
@@ -42,6 +45,8 @@ struct IgemmParams {
   int K, Kld, nchunks;
   int splitk, chunks_per_split;
   int m_tiles, n_tiles;
+  const float* __restrict__ zero;  // >= 64 B of zeros (g_zero)
+  int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC>
@@ -117,51 +122,68 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
   floatx4 areg[AR], breg[BR];
 
+  // (tap, ci) of this thread's k position(s) in the NEXT chunk to load, advanced incrementally (no division in the loop);
+  // the tap-table entry is fetched one chunk ahead so its LDS latency hides behind the MFMAs.
+  constexpr int NE = VEC == 4 ? 1 : 4;
+  const int adv_tap = BK / p.Cin, adv_ci = BK % p.Cin;
+  int ntap[NE], nci[NE];
+  int4 ntt[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int k = kc_begin * BK + kcol + e;
+    ntap[e] = k / p.Cin;
+    nci[e] = k - ntap[e] * p.Cin;
+    ntt[e] = taptab[min(ntap[e], ntaps - 1)];
+  }
+  const float* const zero = p.zero;
+  // element offset of the zero page relative to p.x, so an invalid lane only swaps an offset (pure v_cndmask, no branch)
+  const long long zoff = (reinterpret_cast<const char*>(p.zero) - reinterpret_cast<const char*>(p.x)) / 4;
+
   auto load_chunk = [&](int kc) {
     const int k = kc * BK + kcol;
     // weights
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (wok[i] && k < p.Kld) v = *reinterpret_cast<const floatx4*>(wrow[i] + k);
-      breg[i] = v;
+      const float* src = (wok[i] && k < p.Kld) ? wrow[i] + k : zero;
+      breg[i] = *reinterpret_cast<const floatx4*>(src);
     }
-    // activations
+    // activations: out-of-bounds taps / rows / K tail read the zero page instead of branching around the load
     if (VEC == 4) {
-      int4 tt = make_int4(0, 0, 0, 0);
-      int ci = 0;
-      const bool kok = k < p.K;
-      if (kok) {
-        const int tap = k / p.Cin;
-        ci = k - tap * p.Cin;
-        tt = taptab[tap];
-      }
+      const int4 tt = ntt[0];
+      const bool kok = ntap[0] < ntaps;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        floatx4 v = {0.f, 0.f, 0.f, 0.f};
         const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
-        if (kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-          v = *reinterpret_cast<const floatx4*>(p.x + abase[i] + tt.w + ci);
-        areg[i] = v;
+        const bool ok = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        const long long real = abase[i] + tt.w + nci[0];
+        const long long m = ok ? -1ll : 0ll;
+        areg[i] = *reinterpret_cast<const floatx4*>(p.x + ((real & m) | (zoff & ~m)));
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < AR; ++i) areg[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int ke = k + e;
-        if (ke < p.K) {
-          const int tap = ke / p.Cin;
-          const int ci = ke - tap * p.Cin;
-          const int4 tt = taptab[tap];
+        const int4 tt = ntt[e];
+        const bool kok = ntap[e] < ntaps;
 #pragma unroll
-          for (int i = 0; i < AR; ++i) {
-            const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
-            if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-              areg[i][e] = p.x[abase[i] + tt.w + ci];
-          }
+        for (int i = 0; i < AR; ++i) {
+          const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
+          const bool ok = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+          const long long real = abase[i] + tt.w + nci[e];
+          const long long m = ok ? -1ll : 0ll;
+          areg[i][e] = p.x[(real & m) | (zoff & ~m)];
         }
       }
+    }
+    // advance to the following chunk and prefetch its tap entry
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      nci[e] += adv_ci;
+      ntap[e] += adv_tap;
+      if (nci[e] >= p.Cin) {
+        nci[e] -= p.Cin;
+        ++ntap[e];
+      }
+      ntt[e] = taptab[min(ntap[e], ntaps - 1)];
     }
   };
   auto store_chunk = [&](int buf) {
@@ -190,7 +212,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   int buf = 0;
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const bool more = kc + 1 < kc_end;
+#ifdef RSP_TUNE
+    if (more && !(p.tune & 1)) load_chunk(kc + 1);
+#else
     if (more) load_chunk(kc + 1);  // global loads in flight under this chunk's MFMAs
+#endif
 
     const float* a = As + buf * BM * LDK + (wm * WM + l32) * LDK + h * 16;
     const float* b = Bs + buf * BN * LDK + (wn * WN + l32) * LDK + h * 16;
@@ -209,8 +235,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     }
+#ifdef RSP_TUNE
+    if (more && !(p.tune & 2)) store_chunk(buf ^ 1);
+    if (!(p.tune & 4)) __syncthreads();
+#else
     if (more) store_chunk(buf ^ 1);
     __syncthreads();
+#endif
     buf ^= 1;
   }
 
@@ -401,13 +432,26 @@ int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   return vec4 ? launch_cfg<128, 32, 4, 1, 4>(p, s) : launch_cfg<128, 32, 4, 1, 1>(p, s);
 }
 
-// Heuristic split-K: only when the tile grid cannot fill 256 CUs x 2 workgroups.
-int choose_splitk(int tiles, int nchunks) {
-  if (tiles >= 384 || nchunks < 16) return 1;
-  int sk = rsp_cdiv(1024, tiles);
-  sk = sk > 16 ? 16 : sk;
-  while (sk > 1 && nchunks / sk < 8) --sk;
-  return sk < 1 ? 1 : sk;
+// Split-K by a small cost model.  256 CUs x 2 resident workgroups = 512 slots; equal-sized tiles run in
+// ceil(units/512) rounds, so e.g. C3D conv4 (784 tiles) wastes 1/4 of the machine unsplit.  Splitting K by S makes the
+// rounds shorter (and more numerous) at the price of an fp32 partial round trip + reduce launch.
+int choose_splitk(int tiles, int nchunks, long long M, int Cout) {
+  if (tiles >= 4096 || nchunks < 8) return 1;
+  const double t_chunk2 = 4.7e-6, t_chunk1 = 2.7e-6;   // measured per-chunk time with 2 / 1 workgroups on a CU
+  int best = 1;
+  double best_t = 1e30;
+  for (int S = 1; S <= 16 && S * 4 <= nchunks; ++S) {
+    const int cps = rsp_cdiv(nchunks, S), Se = rsp_cdiv(nchunks, cps);
+    if (Se != S) continue;
+    const long long units = (long long)tiles * Se;
+    double t = units <= 256 ? (cps + 3) * t_chunk1 : (double)rsp_cdiv(units, 512) * (cps + 3) * t_chunk2;
+    if (Se > 1) t += 4e-6 + (double)(Se + 1) * M * Cout * 4.0 / 3.0e12;
+    if (t < best_t * 0.97) {
+      best_t = t;
+      best = Se;
+    }
+  }
+  return best;
 }
 
 bool desc_ok(const rsp_conv3d_desc* d) {
@@ -441,10 +485,26 @@ void fill_reduce(ReduceParams& r, const IgemmParams& p) {
 }
 
 int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
+  static const float* zero_page = nullptr;
+  if (!zero_page) {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero)) != hipSuccess || !z) {
+      rsp_set_error("hipGetSymbolAddress(g_zero) failed");
+      return RSP_ELAUNCH;
+    }
+    zero_page = reinterpret_cast<const float*>(z);
+  }
+  p.zero = zero_page;
+#ifdef RSP_TUNE
+  {
+    const char* e = getenv("RSP_TUNE");
+    p.tune = e ? atoi(e) : 0;
+  }
+#endif
   p.nchunks = rsp_cdiv(p.K, BK);
   const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
   const int tiles = rsp_cdiv(p.M, 128) * rsp_cdiv(p.Cout, bn);
-  int sk = choose_splitk(tiles, p.nchunks);
+  int sk = choose_splitk(tiles, p.nchunks, p.M, p.Cout);
   if (sk > 1) {
     const size_t need = (size_t)sk * p.M * p.Cout * sizeof(float);
     if (!workspace || ws_bytes < need) sk = 1;  // degrade gracefully: still correct
@@ -466,7 +526,7 @@ int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipSt
 
 size_t igemm_partial_bytes(long long M, int Cout, int K) {
   const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-  const int sk = choose_splitk(rsp_cdiv(M, 128) * rsp_cdiv(Cout, bn), rsp_cdiv(K, BK));
+  const int sk = choose_splitk(rsp_cdiv(M, 128) * rsp_cdiv(Cout, bn), rsp_cdiv(K, BK), M, Cout);
   return sk > 1 ? (size_t)sk * M * Cout * sizeof(float) : 0;
 }
 

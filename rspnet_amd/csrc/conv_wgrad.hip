@@ -15,6 +15,8 @@ namespace {
 constexpr int RK = 32;  // rows per chunk
 constexpr int MAX_TAPS = 343;
 
+__device__ __attribute__((aligned(64))) float g_wzero[16];
+
 struct WgradParams {
   const float* __restrict__ x;
   const float* __restrict__ dy;
@@ -27,6 +29,7 @@ struct WgradParams {
   int K, Kld;
   int rows_per_split, splitm;
   int co_tiles, k_tiles;
+  const float* __restrict__ zero;  // >= 64 B of zeros
 };
 
 struct RowPos {
@@ -111,45 +114,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
   floatx4 areg[AR], breg[BR];
 
+  // invalid rows / taps / channels read a zero page instead of branching around the load (pure v_cndmask)
+  const long long zoff_a = (reinterpret_cast<const char*>(p.zero) - reinterpret_cast<const char*>(p.dy)) / 4;
+  const long long zoff_b = (reinterpret_cast<const char*>(p.zero) - reinterpret_cast<const char*>(p.x)) / 4;
+
   auto load_chunk = [&](int rbase) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int r = rbase + arow + i * AROWS_PER_PASS;
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < row_end) {
-        const float* src = p.dy + (long long)r * p.dy_ld + aco;
-        if (VECA) {
-          if (aco < p.Cout) v = *reinterpret_cast<const floatx4*>(src);
-        } else {
+      const long long real = (long long)r * p.dy_ld + aco;
+      if (VECA) {
+        const long long m = (r < row_end && aco < p.Cout) ? -1ll : 0ll;
+        areg[i] = *reinterpret_cast<const floatx4*>(p.dy + ((real & m) | (zoff_a & ~m)));
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (aco + e < p.Cout) v[e] = src[e];
+        for (int e = 0; e < 4; ++e) {
+          const long long m = (r < row_end && aco + e < p.Cout) ? -1ll : 0ll;
+          areg[i][e] = p.dy[((real + e) & m) | (zoff_a & ~m)];
         }
       }
-      areg[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const int r = rbase + brow + i * BROWS_PER_PASS;
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < row_end) {
-        const RowPos& rp = bpos[i];
-        const int id0 = rp.gd * p.sD, ih0 = rp.gh * p.sH, iw0 = rp.gw * p.sW;
-        const long long base = ((((long long)rp.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0) * p.in_ld;
-        if (VECB) {
-          const int id = id0 + boffd[0], ih = ih0 + boffh[0], iw = iw0 + boffw[0];
-          if (bok[0] && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-            v = *reinterpret_cast<const floatx4*>(p.x + base + bdelta[0]);
-        } else {
+      const RowPos& rp = bpos[i];
+      const int id0 = rp.gd * p.sD, ih0 = rp.gh * p.sH, iw0 = rp.gw * p.sW;
+      const long long base = ((((long long)rp.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0) * p.in_ld;
+      if (VECB) {
+        const int id = id0 + boffd[0], ih = ih0 + boffh[0], iw = iw0 + boffw[0];
+        const bool ok = r < row_end && bok[0] && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
+                        (unsigned)iw < (unsigned)p.Wi;
+        const long long m = ok ? -1ll : 0ll;
+        breg[i] = *reinterpret_cast<const floatx4*>(p.x + (((base + bdelta[0]) & m) | (zoff_b & ~m)));
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int id = id0 + boffd[e], ih = ih0 + boffh[e], iw = iw0 + boffw[e];
-            if (bok[e] && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-              v[e] = p.x[base + bdelta[e]];
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int id = id0 + boffd[e], ih = ih0 + boffh[e], iw = iw0 + boffw[e];
+          const bool ok = r < row_end && bok[e] && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
+                          (unsigned)iw < (unsigned)p.Wi;
+          const long long m = ok ? -1ll : 0ll;
+          breg[i][e] = p.x[((base + bdelta[e]) & m) | (zoff_b & ~m)];
         }
       }
-      breg[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) advance(bpos[i], RK, p.Gd, p.Gh, p.Gw);
@@ -346,8 +352,18 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
     return RSP_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
+  static const float* zero_page = nullptr;
+  if (!zero_page) {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_wzero)) != hipSuccess || !z) {
+      rsp_set_error("hipGetSymbolAddress(g_wzero) failed");
+      return RSP_ELAUNCH;
+    }
+    zero_page = reinterpret_cast<const float*>(z);
+  }
   WgradParams p;
   memset(&p, 0, sizeof p);
+  p.zero = zero_page;
   p.x = x; p.dy = dy; p.partial = reinterpret_cast<float*>(workspace);
   p.M = d->N * d->Do * d->Ho * d->Wo;
   p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Ablation build of the library (-DRSP_TUNE): used only by tools/conv_bench.py, never by the product or the tests.
+set -e
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+SRC="$HERE/../rspnet_amd/csrc"
+OUT="$HERE/librspnet_hip_tune.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRSP_TUNE=1 -Wno-unused-result -I"$HERE/../include" -I"$SRC" \
+  "$SRC"/errors.hip "$SRC"/conv_igemm.hip "$SRC"/conv_wgrad.hip "$SRC"/bn_pool.hip "$SRC"/pool_gate.hip "$SRC"/head_loss.hip "$SRC"/glue.hip -o "$OUT"
+echo "built $OUT"
