@@ -169,9 +169,10 @@ int rsp_queue_enqueue(float* queue, int32_t dim, int32_t K, int32_t ptr, const f
  * ------------------------------------------------------------------------------------------------------- */
 /* _diff_speed frame gather (:421-443) fused with the shuffle-BN sample permutation (:384-387) and the
  * NCDHW -> NDHWC layout change:  out[j] = im[src[j]][:, frames(step[j])], frames(s) = 0, s, 2s, ... (T_out of them).
- * im: (B_in, C, T_in, H, W) NCDHW as the reference's data loader hands it over; out: [B_out][T_out][H][W][C]. */
+ * im: (B_in, C, T_in, H, W) NCDHW as the reference's data loader hands it over; out: [B_out][T_out][H][W][C_out],
+ * C_out >= C, extra channels zero (C_out = 4 lets a 3-channel stem convolution use 16-byte gathers). */
 int rsp_clip_gather(const float* im, int32_t B_in, int32_t C, int32_t T_in, int32_t H, int32_t W, const int32_t* src,
-                    const int32_t* step, int32_t B_out, int32_t T_out, float* out, void* stream);
+                    const int32_t* step, int32_t B_out, int32_t T_out, int32_t C_out, float* out, void* stream);
 
 /* _momentum_update_key_encoder (:337-343) on flat parameter buffers: k = k*m + q*(1-m). */
 int rsp_momentum_update(float* k, const float* q, int64_t n, float m, void* stream);

@@ -385,6 +385,76 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
   }
 }
 
+// pass 2, output-centric fast path: windows tile the input exactly (Di % sT == 0 ...) and hold <= 8 positions, so one
+// thread owns a whole window: every y element is read once and every dy element written once (the input-centric
+// kernel above re-reads the window for every element).
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  const long long total = (long long)d.N * d.Do * d.Ho * d.Wo * p.cg;
+  const double invn = 1.0 / (double)p.count;
+  const int nwin = d.kT * d.kH * d.kW;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
+    const int cgi = (int)(idx % p.cg);
+    long long q = idx / p.cg;
+    const long long op = q;
+    const int ow = (int)(q % d.Wo); q /= d.Wo;
+    const int oh = (int)(q % d.Ho); q /= d.Ho;
+    const int od = (int)(q % d.Do);
+    const int n = (int)(q / d.Do);
+    const int c = cgi * VEC;
+    float sc[VEC], sh[VEC], mean[VEC], invstd[VEC], gam[VEC], g[VEC], m1[VEC], m2[VEC];
+    load_vec<VEC>(p.ss + c, sc);
+    load_vec<VEC>(p.ss + d.C + c, sh);
+    load_vec<VEC>(p.mi + c, mean);
+    load_vec<VEC>(p.mi + d.C + c, invstd);
+    if (p.gamma) load_vec<VEC>(p.gamma + c, gam);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) gam[e] = 1.f;
+    }
+    load_vec<VEC>(p.dout + op * d.out_ld + c, g);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      m1[e] = (float)(p.sums[2 * (c + e)] * invn);
+      m2[e] = (float)(p.sums[2 * (c + e) + 1] * invn);
+    }
+    float yv[8][VEC], zv[8][VEC], best[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int wdx = 0; wdx < 8; ++wdx) {
+      if (wdx < nwin) {
+        const int kw = wdx % d.kW, kh = (wdx / d.kW) % d.kH, kt = wdx / (d.kW * d.kH);
+        const long long pos = (((long long)n * d.Di + od * d.sT + kt) * d.Hi + oh * d.sH + kh) * d.Wi + ow * d.sW + kw;
+        zval<VEC>(p, pos, c, sc, sh, yv[wdx], zv[wdx]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float v = p.relu ? fmaxf(zv[wdx][e], 0.f) : zv[wdx][e];
+          if (v > best[e]) { best[e] = v; bi[e] = wdx; }     // first maximum in scan order
+        }
+      }
+    }
+#pragma unroll
+    for (int wdx = 0; wdx < 8; ++wdx) {
+      if (wdx < nwin) {
+        const int kw = wdx % d.kW, kh = (wdx / d.kW) % d.kH, kt = wdx / (d.kW * d.kH);
+        const long long pos = (((long long)n * d.Di + od * d.sT + kt) * d.Hi + oh * d.sH + kh) * d.Wi + ow * d.sW + kw;
+        float o[VEC], dz[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          dz[e] = (bi[e] == wdx && !(p.relu && !(best[e] > 0.f))) ? g[e] : 0.f;
+          const float xhat = (yv[wdx][e] - mean[e]) * invstd[e];
+          o[e] = gam[e] * invstd[e] * (dz[e] - m1[e] - xhat * m2[e]);
+        }
+        store_vec<VEC>(p.dy + pos * d.in_ld + c, o);
+        if (p.dres) store_vec<VEC>(p.dres + pos * d.res_ld + c, dz);
+      }
+    }
+  }
+}
+
 bool pool_ok(const rsp_pool3d_desc* d, bool need_disjoint) {
   if (!d) return false;
   if (d->N <= 0 || d->C <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0) return false;
@@ -506,6 +576,13 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
                      dgamma, dbeta);
   rc = rsp_check_launch("bn_bwd_finalize_kernel");
   if (rc != RSP_OK) return rc;
+  const bool exact = d->Di % d->sT == 0 && d->Hi % d->sH == 0 && d->Wi % d->sW == 0 && d->kT * d->kH * d->kW <= 8;
+  if (exact) {
+    const long long total = (long long)d->N * d->Do * d->Ho * d->Wo * p.cg;
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, p);
+    return rsp_check_launch("bn_bwd_apply_win_kernel");
+  }
   const long long total = (long long)d->N * d->Di * d->Hi * d->Wi * p.cg;
   if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, p);

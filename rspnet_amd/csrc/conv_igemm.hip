@@ -49,18 +49,25 @@ struct IgemmParams {
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(TM >= 1 && TN >= 1, "tile");
 
+  // VEC==4: tiles are filled by LDS-DMA (global_load_lds_dwordx4), which writes 64 lanes x 16 B linearly, so rows are
+  // unpadded (32 floats) and bank conflicts are avoided by an XOR swizzle of the 16-byte slot applied on the SOURCE
+  // address and on the fragment read:  physical slot = logical slot ^ ((row >> 1) & 7)
+  // (ds_read_b128 lane groups then hit 16 distinct 16-byte slots of the 256-byte bank row).
+  // VEC==1 (scalar gather, Cin % 4 != 0): register staging into rows padded to 36 floats.
+  constexpr bool DMA = VEC == 4;
+  constexpr int LDR = DMA ? BK : LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* As = reinterpret_cast<float*>(smem_raw);             // [2][BM][LDK]
-  float* Bs = As + 2 * BM * LDK;                              // [2][BN][LDK]
-  int4* taptab = reinterpret_cast<int4*>(Bs + 2 * BN * LDK);  // [ntaps] {offd, offh, offw, delta}
+  float* As = reinterpret_cast<float*>(smem_raw);             // [2][BM][LDR]
+  float* Bs = As + 2 * BM * LDR;                              // [2][BN][LDR]
+  int4* taptab = reinterpret_cast<int4*>(Bs + 2 * BN * LDR);  // [ntaps] {offd, offh, offw, delta}
   long long* rowaddr = reinterpret_cast<long long*>(taptab + MAX_TAPS + 1);  // [BM]
 
   const int t = threadIdx.x;
@@ -86,7 +93,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
   // ---- per-thread row geometry for the A (im2col) tile ----------------------------------------------------
   const int arow = t >> 3;        // + 32*i
-  const int kcol = (t & 7) * 4;   // k offset inside the chunk
+  // this thread's k offset inside the chunk: linear for register staging, de-swizzled for the DMA path (the LDS
+  // position is fixed by the lane, the data it must fetch is not)
+  const int kcol = (DMA ? ((t & 7) ^ ((arow >> 1) & 7)) : (t & 7)) * 4;
   long long abase[AR];
   int aid[AR], aih[AR], aiw[AR];
 #pragma unroll
@@ -139,44 +148,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   // element offset of the zero page relative to p.x, so an invalid lane only swaps an offset (pure v_cndmask, no branch)
   const long long zoff = (reinterpret_cast<const char*>(p.zero) - reinterpret_cast<const char*>(p.x)) / 4;
 
-  auto load_chunk = [&](int kc) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  auto load_chunk = [&](int kc, int buf) {
     const int k = kc * BK + kcol;
-    // weights
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const float* src = (wok[i] && k < p.Kld) ? wrow[i] + k : zero;
-      breg[i] = *reinterpret_cast<const floatx4*>(src);
-    }
-    // activations: out-of-bounds taps / rows / K tail read the zero page instead of branching around the load
-    if (VEC == 4) {
-      const int4 tt = ntt[0];
-      const bool kok = ntap[0] < ntaps;
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
-        const bool ok = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-        const long long real = abase[i] + tt.w + nci[0];
-        const long long m = ok ? -1ll : 0ll;
-        areg[i] = *reinterpret_cast<const floatx4*>(p.x + ((real & m) | (zoff & ~m)));
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int4 tt = ntt[e];
-        const bool kok = ntap[e] < ntaps;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-          const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
-          const bool ok = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-          const long long real = abase[i] + tt.w + nci[e];
-          const long long m = ok ? -1ll : 0ll;
-          areg[i][e] = p.x[(real & m) | (zoff & ~m)];
-        }
-      }
-    }
-    // advance to the following chunk and prefetch its tap entry
+    // current chunk's tap state; then advance and prefetch the following chunk's tap entry BEFORE any DMA is issued
+    int ctap[NE], cci[NE];
+    int4 ctt[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
+      ctap[e] = ntap[e];
+      cci[e] = nci[e];
+      ctt[e] = ntt[e];
       nci[e] += adv_ci;
       ntap[e] += adv_tap;
       if (nci[e] >= p.Cin) {
@@ -185,14 +169,55 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       }
       ntt[e] = taptab[min(ntap[e], ntaps - 1)];
     }
+    // weights
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const float* src = (wok[i] && k < p.Kld) ? wrow[i] + k : zero;
+      if (DMA) {
+        // wave-uniform LDS base; the hardware adds lane * 16 B
+        float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      } else {
+        breg[i] = *reinterpret_cast<const floatx4*>(src);
+      }
+    }
+    // activations: out-of-bounds taps / rows / K tail read the zero page instead of branching around the load
+    if (VEC == 4) {
+      const int4 tt = ctt[0];
+      const bool kok = ctap[0] < ntaps;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
+        const bool ok = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        const long long real = abase[i] + tt.w + cci[0];
+        const long long m = ok ? -1ll : 0ll;
+        float* dst = As + buf * BM * LDR + i * 32 * LDR + wave * 64 * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.x + ((real & m) | (zoff & ~m))), (lptr_t)dst, 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int4 tt = ctt[e];
+        const bool kok = ctap[e] < ntaps;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
+          const bool ok = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+          const long long real = abase[i] + tt.w + cci[e];
+          const long long m = ok ? -1ll : 0ll;
+          areg[i][e] = p.x[(real & m) | (zoff & ~m)];
+        }
+      }
+    }
   };
   auto store_chunk = [&](int buf) {
-    float* a = As + buf * BM * LDK;
-    float* b = Bs + buf * BN * LDK;
+    if (DMA) return;   // the DMA already landed the tile in LDS
+    float* a = As + buf * BM * LDR;
+    float* b = Bs + buf * BN * LDR;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<floatx4*>(a + (arow + 32 * i) * LDK + kcol) = areg[i];
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<floatx4*>(a + (arow + 32 * i) * LDR + kcol) = areg[i];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) *reinterpret_cast<floatx4*>(b + (arow + 32 * i) * LDK + kcol) = breg[i];
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<floatx4*>(b + (arow + 32 * i) * LDR + kcol) = breg[i];
   };
 
   floatx16 acc[TM][TN];
@@ -204,42 +229,54 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (kc_begin < kc_end) {
-    load_chunk(kc_begin);
+    load_chunk(kc_begin, 0);
     store_chunk(0);
   }
-  __syncthreads();
+  __syncthreads();   // (with DMA in flight hipcc emits s_waitcnt vmcnt(0) before the barrier: the tile has landed)
 
   int buf = 0;
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const bool more = kc + 1 < kc_end;
-#ifdef RSP_TUNE
-    if (more && !(p.tune & 1)) load_chunk(kc + 1);
-#else
-    if (more) load_chunk(kc + 1);  // global loads in flight under this chunk's MFMAs
-#endif
-
-    const float* a = As + buf * BM * LDK + (wm * WM + l32) * LDK + h * 16;
-    const float* b = Bs + buf * BN * LDK + (wn * WN + l32) * LDK + h * 16;
+    // 1. this chunk's operand fragments -> registers.  They are read BEFORE the next chunk's LDS-DMA is issued: hipcc
+    //    orders every ds_read behind all pending LDS-DMA (s_waitcnt vmcnt(0)), so a read issued after the DMA would
+    //    serialise the copy with the MFMAs instead of overlapping it.
+    const float* a = As + buf * BM * LDR + (wm * WM + l32) * LDR;
+    const float* b = Bs + buf * BN * LDR + (wn * WN + l32) * LDR;
+    const int swz = DMA ? ((l32 >> 1) & 7) : 0;   // tile row bases are multiples of 32, so (row >> 1) & 7 == (l32 >> 1) & 7
+    floatx4 af[4][TM], bf[4][TN];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      floatx4 af[TM], bf[TN];
+      const int slot = ((h * 4 + kk) ^ swz) * 4;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const floatx4*>(a + i * 32 * LDK + kk * 4);
+      for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const floatx4*>(a + i * 32 * LDR + slot);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const floatx4*>(b + j * 32 * LDK + kk * 4);
+      for (int j = 0; j < TN; ++j) bf[kk][j] = *reinterpret_cast<const floatx4*>(b + j * 32 * LDR + slot);
+    }
+    // 2. next chunk: LDS-DMA (or global loads into registers) in flight under this chunk's MFMAs
+#ifdef RSP_TUNE
+    if (more && !(p.tune & 1)) load_chunk(kc + 1, buf ^ 1);
+#else
+    if (more) load_chunk(kc + 1, buf ^ 1);
+#endif
+    // 3. 16 k-steps x TM x TN MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-    }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i][e], bf[kk][j][e], acc[i][j], 0, 0, 0);
 #ifdef RSP_TUNE
     if (more && !(p.tune & 2)) store_chunk(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
     if (!(p.tune & 4)) __syncthreads();
 #else
     if (more) store_chunk(buf ^ 1);
+    // keep the wait-for-DMA + barrier BEHIND the MFMAs (hipcc otherwise sinks the register-only MFMAs below it, which
+    // exposes the copy latency instead of hiding it under the matrix pipe)
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #endif
     buf ^= 1;
@@ -286,7 +323,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   }
 
   if (p.stat && !p.partial) {
-    // per-channel (sum, sumsq) of the bias-free conv output over this tile's rows; rows >= M contributed zeros.
+    // per-channel (sum, sumsq) of the bias-free conv output per 128-row block; rows >= M contributed zeros.
+    constexpr int SB = BM / 128;             // stat blocks per tile
+    constexpr int WPB = WAVES_M / SB;        // waves (along M) per stat block
+    static_assert(SB >= 1 && WPB >= 1 && WPB * SB == WAVES_M, "stat blocks");
     float* red = As;  // [WAVES_M][BN][2]  (all LDS reads of the main loop are done: barrier above)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -308,16 +348,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       }
     }
     __syncthreads();
-    if (t < BN && n0 + t < p.Cout) {
-      float s = 0.f, ss = 0.f;
+    for (int idx = t; idx < SB * BN; idx += 256) {
+      const int sb = idx / BN, c = idx - sb * BN;
+      if (n0 + c < p.Cout && (long long)(m_tile * SB + sb) * 128 < p.M) {
+        float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) {
-        s += red[(w * BN + t) * 2 + 0];
-        ss += red[(w * BN + t) * 2 + 1];
+        for (int w = 0; w < WPB; ++w) {
+          s += red[((sb * WPB + w) * BN + c) * 2 + 0];
+          ss += red[((sb * WPB + w) * BN + c) * 2 + 1];
+        }
+        float* o = p.stat + ((long long)(m_tile * SB + sb) * p.Cout + n0 + c) * 2;
+        o[0] = s;
+        o[1] = ss;
       }
-      float* o = p.stat + ((long long)m_tile * p.Cout + n0 + t) * 2;
-      o[0] = s;
-      o[1] = ss;
     }
   }
 }
@@ -408,17 +451,18 @@ __global__ void pack_weight_kernel(const PackParams p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
 int launch_cfg(const IgemmParams& p, hipStream_t s) {
-  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) + BM * sizeof(long long);
+  const size_t lds = (size_t)2 * (BM + BN) * (VEC == 4 ? BK : LDK) * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) +
+                     BM * sizeof(long long);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(p.m_tiles * p.n_tiles, p.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("igemm_kernel");
 }
 
@@ -427,6 +471,12 @@ int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
   p.m_tiles = rsp_cdiv(p.M, 128);
   p.n_tiles = rsp_cdiv(p.Cout, bn);
+#ifdef RSP_TUNE
+  if (bn == 128 && vec4 && (p.tune & 8) && p.splitk == 1) {   // experiment: one 256x128 workgroup per CU, 1 wave per SIMD
+    p.m_tiles = rsp_cdiv(p.M, 256);
+    return launch_cfg<256, 128, 2, 2, 4, 1>(p, s);
+  }
+#endif
   if (bn == 128) return vec4 ? launch_cfg<128, 128, 2, 2, 4>(p, s) : launch_cfg<128, 128, 2, 2, 1>(p, s);
   if (bn == 64) return vec4 ? launch_cfg<128, 64, 2, 2, 4>(p, s) : launch_cfg<128, 64, 2, 2, 1>(p, s);
   return vec4 ? launch_cfg<128, 32, 4, 1, 4>(p, s) : launch_cfg<128, 32, 4, 1, 1>(p, s);

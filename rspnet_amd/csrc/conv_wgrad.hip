@@ -113,6 +113,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 
   floatx4 areg[AR], breg[BR];
+  const int st_w = RK % p.Gw, st_h = (RK / p.Gw) % p.Gh, st_d = (RK / (p.Gw * p.Gh)) % p.Gd,
+            st_n = RK / (p.Gw * p.Gh * p.Gd);
 
   // invalid rows / taps / channels read a zero page instead of branching around the load (pure v_cndmask)
   const long long zoff_a = (reinterpret_cast<const char*>(p.zero) - reinterpret_cast<const char*>(p.dy)) / 4;
@@ -157,8 +159,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
       }
     }
+    // next chunk: +RK rows, as a branch-free mixed-radix add (each digit step < its radix, so carries are 0/1)
 #pragma unroll
-    for (int i = 0; i < BR; ++i) advance(bpos[i], RK, p.Gd, p.Gh, p.Gw);
+    for (int i = 0; i < BR; ++i) {
+      RowPos& r = bpos[i];
+      r.gw += st_w;
+      int c = r.gw >= p.Gw;
+      r.gw -= c ? p.Gw : 0;
+      r.gh += st_h + c;
+      c = r.gh >= p.Gh;
+      r.gh -= c ? p.Gh : 0;
+      r.gd += st_d + c;
+      c = r.gd >= p.Gd;
+      r.gd -= c ? p.Gd : 0;
+      r.n += st_n + c;
+    }
   };
   auto store_chunk = [&](int buf) {
     float* a = At + buf * RK * BM;

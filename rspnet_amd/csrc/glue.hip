@@ -8,7 +8,7 @@ namespace {
 // out[j][t][h][w][c] = im[src[j]][c][t*step[j]][h][w]      (NCDHW in, NDHWC out)
 __global__ __launch_bounds__(256) void clip_gather_kernel(const float* __restrict__ im, int C, int T_in, int H, int W,
                                                           const int* __restrict__ src, const int* __restrict__ step,
-                                                          int B_out, int T_out, float* __restrict__ out) {
+                                                          int B_out, int T_out, int C_out, float* __restrict__ out) {
   const long long hw = (long long)H * W;
   const long long total = (long long)B_out * T_out * hw;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
@@ -19,8 +19,9 @@ __global__ __launch_bounds__(256) void clip_gather_kernel(const float* __restric
     const int b = src[j];
     const int tin = t * step[j];
     const float* s = im + (((long long)b * C) * T_in + tin) * hw + p;
-    float* o = out + i * C;
+    float* o = out + i * C_out;
     for (int c = 0; c < C; ++c) o[c] = s[(long long)c * T_in * hw];
+    for (int c = C; c < C_out; ++c) o[c] = 0.f;   // zero channel padding (lets a Cin=3 stem use 16-byte gathers)
   }
 }
 
@@ -88,12 +89,13 @@ int grid_for(long long total) {
 extern "C" {
 
 int rsp_clip_gather(const float* im, int32_t B_in, int32_t C, int32_t T_in, int32_t H, int32_t W, const int32_t* src,
-                    const int32_t* step, int32_t B_out, int32_t T_out, float* out, void* stream) {
+                    const int32_t* step, int32_t B_out, int32_t T_out, int32_t C_out, float* out, void* stream) {
   RSP_REQUIRE(im && src && step && out, "rsp_clip_gather: null pointer");
-  RSP_REQUIRE(B_in > 0 && C > 0 && T_in > 0 && H > 0 && W > 0 && B_out > 0 && T_out > 0, "rsp_clip_gather: bad size");
+  RSP_REQUIRE(B_in > 0 && C > 0 && T_in > 0 && H > 0 && W > 0 && B_out > 0 && T_out > 0 && C_out >= C,
+              "rsp_clip_gather: bad size");
   const long long total = (long long)B_out * T_out * H * W;
   hipLaunchKernelGGL(clip_gather_kernel, dim3(grid_for(total) * 2), dim3(256), 0, (hipStream_t)stream, im, C, T_in, H, W, src,
-                     step, B_out, T_out, out);
+                     step, B_out, T_out, C_out, out);
   return rsp_check_launch("clip_gather_kernel");
 }
 

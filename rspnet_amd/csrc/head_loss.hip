@@ -20,16 +20,27 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   float* sr = sm + C;
   const int b = blockIdx.x, t = threadIdx.x;
   const float invP = 1.f / (float)P;
-  for (int c = t; c < C; c += 256) {
-    float s = 0.f;
+  const int lane = t & 63, wave = t >> 6;
+  // mean over positions: wave w takes positions w, w+4, ... (independent loads in flight), fixed-order combine
+  float* part = sm + C + 2 * dim;   // [4][C]
+  for (int c = lane; c < C; c += 64) {
+    float s0 = 0.f, s1 = 0.f;
     const float* f = feat + (long long)b * P * ld + c;
-    for (int p = 0; p < P; ++p) s += f[(long long)p * ld];
-    s *= invP;
+    int p = wave;
+    for (; p + 4 < P; p += 8) {
+      s0 += f[(long long)p * ld];
+      s1 += f[(long long)(p + 4) * ld];
+    }
+    if (p < P) s0 += f[(long long)p * ld];
+    part[wave * C + c] = s0 + s1;
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const float s = ((part[c] + part[C + c]) + (part[2 * C + c] + part[3 * C + c])) * invP;
     sp[c] = s;
     pooled[(long long)b * C + c] = s;
   }
   __syncthreads();
-  const int lane = t & 63, wave = t >> 6;
   for (int o = wave; o < 2 * dim; o += 4) {
     const int hsel = o / dim, oo = o - hsel * dim;
     const float* w = (hsel ? w2 : w1) + (long long)oo * C;
@@ -310,9 +321,9 @@ int rsp_head_fwd(const float* feat, int32_t B, int32_t P, int32_t C, int32_t fea
                  const float* b1, const float* w2, const float* b2, int32_t dim, float* out1, float* out2,
                  float* pooled, float* raw, void* stream) {
   RSP_REQUIRE(feat && w1 && b1 && w2 && b2 && out1 && out2 && pooled && raw, "rsp_head_fwd: null pointer");
-  RSP_REQUIRE(B > 0 && P > 0 && C > 0 && dim > 0 && feat_ld >= C && (C + 2 * dim) * 4 <= 64 * 1024,
+  RSP_REQUIRE(B > 0 && P > 0 && C > 0 && dim > 0 && feat_ld >= C && (5 * C + 2 * dim) * 4 <= 64 * 1024,
               "rsp_head_fwd: bad size");
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)(C + 2 * dim) * 4, (hipStream_t)stream, feat, B, P, C,
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)(5 * C + 2 * dim) * 4, (hipStream_t)stream, feat, B, P, C,
                      feat_ld, w1, b1, w2, b2, dim, out1, out2, pooled, raw);
   return rsp_check_launch("head_fwd_kernel");
 }

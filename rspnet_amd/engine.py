@@ -97,9 +97,22 @@ class PackedWeights:
         key = id(node.conv)
         w = self._cache.get(key)
         if w is None:
-            w = _ops.backend().conv_pack_fwd(cg, node.conv.weight.data)
+            w = _ops.backend().conv_pack_fwd(cg, pad_in_channels(node.conv.weight.data, cg.Cin))
             self._cache[key] = w
         return w
+
+
+def pad_in_channels(w: torch.Tensor, cin: int) -> torch.Tensor:
+    """(Cout,Cin,k..) weight zero-padded to `cin` input channels — the 3-channel stems run on clips padded to 4
+    channels so their im2col gathers are 16-byte loads (INPUT_CHANNEL_PAD)."""
+    if w.shape[1] == cin:
+        return w
+    out = torch.zeros((w.shape[0], cin) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+    out[:, :w.shape[1]] = w
+    return out
+
+
+INPUT_CHANNEL_PAD = 4
 
 
 def _slice_of(slots, into, lead_shape, device):
@@ -125,7 +138,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool) 
             xin = slots[node.src]
             N, D, H, W, Cin = xin.shape
             w = node.conv.weight
-            cg = ConvGeom(N, D, H, W, Cin, w.shape[0], node.k, node.s, node.p)
+            cg = ConvGeom(N, D, H, W, Cin, w.shape[0], node.k, node.s, node.p, Cin_alg=w.shape[1])
             bias = getattr(node.conv, "bias", None)
             y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), None if bias is None else bias.data, True)
             bn = node.bn
@@ -202,11 +215,17 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                     # A conv bias in front of train-mode BatchNorm has an identically-zero gradient (BN subtracts the
                     # batch mean); the reference's autograd produces ~1e-8 rounding noise there.
                     gb.zero_()
-            be.conv_wgrad(sv.cg, sv.x, dy, grad_of(node.conv.weight))
+            gw = grad_of(node.conv.weight)
+            if gw is not None and gw.shape[1] != sv.cg.Cin:      # channel-padded stem: drop the pad channel's gradient
+                gpad = torch.empty((gw.shape[0], sv.cg.Cin) + tuple(gw.shape[2:]), dtype=gw.dtype, device=gw.device)
+                be.conv_wgrad(sv.cg, sv.x, dy, gpad)
+                gw.copy_(gpad[:, :gw.shape[1]])
+            else:
+                be.conv_wgrad(sv.cg, sv.x, dy, gw)
             if after_param_grads is not None:
                 after_param_grads(ni)
             if node.src != plan.input_slot:
-                add_grad(node.src, be.conv_dgrad(sv.cg, dy, node.conv.weight.data))
+                add_grad(node.src, be.conv_dgrad(sv.cg, dy, pad_in_channels(node.conv.weight.data, sv.cg.Cin)))
             del dy, dout, sv
         elif isinstance(node, Pool):
             pg, idx = ctx.saved.pop(ni)

@@ -22,6 +22,7 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 from .. import ops as _ops
+from ..engine import INPUT_CHANNEL_PAD
 from ..flat import FlatEncoderPair
 
 BUCKET_FLOATS = 8 << 20  # 32 MiB gradient buckets: few large xGMI collectives
@@ -193,7 +194,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         owner = G // B
         if ws == 1:
             src = torch.from_numpy(idx.astype(np.int32)).to(dev, non_blocking=True)
-            x = be.clip_gather(im, src, step[src.long()].contiguous(), T_out)
+            x = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
         else:
             send_src, in_splits = [], []
             for r in range(ws):
@@ -203,7 +204,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             send_src = np.concatenate(send_src).astype(np.int32)
             out_splits = [int((owner[rank] == s).sum()) for s in range(ws)]
             src = torch.from_numpy(send_src).to(dev, non_blocking=True)
-            xs = be.clip_gather(im, src, step[src.long()].contiguous(), T_out)
+            xs = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
             x = torch.empty_like(xs)
             dist.all_to_all_single(x, xs, out_splits, in_splits)
         self._nbt_k += 1
@@ -293,7 +294,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
             kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
             src = torch.arange(B, dtype=torch.int32, device=dev)
-            x_q = be.clip_gather(im_q, src, step_q, T_real)
+            x_q = be.clip_gather(im_q, src, step_q, T_real, max(C, INPUT_CHANNEL_PAD))
             self._nbt_q += 1
 
         l1, l2, lp, ln = _PretextFn.apply(self, x_q, (k_A, k_M, kneg_A, kneg_M), *self._q_params)

@@ -10,7 +10,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops as _ops
-from ..engine import PackedWeights, run_backward, run_forward
+from ..engine import INPUT_CHANNEL_PAD, PackedWeights, run_backward, run_forward
 
 
 class Flatten(nn.Module):
@@ -102,7 +102,7 @@ class MultiTaskWrapper(nn.Module):
         B = x.shape[0]
         src = torch.arange(B, dtype=torch.int32, device=x.device)
         step = torch.ones(B, dtype=torch.int32, device=x.device)
-        xn = be.clip_gather(x.contiguous(), src, step, x.shape[2])
+        xn = be.clip_gather(x.contiguous(), src, step, x.shape[2], max(x.shape[1], INPUT_CHANNEL_PAD))
         with torch.no_grad():
             x1, x2, _ = self.forward_ndhwc(xn, keep=False)
         return x1, x2

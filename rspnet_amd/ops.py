@@ -29,6 +29,7 @@ class ConvGeom:
     k: Tuple[int, int, int]
     s: Tuple[int, int, int]
     p: Tuple[int, int, int]
+    Cin_alg: int = 0    # algorithmic input channels when Cin includes zero padding (FLOP accounting only)
 
     @property
     def out_dims(self):
@@ -42,7 +43,7 @@ class ConvGeom:
     @property
     def flops(self):
         """Algorithmic FLOPs of one pass (2*MACs, padded taps included — SURVEY.md §8d)."""
-        return 2 * self.rows * self.Cout * self.Cin * self.k[0] * self.k[1] * self.k[2]
+        return 2 * self.rows * self.Cout * (self.Cin_alg or self.Cin) * self.k[0] * self.k[1] * self.k[2]
 
     def desc(self, in_ld=None, out_ld=None) -> _lib.ConvDesc:
         do, ho, wo = self.out_dims
@@ -350,14 +351,15 @@ class HipOps:
                                               keys.shape[0], _stream()), "rsp_queue_enqueue")
 
     # ---- glue -------------------------------------------------------------------------------------------------
-    def clip_gather(self, im, src, step, T_out: int):
+    def clip_gather(self, im, src, step, T_out: int, c_out: Optional[int] = None):
         _chk(im, "im")
         _chk(src, "src", torch.int32)
         _chk(step, "step", torch.int32)
         B_in, Cc, T_in, H, W = im.shape
         B_out = src.shape[0]
-        out = torch.empty((B_out, T_out, H, W, Cc), dtype=torch.float32, device=im.device)
-        _lib.check(self.lib.rsp_clip_gather(_ptr(im), B_in, Cc, T_in, H, W, _ptr(src), _ptr(step), B_out, T_out, _ptr(out),
+        c_out = c_out or Cc
+        out = torch.empty((B_out, T_out, H, W, c_out), dtype=torch.float32, device=im.device)
+        _lib.check(self.lib.rsp_clip_gather(_ptr(im), B_in, Cc, T_in, H, W, _ptr(src), _ptr(step), B_out, T_out, c_out, _ptr(out),
                                             _stream()), "rsp_clip_gather")
         return out
 

@@ -184,12 +184,12 @@ class CpuOps:
     def queue_enqueue(self, queue, ptr, keys):
         queue[:, ptr:ptr + keys.shape[0]] = keys.t()
 
-    def clip_gather(self, im, src, step, T_out):
-        out = torch.empty((src.shape[0], T_out, im.shape[3], im.shape[4], im.shape[1]), dtype=im.dtype)
+    def clip_gather(self, im, src, step, T_out, c_out=None):
+        out = torch.zeros((src.shape[0], T_out, im.shape[3], im.shape[4], c_out or im.shape[1]), dtype=im.dtype)
         for j in range(src.shape[0]):
             s = int(step[j])
             frames = im[int(src[j])][:, 0:T_out * s:s][:, :T_out]
-            out[j] = frames.permute(1, 2, 3, 0)
+            out[j][..., :im.shape[1]] = frames.permute(1, 2, 3, 0)
         return out
 
     def momentum_update(self, k_flat, q_flat, m):

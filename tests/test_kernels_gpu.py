@@ -242,6 +242,9 @@ def test_clip_gather(hip):
     step = torch.tensor([1, 2, 2, 1, 2], dtype=torch.int32)
     out = hip.clip_gather(im.to(DEV), src.to(DEV), step.to(DEV), 16)
     assert torch.equal(out.cpu(), CPU.clip_gather(im, src, step, 16))
+    out4 = hip.clip_gather(im.to(DEV), src.to(DEV), step.to(DEV), 16, 4)        # zero channel padding for the stems
+    assert torch.equal(out4.cpu(), CPU.clip_gather(im, src, step, 16, 4))
+    assert float(out4[..., 3].abs().max()) == 0
 
 
 @pytest.mark.parametrize("n", [4096, 1000003])

@@ -23,7 +23,7 @@ from rspnet_amd import ops
 from rspnet_amd.ops import ConvGeom
 
 B = args.batch
-LAYERS = [("conv1", 16, 112, 3, 64), ("conv2", 16, 56, 64, 128), ("conv3a", 8, 28, 128, 256), ("conv3b", 8, 28, 256, 256),
+LAYERS = [("conv1", 16, 112, 3, 64), ("conv1p4", 16, 112, 4, 64), ("conv2", 16, 56, 64, 128), ("conv3a", 8, 28, 128, 256), ("conv3b", 8, 28, 256, 256),
           ("conv4a", 4, 14, 256, 512), ("conv4b", 4, 14, 512, 512), ("conv5a", 2, 7, 512, 512)]
 be = ops.backend()
 dev = torch.device("cuda", 0)
@@ -54,7 +54,7 @@ for name, T, HW, cin, cout in LAYERS:
         if what == "fwd":
             ms = timeit(lambda: be.conv_fwd(g, x, wp, None, True))
         elif what == "dgrad":
-            if cin == 3:
+            if cin <= 4:
                 continue
             ms = timeit(lambda: be.conv_dgrad(g, dy, w))
         else:
