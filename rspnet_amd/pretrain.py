@@ -1,0 +1,221 @@
+"""Pretext-training driver for rspnet_amd — the `pretrain.py` surface of the reference (config keys, CLI flag names,
+checkpoint layout, LR policy) around the MI355X-native step.
+
+Mirrors /root/reference/pretrain.py:31-336 for what touches the hot path: Engine construction (:33-110: model factory,
+Loss(margin=2.0, A, M), LR scaling, SGD, CosineAnnealingLR per epoch with eta_min = lr/1000), checkpoint load with the arch
+check (:112-132), the train loop (:147-197: forward, loss, zero_grad/backward/step, top-k accuracies), epoch loop and
+checkpoint dict (:220-260), one process per GPU started with mp.spawn and a tcp://127.0.0.1 rendezvous (:263-336).
+The data pipeline (decord decode + GPU augmentation) is out of scope: the loader here is any iterable
+of (clip_q, clip_k) device tensors; `SyntheticClips` stands in for it.  The config is the resolved JSON the reference
+saves as run_*/config.json (rspnet_amd/config/pretrain/*.json ship the four shipped pretext configs).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import math
+import os
+import socket
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+from .framework.utils.checkpoint import CheckpointManager
+from .framework.utils.environment import scale_learning_rate
+from .moco import Loss, ModelFactory
+from .optim import SGD
+from .utils.moco import replace_moco_k_in_config
+
+logger = logging.getLogger(__name__)
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
+    """Top-k hit rate x100 (framework/metrics/classification.py:6-20); stays on device (no sync)."""
+    maxk = max(topk)
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.view(1, -1).expand_as(pred.t()))
+    return [correct[:k].reshape(-1).float().sum(0) * (100.0 / target.size(0)) for k in topk]
+
+
+class SyntheticClips:
+    """Stand-in data loader: `steps` batches of N(0,1) clip pairs (B,3,T,H,W), generated once on the device."""
+
+    def __init__(self, batch_size, T, size, steps, device, seed=1234):
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.q = torch.randn(batch_size, 3, T, size, size, device=device, generator=g)
+        self.k = torch.randn(batch_size, 3, T, size, size, device=device, generator=g)
+        self.steps = steps
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            yield self.q, self.k
+
+
+class Engine:
+    def __init__(self, args, cfg: dict, local_rank: int, train_loader=None):
+        self.args, self.cfg, self.local_rank = args, cfg, local_rank
+        self.device = torch.device("cuda", local_rank)
+        self.model = ModelFactory(cfg).build_moco_diffloss(device=self.device)
+        self.criterion = Loss(margin=2.0, A=float(cfg["loss_lambda"]["A"]), M=float(cfg["loss_lambda"]["M"]))
+        self.batch_size = int(cfg["batch_size"])
+        self.learning_rate = float(cfg["optimizer"]["lr"])
+        if not args.no_scale_lr:
+            self.learning_rate = scale_learning_rate(self.learning_rate, args.world_size, self.batch_size)
+        o = cfg["optimizer"]
+        self.optimizer = SGD([p for p in self.model.parameters() if p.requires_grad], lr=self.learning_rate,
+                             momentum=float(o["momentum"]), dampening=float(o["dampening"]),
+                             weight_decay=float(o["weight_decay"]), nesterov=bool(o["nesterov"]))
+        self.num_epochs = int(cfg["num_epochs"])          # the jsonnet value is the STRING '200' (moco-train-base.jsonnet:18)
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=self.num_epochs,
+                                                                    eta_min=self.learning_rate / 1000)
+        self.arch = cfg["arch"]
+        self.checkpoint = (CheckpointManager(args.experiment_dir, keep_interval=int(cfg["checkpoint_interval"]))
+                           if local_rank == 0 else None)
+        self.log_interval = int(cfg["log_interval"])
+        self.current_epoch = 0
+        self.best_loss = math.inf
+        self.train_loader = train_loader or SyntheticClips(
+            self.batch_size, int(cfg["temporal_transforms"]["size"]), int(cfg["spatial_transforms"]["size"]),
+            args.steps_per_epoch, self.device, seed=args.seed + local_rank)
+
+    # ---- checkpoints (pretrain.py:112-132) ---------------------------------------------------------------------------
+    def _load_ckpt_file(self, path):
+        states = torch.load(path, map_location=self.device, weights_only=False)
+        if states["arch"] != self.arch:
+            raise ValueError(f'Loading checkpoint arch {states["arch"]} does not match current arch {self.arch}')
+        return states
+
+    def load_checkpoint(self, path):
+        states = self._load_ckpt_file(path)
+        self.model.module.load_state_dict(states["model"])
+        self.optimizer.load_state_dict(states["optimizer"])
+        self.scheduler.load_state_dict(states["scheduler"])
+        self.current_epoch = states["epoch"]
+        self.best_loss = states["best_loss"]
+
+    def load_model(self, path):
+        self.model.module.load_state_dict(self._load_ckpt_file(path)["model"])
+
+    # ---- training (pretrain.py:147-260) ------------------------------------------------------------------------------
+    def train_epoch(self):
+        sums = torch.zeros(4, device=self.device)
+        n = 0
+        t0 = time.perf_counter()
+        for it, (clip_q, clip_k) in enumerate(self.train_loader):
+            output, target, ranking_logits, ranking_target = self.model(clip_q, clip_k)
+            loss, loss_A, loss_M = self.criterion(output, target, ranking_logits, ranking_target)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+            acc1_A, acc5_A = accuracy(output[0], target, topk=(1, 5))
+            acc1_M, = accuracy(torch.cat(ranking_logits, dim=1), target, topk=(1,))
+            sums += torch.stack([loss.detach(), loss_A, loss_M, acc1_A])
+            n += 1
+            if self.local_rank == 0 and (it + 1) % self.log_interval == 0:    # the only host sync (pretrain.py:177-185)
+                m = (sums / n).tolist()
+                logger.info("epoch %d it %d loss %.4f loss_A %.4f loss_M %.4f acc1_A %.2f acc1_M %.2f", self.current_epoch,
+                            it + 1, m[0], m[1], m[2], m[3], float(acc1_M))
+        torch.cuda.synchronize(self.device)
+        dt = time.perf_counter() - t0
+        mean = (sums / max(n, 1)).tolist()
+        return {"loss": mean[0], "loss_A": mean[1], "loss_M": mean[2], "acc1_A": mean[3],
+                "clips_per_s": n * self.batch_size * self.args.world_size / dt}
+
+    def run(self):
+        num_epochs = 1 if self.args.debug else self.num_epochs
+        self.model.train()
+        stats = None
+        while self.current_epoch < num_epochs:
+            stats = self.train_epoch()
+            self.scheduler.step()
+            self.current_epoch += 1
+            if self.local_rank == 0:
+                is_best = stats["loss"] < self.best_loss
+                self.best_loss = min(self.best_loss, stats["loss"])
+                self.checkpoint.save({"epoch": self.current_epoch, "arch": self.arch,
+                                      "model": self.model.module.state_dict(), "best_loss": self.best_loss,
+                                      "optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()},
+                                     is_best, self.current_epoch)
+                logger.info("epoch %d done: %s", self.current_epoch, json.dumps(stats))
+        return stats
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def main_worker(local_rank: int, args, dist_url: str):
+    logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO, format="%(asctime)s %(message)s")
+    torch.manual_seed(args.seed + local_rank)                       # pretrain.py:266-267
+    torch.cuda.set_device(local_rank)
+    if args.world_size > 1:
+        dist.init_process_group("nccl", init_method=dist_url, rank=local_rank, world_size=args.world_size,
+                                device_id=torch.device("cuda", local_rank))
+    with open(args.config) as f:
+        cfg = json.load(f)
+    for snippet in args.ext_config or []:                           # -x overlays: JSON objects merged on top
+        _merge(cfg, json.loads(snippet))
+    replace_moco_k_in_config(cfg)
+    if local_rank == 0:
+        Path(args.experiment_dir).mkdir(parents=True, exist_ok=True)
+        with open(Path(args.experiment_dir) / "config.json", "w") as f:
+            json.dump(cfg, f, indent=2)
+    engine = Engine(args, cfg, local_rank)
+    if args.load_model is not None:
+        engine.load_model(args.load_model)
+    if args.load_checkpoint is not None:
+        engine.load_checkpoint(args.load_checkpoint)
+    stats = engine.run()
+    if args.world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return stats
+
+
+def _merge(base: dict, over: dict):
+    for k, v in over.items():
+        if isinstance(v, dict) and isinstance(base.get(k), dict):
+            _merge(base[k], v)
+        else:
+            base[k] = v
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description="RSPNet pretext training on MI355X (flag names follow the reference's arguments.py)")
+    ap.add_argument("-c", "--config", required=True, help="resolved config JSON (e.g. rspnet_amd/config/pretrain/c3d.json)")
+    ap.add_argument("-x", "--ext-config", action="append", help="JSON object merged over the config (may repeat)")
+    ap.add_argument("-e", "--experiment-dir", required=True)
+    ap.add_argument("--load-checkpoint", default=None)
+    ap.add_argument("--load-model", default=None)
+    ap.add_argument("-d", "--debug", action="store_true", help="1 epoch, DEBUG logging, allows --ws 1 (pretrain.py:312-316)")
+    ap.add_argument("--ws", "--world-size", dest="world_size", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-scale-lr", action="store_true")
+    ap.add_argument("--steps-per-epoch", type=int, default=100, help="synthetic loader length")
+    args = ap.parse_args(argv)
+    if args.world_size is None:
+        args.world_size = torch.cuda.device_count()
+    return args
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    # Unlike the reference (which needs >= 2 ranks for shuffle-BN unless --debug), one GPU is a supported configuration.
+    if args.world_size <= 1:
+        return main_worker(0, args, "")
+    url = f"tcp://127.0.0.1:{_free_port()}"
+    torch.multiprocessing.spawn(main_worker, args=(args, url), nprocs=args.world_size)
+
+
+if __name__ == "__main__":
+    main()
