@@ -141,6 +141,19 @@ int rsp_head_bwd(const float* dout1, const float* dout2, const float* pooled, co
                  float* db1, float* dw2, float* db2, float* dfeat, void* workspace, size_t workspace_bytes,
                  void* stream);
 
+/* 'mlp' head variant (moco/split_wrapper.py:171-179: pool -> Linear(C,C) -> ReLU -> Linear(C,dim) -> F.normalize),
+ * built from generic pieces.  x:[N][P][C] pitch ld; linear weights (Cout,Cin) row-major like nn.Linear.weight. */
+int rsp_spatial_mean_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t ld, float* mean, void* stream);
+int rsp_spatial_mean_bwd(const float* dmean, int32_t N, int32_t P, int32_t C, int32_t ld, float* dx, void* stream);
+int rsp_linear_fwd(const float* x, int32_t B, int32_t Cin, const float* w, const float* bias, int32_t Cout, int relu,
+                   float* y, void* stream);
+size_t rsp_linear_bwd_workspace(int32_t B, int32_t Cout);
+/* y = forward output (for the ReLU mask); dx may be NULL. */
+int rsp_linear_bwd(const float* x, const float* y, const float* dy, const float* w, int32_t B, int32_t Cin, int32_t Cout,
+                   int relu, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+int rsp_l2norm_fwd(const float* x, int32_t B, int32_t dim, float* y, void* stream);
+int rsp_l2norm_bwd(const float* x, const float* dy, int32_t B, int32_t dim, float* dx, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Contrastive block (moco/builder_diffspeed_diffloss.py:521-538) and Loss (:263-283).
  * logits1 = [qA.kA | qA@queue]/T, logits2 = [qA.knegA | qA@queue]/T  each [B][1+K];  lposM = qM.kM/T, lnegM = qM.knegM/T

@@ -29,17 +29,27 @@ CASES = [
     ("resnet18", 8, 64, 64, (1, 2), 1),
     ("r2plus1d-vcop", 4, 32, 64, (1, 2), 1),
     ("s3dg", 4, 64, 64, (1, 2), 1),
+    ("c3d:mlp", 4, 32, 64, (1,), 1),      # fc_type='mlp' heads (moco/split_wrapper.py:171-179)
 ]
 # see ref_harness.run_reference_step "knife-edge guard"; the wide (921/1152-channel) R(2+1)D and S3D-G late layers
 # have too many elements for 1e-5 to be findable, 3e-6 is still > the ~1e-6 rounding band of z.
-MIN_RELU_MARGIN = {"c3d": 3e-6, "resnet18": 3e-6, "r2plus1d-vcop": 3e-6, "s3dg": 3e-6}
+MIN_RELU_MARGIN = {"c3d": 3e-6, "c3d:mlp": 3e-6, "resnet18": 3e-6, "r2plus1d-vcop": 3e-6, "s3dg": 3e-6}
 LR = 0.05
 SPEED = 2
 T_IN = 32
 
 
+def split_arch(tag):
+    """'c3d:mlp' -> ('c3d', 'mlp'); plain arch names use the default 'linear' heads."""
+    return tuple(tag.split(":")) if ":" in tag else (tag, "linear")
+
+
+def tag_file(tag):
+    return tag.replace("-", "_").replace(":", "_")
+
+
 def case_name(arch, ws, seed):
-    return f"{arch.replace('-', '_')}_ws{ws}_s{seed}"
+    return f"{tag_file(arch)}_ws{ws}_s{seed}"
 
 
 def case_inputs(spec, arch, B, HW, K, ws, seed):
@@ -80,7 +90,7 @@ def _worker(rank, ws, arch, B, HW, K, seed, port, tmpdir):
     from oracle import ref_harness as R
     torch.set_num_threads(max(1, 8 // ws))
     R.ensure_process_group(rank, ws, port)
-    model = R.build_reference_model(arch, K=K)
+    model = R.build_reference_model(split_arch(arch)[0], K=K, fc_type=split_arch(arch)[1])
     spec = R.state_spec(model)
     state, mom, clips, perms_B, sh = case_inputs(spec, arch, B, HW, K, ws, seed)
     res = R.run_reference_step(model, state, clips[rank][0], clips[rank][1], [perms_B[rank], sh[0], sh[1]],
@@ -106,7 +116,7 @@ def run_case(arch, B, HW, K, ws, seed):
                 out.update({k: z[k] for k in z.files})
         with open(os.path.join(tmp, "spec.json")) as f:
             spec = json.load(f)
-    out["meta"] = np.array(json.dumps(dict(arch=arch, B=B, HW=HW, K=K, ws=ws, seed=seed, lr=LR, speed=SPEED,
+    out["meta"] = np.array(json.dumps(dict(arch=split_arch(arch)[0], fc_type=split_arch(arch)[1], B=B, HW=HW, K=K, ws=ws, seed=seed, lr=LR, speed=SPEED,
                                            T_in=T_IN, m=0.999, T=0.07, sgd_momentum=0.9, weight_decay=1e-4,
                                            margin=2.0, A=1.0, M=1.0)))
     return out, spec
@@ -136,7 +146,7 @@ def main():
                     continue
                 name = case_name(arch, ws, seed)
                 np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
-                with open(os.path.join(GOLDEN, f"state_spec_{arch.replace('-', '_')}.json"), "w") as f:
+                with open(os.path.join(GOLDEN, f"state_spec_{tag_file(arch)}.json"), "w") as f:
                     json.dump(spec, f, indent=0)
                 index.append([arch, ws, seed])
                 kept += 1

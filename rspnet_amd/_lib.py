@@ -70,6 +70,13 @@ SIGNATURES = {
     "rsp_head_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "rsp_head_bwd_workspace": (_sz, [_i32, _i32]),
     "rsp_head_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_spatial_mean_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "rsp_spatial_mean_bwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "rsp_linear_fwd": (C.c_int, [_p, _i32, _i32, _p, _p, _i32, C.c_int, _p, _p]),
+    "rsp_linear_bwd_workspace": (_sz, [_i32, _i32]),
+    "rsp_linear_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_int, _p, _p, _p, _p, _sz, _p]),
+    "rsp_l2norm_fwd": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "rsp_l2norm_bwd": (C.c_int, [_p, _p, _i32, _i32, _p, _p]),
     "rsp_logits_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p]),
     "rsp_logits_bwd_workspace": (_sz, [_i32, _i32, _i32]),
     "rsp_logits_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),

@@ -313,6 +313,105 @@ __global__ void enqueue_kernel(float* __restrict__ queue, int dim, int K, int pt
   queue[(long long)c * K + ptr + j] = keys[(long long)j * dim + c];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// generic small pieces for the 'mlp' projection head (split_wrapper.py:171-179): mean -> Linear -> ReLU -> Linear -> L2
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smean_kernel(const float* __restrict__ x, int P, int C, int ld, float* __restrict__ mean) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int pp = pl; pp < P; pp += 4) s += x[((long long)n * P + pp) * ld + c];
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x;
+    mean[(long long)n * C + c] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) / (float)P;
+  }
+}
+__global__ void smean_bwd_kernel(const float* __restrict__ dmean, int P, int C, int ld, long long total, float* __restrict__ dx) {
+  const float invP = 1.f / (float)P;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long row = i / C;
+    dx[row * ld + c] = dmean[(row / P) * C + c] * invP;
+  }
+}
+// y[b][o] = act(b[o] + sum_c w[o][c] x[b][c]); one wave per output
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int B, int Cin, int Cout, int relu,
+                                                         float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const long long o = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (o >= (long long)B * Cout) return;
+  const int b = (int)(o / Cout), co = (int)(o % Cout);
+  float s = 0.f;
+  for (int c = lane; c < Cin; c += 64) s = fmaf(w[(long long)co * Cin + c], x[(long long)b * Cin + c], s);
+  s = rsp_wave_sum(s);
+  if (lane == 0) {
+    s += bias ? bias[co] : 0.f;
+    y[o] = relu ? fmaxf(s, 0.f) : s;
+  }
+}
+__global__ void linear_bwd_dz_kernel(const float* __restrict__ y, const float* __restrict__ dy, long long n, int relu,
+                                     float* __restrict__ dz) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) dz[i] = (relu && !(y[i] > 0.f)) ? 0.f : dy[i];
+}
+__global__ void linear_bwd_w_kernel(const float* __restrict__ dz, const float* __restrict__ x, int B, int Cin, int Cout,
+                                    float* __restrict__ dw, float* __restrict__ db) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)Cout * Cin) return;
+  const int o = (int)(i / Cin), c = (int)(i % Cin);
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dz[(long long)b * Cout + o];
+    s = fmaf(d, x[(long long)b * Cin + c], s);
+    sb += d;
+  }
+  dw[i] = s;
+  if (c == 0 && db) db[o] = sb;
+}
+__global__ void linear_bwd_x_kernel(const float* __restrict__ dz, const float* __restrict__ w, int B, int Cin, int Cout,
+                                    float* __restrict__ dx) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)B * Cin) return;
+  const int b = (int)(i / Cin), c = (int)(i % Cin);
+  float s = 0.f;
+  for (int o = 0; o < Cout; ++o) s = fmaf(dz[(long long)b * Cout + o], w[(long long)o * Cin + c], s);
+  dx[i] = s;
+}
+// y = x / max(|x|, 1e-12) per row; one wave per row
+__global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ x, int dim, float* __restrict__ y) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float ss = 0.f;
+  for (int o = lane; o < dim; o += 64) ss = fmaf(x[(long long)b * dim + o], x[(long long)b * dim + o], ss);
+  ss = rsp_wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  for (int o = lane; o < dim; o += 64) y[(long long)b * dim + o] = x[(long long)b * dim + o] / nrm;
+}
+__global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int dim,
+                                                        float* __restrict__ dx) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* r = x + (long long)b * dim;
+  const float* g = dy + (long long)b * dim;
+  float ss = 0.f, dot = 0.f;
+  for (int o = lane; o < dim; o += 64) {
+    ss = fmaf(r[o], r[o], ss);
+    dot = fmaf(r[o], g[o], dot);
+  }
+  ss = rsp_wave_sum(ss);
+  dot = rsp_wave_sum(dot);
+  const float nrm = sqrtf(ss);
+  float* d = dx + (long long)b * dim;
+  if (nrm > 1e-12f) {
+    const float inv = 1.f / nrm, k = dot * inv * inv;
+    for (int o = lane; o < dim; o += 64) d[o] = (g[o] - r[o] * k) * inv;
+  } else {
+    for (int o = lane; o < dim; o += 64) d[o] = g[o] * 1e12f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -429,6 +528,63 @@ int rsp_queue_enqueue(float* queue, int32_t dim, int32_t K, int32_t ptr, const f
   hipLaunchKernelGGL(enqueue_kernel, dim3(rsp_cdiv((long long)n * dim, 256)), dim3(256), 0, (hipStream_t)stream, queue, dim, K,
                      ptr, keys, n);
   return rsp_check_launch("enqueue_kernel");
+}
+
+int rsp_spatial_mean_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t ld, float* mean, void* stream) {
+  RSP_REQUIRE(x && mean && N > 0 && P > 0 && C > 0 && ld >= C, "rsp_spatial_mean_fwd: bad argument");
+  hipLaunchKernelGGL(smean_kernel, dim3(N, rsp_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, P, C, ld, mean);
+  return rsp_check_launch("smean_kernel");
+}
+
+int rsp_spatial_mean_bwd(const float* dmean, int32_t N, int32_t P, int32_t C, int32_t ld, float* dx, void* stream) {
+  RSP_REQUIRE(dmean && dx && N > 0 && P > 0 && C > 0 && ld >= C, "rsp_spatial_mean_bwd: bad argument");
+  const long long total = (long long)N * P * C;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(smean_bwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, dmean, P,
+                     C, ld, total, dx);
+  return rsp_check_launch("smean_bwd_kernel");
+}
+
+int rsp_linear_fwd(const float* x, int32_t B, int32_t Cin, const float* w, const float* bias, int32_t Cout, int relu,
+                   float* y, void* stream) {
+  RSP_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0, "rsp_linear_fwd: bad argument");
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(rsp_cdiv((long long)B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, B,
+                     Cin, Cout, relu, y);
+  return rsp_check_launch("linear_fwd_kernel");
+}
+
+size_t rsp_linear_bwd_workspace(int32_t B, int32_t Cout) { return (size_t)B * Cout * sizeof(float); }
+
+int rsp_linear_bwd(const float* x, const float* y, const float* dy, const float* w, int32_t B, int32_t Cin, int32_t Cout,
+                   int relu, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(x && y && dy && w && dw && workspace && B > 0 && Cin > 0 && Cout > 0, "rsp_linear_bwd: bad argument");
+  if (workspace_bytes < rsp_linear_bwd_workspace(B, Cout)) {
+    rsp_set_error("rsp_linear_bwd: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* dz = reinterpret_cast<float*>(workspace);
+  const long long n = (long long)B * Cout;
+  hipLaunchKernelGGL(linear_bwd_dz_kernel, dim3(rsp_cdiv(n, 256)), dim3(256), 0, s, y, dy, n, relu, dz);
+  int rc = rsp_check_launch("linear_bwd_dz_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(rsp_cdiv((long long)Cout * Cin, 256)), dim3(256), 0, s, dz, x, B, Cin, Cout, dw, db);
+  rc = rsp_check_launch("linear_bwd_w_kernel");
+  if (rc != RSP_OK || !dx) return rc;
+  hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(rsp_cdiv((long long)B * Cin, 256)), dim3(256), 0, s, dz, w, B, Cin, Cout, dx);
+  return rsp_check_launch("linear_bwd_x_kernel");
+}
+
+int rsp_l2norm_fwd(const float* x, int32_t B, int32_t dim, float* y, void* stream) {
+  RSP_REQUIRE(x && y && B > 0 && dim > 0, "rsp_l2norm_fwd: bad argument");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, dim, y);
+  return rsp_check_launch("l2norm_fwd_kernel");
+}
+
+int rsp_l2norm_bwd(const float* x, const float* dy, int32_t B, int32_t dim, float* dx, void* stream) {
+  RSP_REQUIRE(x && dy && dx && B > 0 && dim > 0, "rsp_l2norm_bwd: bad argument");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, dy, dim, dx);
+  return rsp_check_launch("l2norm_bwd_kernel");
 }
 
 }  // extern "C"

@@ -26,8 +26,9 @@ class MultiTaskWrapper(nn.Module):
             raise NotImplementedError("finetune=True is the downstream path (finetune.py), outside the pretext hot path")
         if groups != 1:
             raise NotImplementedError("groups != 1 is not used by any shipped pretext config")
-        if fc_type != "linear":
-            raise NotImplementedError(f"fc_type '{fc_type}': only 'linear' (config/pretrain/moco-train-base.jsonnet:35)")
+        if fc_type not in ("linear", "mlp"):
+            raise NotImplementedError(f"fc_type '{fc_type}': the pretext configs use 'linear' (moco-train-base.jsonnet:35) "
+                                      "or 'mlp'; conv/convbn/speednet heads are not used by any shipped config")
         self.finetune = finetune
         self.moco_dim = num_classes
         self.num_classes = num_classes
@@ -37,8 +38,9 @@ class MultiTaskWrapper(nn.Module):
 
         self.encoder = base_encoder(num_classes=1)
         feat_dim = self._get_feat_dim(self.encoder)
-        self.fc1 = self._get_linear_fc(feat_dim, self.moco_dim)
-        self.fc2 = self._get_linear_fc(feat_dim, self.moco_dim)
+        make = self._get_linear_fc if fc_type == "linear" else self._get_mlp_fc
+        self.fc1 = make(feat_dim, self.moco_dim)
+        self.fc2 = make(feat_dim, self.moco_dim)
 
         self._plan = None
         self._packed = PackedWeights()
@@ -47,6 +49,12 @@ class MultiTaskWrapper(nn.Module):
     @staticmethod
     def _get_linear_fc(feat_dim: int, moco_dim: int):
         return nn.Sequential(nn.AdaptiveAvgPool3d((1, 1, 1)), Flatten(), nn.Linear(feat_dim, moco_dim))
+
+    @staticmethod
+    def _get_mlp_fc(feat_dim: int, moco_dim: int):
+        # split_wrapper.py:171-179: indices 2 and 4 carry the parameters (state-dict keys fcN.2.*, fcN.4.*)
+        return nn.Sequential(nn.AdaptiveAvgPool3d((1, 1, 1)), Flatten(), nn.Linear(feat_dim, feat_dim), nn.ReLU(inplace=True),
+                             nn.Linear(feat_dim, moco_dim))
 
     @staticmethod
     def _get_feat_dim(encoder):
@@ -79,6 +87,17 @@ class MultiTaskWrapper(nn.Module):
         be = _ops.backend()
         feat, ctx = run_forward(self.plan(), x, self._packed, keep)
         self.feat = feat
+        if self.fc_type == "mlp":
+            pooled = be.spatial_mean_fwd(feat)
+            outs, saved = [], []
+            for fc in (self.fc1, self.fc2):
+                hid = be.linear_fwd(pooled, fc[2].weight.data, fc[2].bias.data, True)
+                raw = be.linear_fwd(hid, fc[4].weight.data, fc[4].bias.data, False)
+                outs.append(be.l2norm_fwd(raw))
+                saved.append((hid, raw))
+            if keep:
+                ctx.head = (pooled, saved)
+            return outs[0], outs[1], ctx
         l1, l2 = self.fc1[2], self.fc2[2]
         x1, x2, pooled, raw = be.head_fwd(feat, l1.weight.data, l1.bias.data, l2.weight.data, l2.bias.data)
         if keep:
@@ -87,6 +106,19 @@ class MultiTaskWrapper(nn.Module):
 
     def backward_ndhwc(self, ctx, d1: Tensor, d2: Tensor, grad_of, after_param_grads=None):
         be = _ops.backend()
+        if self.fc_type == "mlp":
+            pooled, saved = ctx.head
+            dpooled = None
+            for fc, (hid, raw), d in ((self.fc1, saved[0], d1), (self.fc2, saved[1], d2)):
+                draw = be.l2norm_bwd(raw, d.contiguous())
+                dhid = be.linear_bwd(hid, raw, draw, fc[4].weight.data, False, grad_of(fc[4].weight), grad_of(fc[4].bias))
+                dp = be.linear_bwd(pooled, hid, dhid, fc[2].weight.data, True, grad_of(fc[2].weight), grad_of(fc[2].bias))
+                dpooled = dp if dpooled is None else dpooled + dp
+            dfeat = be.spatial_mean_bwd(dpooled, ctx.feat_shape)
+            if after_param_grads is not None:
+                after_param_grads(-1)
+            run_backward(self.plan(), ctx, dfeat, grad_of, after_param_grads)
+            return
         l1, l2 = self.fc1[2], self.fc2[2]
         pooled, raw = ctx.head
         dfeat = be.head_bwd(d1.contiguous(), d2.contiguous(), pooled, raw, l1.weight.data, l2.weight.data, ctx.feat_shape,

@@ -300,6 +300,49 @@ class HipOps:
                                          _ptr(dfeat), _ptr(ws), wsb, _stream()), "rsp_head_bwd")
         return dfeat
 
+    # generic pieces of the 'mlp' head
+    def spatial_mean_fwd(self, x):
+        _chk(x, "x")
+        N, D, H, W, Cc = x.shape
+        mean = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.rsp_spatial_mean_fwd(_ptr(x), N, D * H * W, Cc, Cc, _ptr(mean), _stream()), "rsp_spatial_mean_fwd")
+        return mean
+
+    def spatial_mean_bwd(self, dmean, shape):
+        N, D, H, W, Cc = shape
+        dx = torch.empty(shape, dtype=torch.float32, device=dmean.device)
+        _lib.check(self.lib.rsp_spatial_mean_bwd(_ptr(_chk(dmean, "dmean")), N, D * H * W, Cc, Cc, _ptr(dx), _stream()),
+                   "rsp_spatial_mean_bwd")
+        return dx
+
+    def linear_fwd(self, x, w, b, relu: bool):
+        B, Cin = x.shape
+        y = torch.empty((B, w.shape[0]), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.rsp_linear_fwd(_ptr(_chk(x, "x")), B, Cin, _ptr(_chk(w, "w")), _ptr(b), w.shape[0], int(relu), _ptr(y),
+                                           _stream()), "rsp_linear_fwd")
+        return y
+
+    def linear_bwd(self, x, y, dy, w, relu: bool, dw_out, db_out, want_dx=True):
+        B, Cin = x.shape
+        Cout = w.shape[0]
+        dx = torch.empty_like(x) if want_dx else None
+        wsb = self.lib.rsp_linear_bwd_workspace(B, Cout)
+        ws = self._workspace(x.device, wsb)
+        _lib.check(self.lib.rsp_linear_bwd(_ptr(x), _ptr(y), _ptr(_chk(dy, "dy")), _ptr(w), B, Cin, Cout, int(relu), _ptr(dx),
+                                           _ptr(dw_out), _ptr(db_out), _ptr(ws), wsb, _stream()), "rsp_linear_bwd")
+        return dx
+
+    def l2norm_fwd(self, x):
+        y = torch.empty_like(x)
+        _lib.check(self.lib.rsp_l2norm_fwd(_ptr(_chk(x, "x")), x.shape[0], x.shape[1], _ptr(y), _stream()), "rsp_l2norm_fwd")
+        return y
+
+    def l2norm_bwd(self, x, dy):
+        dx = torch.empty_like(x)
+        _lib.check(self.lib.rsp_l2norm_bwd(_ptr(x), _ptr(_chk(dy, "dy")), x.shape[0], x.shape[1], _ptr(dx), _stream()),
+                   "rsp_l2norm_bwd")
+        return dx
+
     def logits_fwd(self, qA, qM, kA, kM, knegA, knegM, queue, inv_T: float):
         B, dim = qA.shape
         K = queue.shape[1]

@@ -157,6 +157,33 @@ class CpuOps:
         db2.copy_(gb2)
         return (gp / P).view(feat_shape[0], 1, 1, 1, -1).expand(feat_shape).contiguous()
 
+    def spatial_mean_fwd(self, x):
+        return x.mean(dim=(1, 2, 3))
+
+    def spatial_mean_bwd(self, dmean, shape):
+        P = shape[1] * shape[2] * shape[3]
+        return (dmean / P).view(shape[0], 1, 1, 1, -1).expand(shape).contiguous()
+
+    def linear_fwd(self, x, w, b, relu):
+        y = F.linear(x, w, b)
+        return F.relu(y) if relu else y
+
+    def linear_bwd(self, x, y, dy, w, relu, dw_out, db_out, want_dx=True):
+        dz = dy * (y > 0) if relu else dy
+        dw_out.copy_(dz.t() @ x)
+        if db_out is not None:
+            db_out.copy_(dz.sum(0))
+        return dz @ w if want_dx else None
+
+    def l2norm_fwd(self, x):
+        return F.normalize(x, dim=1)
+
+    @torch.enable_grad()
+    def l2norm_bwd(self, x, dy):
+        xx = x.detach().requires_grad_(True)
+        (g,) = torch.autograd.grad(F.normalize(xx, dim=1), xx, dy)
+        return g
+
     def logits_fwd(self, qA, qM, kA, kM, knegA, knegM, queue, inv_T):
         lneg = (qA @ queue) * inv_T
         l1 = torch.cat([(qA * kA).sum(1, keepdim=True) * inv_T, lneg], 1)

@@ -44,7 +44,8 @@ def fwd_tol(arch, default):
 
 
 def load_spec(arch):
-    with open(os.path.join(GOLDEN, f"state_spec_{arch.replace('-', '_')}.json")) as f:
+    from oracle.gen_golden import tag_file
+    with open(os.path.join(GOLDEN, f"state_spec_{tag_file(arch)}.json")) as f:
         raw = json.load(f)
     return {k: (tuple(s), d) for k, (s, d) in raw.items()}
 
@@ -82,9 +83,10 @@ def run_restatement(arch, meta, inputs):
     ws = meta["ws"]
     states = [{k: torch.from_numpy(v.copy()) for k, v in state.items()} for _ in range(ws)]
     moms = [{k: torch.from_numpy(v.copy()) for k, v in mom.items()} for _ in range(ws)]
-    outs = S.moco_step(arch, states, [torch.from_numpy(c[0]) for c in clips], [torch.from_numpy(c[1]) for c in clips],
+    outs = S.moco_step(meta["arch"], states, [torch.from_numpy(c[0]) for c in clips], [torch.from_numpy(c[1]) for c in clips],
                        [torch.from_numpy(p) for p in perms_B], (torch.from_numpy(sh[0]), torch.from_numpy(sh[1])),
-                       meta["speed"], K=meta["K"], m=meta["m"], T=meta["T"], margin=meta["margin"], A=meta["A"],
+                       meta["speed"], K=meta["K"], m=meta["m"], T=meta["T"], fc_type=meta.get("fc_type", "linear"),
+                       margin=meta["margin"], A=meta["A"],
                        Mw=meta["M"], lr=meta["lr"], sgd_momentum=meta["sgd_momentum"],
                        weight_decay=meta["weight_decay"], momentum_buffers=moms)
     return outs, states, moms

@@ -43,7 +43,8 @@ def run_model_step(arch, meta, inputs, rank, device, optimizer="fused"):
     """One teacher-forced step of rspnet_amd on `device`.  Returns (out dict, post state dict, momentum_post dict)."""
     from rspnet_amd.optim import SGD
     state, mom, clips, perms_B, sh = inputs
-    wrapped = ModelFactory(make_cfg(arch, meta["K"], m=meta["m"], T=meta["T"])).build_moco_diffloss(device=device)
+    wrapped = ModelFactory(make_cfg(meta.get("arch", arch), meta["K"], fc_type=meta.get("fc_type", "linear"), m=meta["m"],
+                                    T=meta["T"])).build_moco_diffloss(device=device)
     model = wrapped.module
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
     model.train()

@@ -341,3 +341,28 @@ def test_bn_act_pool_channel_slices(hip):
                                 False, dg, db)
     close(dy, dy_ref, 2e-5, "sliced bwd dy")
     close(dg, dg_ref, 2e-5, "sliced dgamma")
+
+
+def test_mlp_head_pieces(hip):
+    B, C, dim = 5, 512, 128
+    feat = rnd(B, 2, 3, 3, C, seed=1)
+    close(hip.spatial_mean_fwd(feat.to(DEV)), CPU.spatial_mean_fwd(feat), 1e-6, "spatial mean")
+    dm = rnd(B, C, seed=2)
+    close(hip.spatial_mean_bwd(dm.to(DEV), tuple(feat.shape)), CPU.spatial_mean_bwd(dm, tuple(feat.shape)), 1e-6, "mean bwd")
+    x, w, b = rnd(B, C, seed=3), rnd(dim, C, seed=4, scale=C ** -0.5), rnd(dim, seed=5)
+    for relu in (True, False):
+        y_ref = CPU.linear_fwd(x, w, b, relu)
+        y = hip.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), relu)
+        close(y, y_ref, 1e-5, "linear fwd")
+        dy = rnd(B, dim, seed=6)
+        dw_ref, db_ref = torch.empty_like(w), torch.empty_like(b)
+        dx_ref = CPU.linear_bwd(x, y_ref, dy, w, relu, dw_ref, db_ref)
+        dw, db = torch.empty_like(w, device=DEV), torch.empty_like(b, device=DEV)
+        dx = hip.linear_bwd(x.to(DEV), y, dy.to(DEV), w.to(DEV), relu, dw, db)
+        close(dx, dx_ref, 2e-5, "linear dx")
+        close(dw, dw_ref, 2e-5, "linear dw")
+        close(db, db_ref, 2e-5, "linear db")
+    r = rnd(B, dim, seed=7)
+    close(hip.l2norm_fwd(r.to(DEV)), CPU.l2norm_fwd(r), 1e-6, "l2norm")
+    g = rnd(B, dim, seed=8)
+    close(hip.l2norm_bwd(r.to(DEV), g.to(DEV)), CPU.l2norm_bwd(r, g), 2e-5, "l2norm bwd")
