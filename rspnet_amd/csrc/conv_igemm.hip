@@ -46,6 +46,7 @@ struct IgemmParams {
   int splitk, chunks_per_split;
   int m_tiles, n_tiles;
   const float* __restrict__ zero;  // >= 64 B of zeros (g_zero)
+  unsigned x_bytes, w_bytes;       // extents for the buffer descriptors of the DMA path (< 4 GiB)
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
@@ -148,8 +149,22 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   // element offset of the zero page relative to p.x, so an invalid lane only swaps an offset (pure v_cndmask, no branch)
   const long long zoff = (reinterpret_cast<const char*>(p.zero) - reinterpret_cast<const char*>(p.x)) / 4;
 
-  typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // DMA path addressing: raw buffer descriptors (wave-uniform SGPRs) + 32-bit byte offsets.  An out-of-range offset makes
+  // the hardware return zeros, so padding taps / tail rows / K tail cost one v_cndmask and no zero page or 64-bit math.
+  __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  unsigned abase32[AR], wrowoff[BR], rowoff[AR];
+  bool rowok[AR];
+  int last_tap = -1;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    abase32[i] = (unsigned)(abase[i] * 4);
+    rowoff[i] = 0;
+    rowok[i] = false;
+  }
+#pragma unroll
+  for (int i = 0; i < BR; ++i) wrowoff[i] = (unsigned)(n0 + arow + 32 * i) * (unsigned)p.Kld * 4u;
 
   auto load_chunk = [&](int kc, int buf) {
     const int k = kc * BK + kcol;
@@ -169,32 +184,39 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
       }
       ntt[e] = taptab[min(ntap[e], ntaps - 1)];
     }
-    // weights
+    if (DMA) {
+      const unsigned k4 = (unsigned)k * 4u;
+      const bool kin = k < p.Kld;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const float* src = (wok[i] && k < p.Kld) ? wrow[i] + k : zero;
-      if (DMA) {
-        // wave-uniform LDS base; the hardware adds lane * 16 B
-        float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-      } else {
-        breg[i] = *reinterpret_cast<const floatx4*>(src);
+      for (int i = 0; i < BR; ++i) {
+        const unsigned off = (wok[i] && kin) ? wrowoff[i] + k4 : 0xffffffffu;
+        float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;   // wave-uniform base; hardware adds lane*16 B
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, off, 0, 0, 0);
       }
-    }
-    // activations: out-of-bounds taps / rows / K tail read the zero page instead of branching around the load
-    if (VEC == 4) {
-      const int4 tt = ctt[0];
-      const bool kok = ctap[0] < ntaps;
+      if (ctap[0] != last_tap) {   // row validity / offsets change only when this lane's tap does (every Cin/32 chunks)
+        last_tap = ctap[0];
+        const int4 tt = ctt[0];
+        const bool kok = ctap[0] < ntaps;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
+          rowok[i] = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+          rowoff[i] = abase32[i] + (unsigned)tt.w * 4u;
+        }
+      }
+      const unsigned ci4 = (unsigned)cci[0] * 4u;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
-        const bool ok = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-        const long long real = abase[i] + tt.w + cci[0];
-        const long long m = ok ? -1ll : 0ll;
+        const unsigned off = rowok[i] ? rowoff[i] + ci4 : 0xffffffffu;
         float* dst = As + buf * BM * LDR + i * 32 * LDR + wave * 64 * 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.x + ((real & m) | (zoff & ~m))), (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
       }
     } else {
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const float* src = (wok[i] && k < p.Kld) ? wrow[i] + k : zero;
+        breg[i] = *reinterpret_cast<const floatx4*>(src);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int4 tt = ctt[e];
@@ -228,6 +250,14 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#ifdef RSP_TUNE
+  // experiment: start the second workgroup of each CU half a chunk late so that the two co-resident waves of a SIMD
+  // alternate (one in its MFMA burst while the other fetches) instead of running their phases in lockstep
+  if ((p.tune & 16) && ((blockIdx.x >> 8) & 1)) {
+    const int reps = (p.tune >> 8) & 0xff;
+    for (int i = 0; i < (reps ? reps : 4); ++i) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   if (kc_begin < kc_end) {
     load_chunk(kc_begin, 0);
     store_chunk(0);
@@ -259,6 +289,10 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
     if (more) load_chunk(kc + 1, buf ^ 1);
 #endif
     // 3. 16 k-steps x TM x TN MFMAs
+#ifdef RSP_TUNE
+    if (p.tune & 32) __builtin_amdgcn_s_setprio(1);
+    if (p.tune & 64) __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -269,6 +303,7 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i][e], bf[kk][j][e], acc[i][j], 0, 0, 0);
 #ifdef RSP_TUNE
+    if (p.tune & 96) __builtin_amdgcn_s_setprio(0);
     if (more && !(p.tune & 2)) store_chunk(buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     if (!(p.tune & 4)) __syncthreads();
@@ -666,7 +701,12 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   p.offstep = 1;
   p.K = d->kT * d->kH * d->kW * d->Cin;
   p.Kld = (int)rsp_align_up((size_t)p.K, 4);
-  const bool vec4 = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x);
+  const unsigned long long xb = (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
+  const unsigned long long wb = (unsigned long long)d->Cout * p.Kld * 4ull;
+  p.x_bytes = (unsigned)xb;
+  p.w_bytes = (unsigned)wb;
+  // the LDS-DMA path addresses with 32-bit byte offsets; bigger tensors take the (slower) scalar-gather path
+  const bool vec4 = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x) && xb < (1ull << 32) && wb < (1ull << 32);
   return run_igemm(p, vec4, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -758,7 +798,11 @@ int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_r
     p.offstep = -1;
     p.K = g.nt * g.nh * g.nw * d->Cout;
     p.Kld = pk.Kld;
-    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy);
+    const unsigned long long xb = (unsigned long long)d->N * d->Do * d->Ho * d->Wo * d->out_ld * 4ull;
+    const unsigned long long wb = (unsigned long long)pk.O * pk.Kld * 4ull;
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && xb < (1ull << 32) && wb < (1ull << 32);
     int rc = run_igemm(p, vec4, part, part_bytes, s);
     if (rc != RSP_OK) return rc;
     woff += (size_t)pk.O * pk.Kld;
