@@ -30,6 +30,8 @@ struct WgradParams {
   int rows_per_split, splitm;
   int co_tiles, k_tiles;
   const float* __restrict__ zero;  // >= 64 B of zeros
+  unsigned x_bytes, dy_bytes;      // extents for the buffer descriptors of the DMA variant
+  int tune;
 };
 
 struct RowPos {
@@ -203,7 +205,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   int buf = 0;
   for (int rb = row_begin; rb < row_end; rb += RK) {
     const bool more = rb + RK < row_end;
+#ifdef RSP_TUNE
+    if (more && !(p.tune & 1)) load_chunk(rb + RK);
+#else
     if (more) load_chunk(rb + RK);
+#endif
     const float* a = At + buf * RK * BM + wm * WM + l32;
     const float* b = Bt + buf * RK * BN + wn * WN + l32;
 #pragma unroll
@@ -219,7 +225,217 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+#ifdef RSP_TUNE
+    if (more && !(p.tune & 2)) store_chunk(buf ^ 1);
+#else
     if (more) store_chunk(buf ^ 1);
+#endif
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  float* dst = p.partial + (long long)z * p.Cout * p.Kld;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int k = k0 + wn * WN + j * 32 + l32;
+    if (k < p.Kld) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = co0 + wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
+          if (co < p.Cout) dst[(long long)co * p.Kld + k] = acc[i][j][e];
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (Cin % 4 == 0, Cout % 4 == 0, tensors < 4 GiB): both tiles are filled by buffer_load ... lds with
+// 32-bit offsets (out-of-range => hardware zero fill).  Row geometry (input byte offset + a validity bit per tap of this
+// k-tile) is produced once per chunk by 32 lanes into a 3-deep LDS ring, so the other 224 threads spend ~4 VALU per
+// 16-byte copy instead of ~40: on this fp32 MFMA loop every VALU issue slot comes straight out of the matrix pipe's.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int ACOLS = BM / 4, BCOLS = BN / 4;
+  constexpr int ARP = 256 / ACOLS, BRP = 256 / BCOLS;
+  constexpr int AR = RK / ARP, BR = RK / BRP;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* At = reinterpret_cast<float*>(smem_raw);          // [2][RK][BM]
+  float* Bt = At + 2 * RK * BM;                            // [2][RK][BN]
+  uint2* rowtab = reinterpret_cast<uint2*>(Bt + 2 * RK * BN);   // [3][RK] {input byte offset, tap validity bits}
+  int4* taptile = reinterpret_cast<int4*>(rowtab + 3 * RK);     // [<=33] {offd, offh, offw, -}
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tile = rsp_xcd_remap(blockIdx.x, gridDim.x);
+  const int co_tile = tile / p.k_tiles, k_tile = tile - co_tile * p.k_tiles;
+  const int co0 = co_tile * BM, k0 = k_tile * BN;
+  const int z = blockIdx.y;
+  const int row_begin = z * p.rows_per_split;
+  const int row_end = min(p.M, row_begin + p.rows_per_split);
+
+  __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+  // taps covered by this k-tile
+  const int ntaps = p.kT * p.kH * p.kW;
+  const int tap_lo = k0 / p.Cin;
+  const int tap_hi = min(ntaps - 1, (k0 + BN - 1) / p.Cin);
+  const int ntl = tap_hi - tap_lo + 1;   // <= 32 (host-checked)
+  if (t < ntl) {
+    const int tap = tap_lo + t;
+    const int kw = tap % p.kW, q = tap / p.kW;
+    const int kh = q % p.kH, kt = q / p.kH;
+    taptile[t] = make_int4(kt - p.pT, kh - p.pH, kw - p.pW, 0);
+  }
+
+  // A side (dy)
+  const int acol = (t % ACOLS) * 4, arow = t / ACOLS;
+  const bool acol_ok = co0 + acol < p.Cout;
+  unsigned aoff[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i)
+    aoff[i] = ((unsigned)(row_begin + arow + i * ARP) * (unsigned)p.dy_ld + (unsigned)(co0 + acol)) * 4u;
+  const unsigned astep = (unsigned)RK * (unsigned)p.dy_ld * 4u;
+  // B side (im2col x): this thread's k -> tap bit and byte delta
+  const int bcol = (t % BCOLS) * 4, brow = t / BCOLS;
+  const int kk = k0 + bcol;
+  const bool bok = kk < p.K;
+  int mybit = 0;
+  unsigned bdelta4 = 0;
+  {
+    const int k1 = bok ? kk : k0;
+    const int tap = k1 / p.Cin, ci = k1 - tap * p.Cin;
+    const int kw = tap % p.kW, q = tap / p.kW;
+    const int kh = q % p.kH, kt = q / p.kH;
+    mybit = tap - tap_lo;
+    bdelta4 = (unsigned)(((((kt - p.pT) * p.Hi + (kh - p.pH)) * p.Wi + (kw - p.pW)) * p.in_ld + ci) * 4);
+  }
+
+  // producer state: lane t < RK owns row (chunk base + t)
+  RowPos pos;
+  {
+    const int r = row_begin + (t & (RK - 1));
+    pos.gw = r % p.Gw;
+    int q = r / p.Gw;
+    pos.gh = q % p.Gh;
+    q /= p.Gh;
+    pos.gd = q % p.Gd;
+    pos.n = q / p.Gd;
+  }
+  const int st_w = RK % p.Gw, st_h = (RK / p.Gw) % p.Gh, st_d = (RK / (p.Gw * p.Gh)) % p.Gd,
+            st_n = RK / (p.Gw * p.Gh * p.Gd);
+  __syncthreads();   // taptile visible
+
+  auto produce = [&](int chunk, int slot) {   // lanes t < RK: geometry of row (row_begin + chunk*RK + t)
+    if (t < RK) {
+      const int r = row_begin + chunk * RK + t;
+      uint2 e = make_uint2(0u, 0u);
+      if (r < row_end) {
+        const int id0 = pos.gd * p.sD, ih0 = pos.gh * p.sH, iw0 = pos.gw * p.sW;
+        e.x = (unsigned)(((((long long)pos.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0) * p.in_ld * 4);
+        unsigned m = 0;
+        for (int j = 0; j < ntl; ++j) {
+          const int4 tt = taptile[j];
+          const int id = id0 + tt.x, ih = ih0 + tt.y, iw = iw0 + tt.z;
+          if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) m |= 1u << j;
+        }
+        e.y = m;
+      }
+      rowtab[slot * RK + t] = e;
+      // advance to the row RK further on (branch-free mixed-radix add)
+      pos.gw += st_w;
+      int c = pos.gw >= p.Gw;
+      pos.gw -= c ? p.Gw : 0;
+      pos.gh += st_h + c;
+      c = pos.gh >= p.Gh;
+      pos.gh -= c ? p.Gh : 0;
+      pos.gd += st_d + c;
+      c = pos.gd >= p.Gd;
+      pos.gd -= c ? p.Gd : 0;
+      pos.n += st_n + c;
+    }
+  };
+
+  uint2 rt[BR];
+  auto read_rowtab = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < BR; ++i) rt[i] = rowtab[slot * RK + brow + i * BRP];
+  };
+  auto issue = [&](int chunk, int buf) {   // uses rt[] read earlier (no LDS access after the first DMA of a chunk)
+    const int rbase = row_begin + chunk * RK;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const bool ok = acol_ok && rbase + arow + i * ARP < row_end;
+      const unsigned off = ok ? aoff[i] : 0xffffffffu;
+      aoff[i] += astep;
+      float* dst = At + buf * RK * BM + i * ARP * BM + wave * 256;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (lptr_t)dst, 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const bool ok = bok && ((rt[i].y >> mybit) & 1u);
+      const unsigned off = ok ? rt[i].x + bdelta4 : 0xffffffffu;
+      float* dst = Bt + buf * RK * BN + i * BRP * BN + wave * 256;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nchunk = (row_end - row_begin + RK - 1) / RK;
+  produce(0, 0);
+  produce(1, 1);
+  __syncthreads();
+  if (nchunk > 0) {
+    read_rowtab(0);
+    issue(0, 0);
+  }
+  __syncthreads();   // vmcnt(0) + barrier: chunk 0 landed
+
+  int buf = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    // 1. every LDS access of this iteration first (hipcc orders LDS accesses behind pending LDS-DMA)
+    const float* a = At + buf * RK * BM + wm * WM + l32;
+    const float* b = Bt + buf * RK * BN + wn * WN + l32;
+    float af[RK / 2][TM], bf[RK / 2][TN];
+#pragma unroll
+    for (int s2 = 0; s2 < RK / 2; ++s2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[s2][i] = a[(2 * s2 + h) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[s2][j] = b[(2 * s2 + h) * BN + j * 32];
+    }
+    if (more) read_rowtab((c + 1) % 3);
+    produce(c + 2, (c + 2) % 3);
+    // 2. next chunk's copies in flight under this chunk's MFMAs
+    if (more) issue(c + 1, buf ^ 1);
+    // 3. MFMAs
+#pragma unroll
+    for (int s2 = 0; s2 < RK / 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     buf ^= 1;
   }
@@ -294,6 +510,20 @@ int launch_w(const WgradParams& p, hipStream_t s) {
   dim3 grid(p.co_tiles * p.k_tiles, p.splitm);
   hipLaunchKernelGGL((wgrad_kernel<BM, BN, WAVES_M, WAVES_N, VECA, VECB>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("wgrad_kernel");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_w_dma(const WgradParams& p, hipStream_t s) {
+  const size_t lds = (size_t)2 * RK * (BM + BN) * sizeof(float) + 3 * RK * sizeof(uint2) + 34 * sizeof(int4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.co_tiles * p.k_tiles, p.splitm);
+  hipLaunchKernelGGL((wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds, s, p);
+  return rsp_check_launch("wgrad_dma_kernel");
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -379,6 +609,9 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   WgradParams p;
   memset(&p, 0, sizeof p);
   p.zero = zero_page;
+#ifdef RSP_TUNE
+  { const char* e = getenv("RSP_TUNE"); p.tune = e ? atoi(e) : 0; }
+#endif
   p.x = x; p.dy = dy; p.partial = reinterpret_cast<float*>(workspace);
   p.M = d->N * d->Do * d->Ho * d->Wo;
   p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
@@ -392,8 +625,20 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   p.co_tiles = w.co_tiles; p.k_tiles = w.k_tiles;
   const bool va = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy);
   const bool vb = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x);
+  const unsigned long long xb = (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
+  const unsigned long long dyb = (unsigned long long)p.M * d->out_ld * 4ull;
+  p.x_bytes = (unsigned)xb;
+  p.dy_bytes = (unsigned)dyb;
+  bool dma = va && vb && xb < (1ull << 32) && dyb < (1ull << 32) && (w.bn + d->Cin - 1) / d->Cin + 1 <= 32;
+#ifdef RSP_TUNE
+  if (p.tune & 128) dma = false;
+#endif
   int rc;
-  if (w.bm == 128 && w.bn == 128) rc = launch_w_vec<128, 128, 2, 2>(p, va, vb, s);
+  if (dma && w.bm == 128 && w.bn == 128) rc = launch_w_dma<128, 128, 2, 2>(p, s);
+  else if (dma && w.bm == 128) rc = launch_w_dma<128, 64, 2, 2>(p, s);
+  else if (dma && w.bn == 128) rc = launch_w_dma<64, 128, 2, 2>(p, s);
+  else if (dma) rc = launch_w_dma<64, 64, 2, 2>(p, s);
+  else if (w.bm == 128 && w.bn == 128) rc = launch_w_vec<128, 128, 2, 2>(p, va, vb, s);
   else if (w.bm == 128) rc = launch_w_vec<128, 64, 2, 2>(p, va, vb, s);
   else if (w.bn == 128) rc = launch_w_vec<64, 128, 2, 2>(p, va, vb, s);
   else rc = launch_w_vec<64, 64, 2, 2>(p, va, vb, s);
