@@ -126,7 +126,7 @@ def main():
     if ws > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         flops = sum(e[1] for e in log)
@@ -137,7 +137,16 @@ def main():
             a[0] += f
             a[1] += e0.elapsed_time(e1)
             a[2] += 1
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        all_tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # dominant kernel = igemm_kernel (conv forward + input-gradient launches share it); wgrad_kernel reported beside it
+        dom = [per_kind.get("conv_fwd", [0, 0, 0]), per_kind.get("conv_dgrad", [0, 0, 0])]
+        dflops, dms, dn = (sum(x[i] for x in dom) for i in range(3))
+        achieved = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.arch == "c3d" and B == 32:
+            with open(tpath) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch"] / 1e9, 3)
         clips = ws * B * args.steps / dt
         res = {
             "metric": f"clips/sec pretext step ({args.arch} 16x{hw}x{hw}, B={B}/GPU)",
@@ -149,9 +158,13 @@ def main():
                        "global_batch": B * ws, "parallelism": f"dp{ws}"},
             "final_loss": round(final_loss, 5),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "igemm_kernel / wgrad_kernel (conv fwd+dgrad+wgrad launches, fp32 MFMA)",
-                         "launches": len(log), "conv_ms_per_step": round(ms / args.steps, 3),
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "GB HBM per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
+                         "kernel": "igemm_kernel (implicit-GEMM conv3d forward + dgrad, v_mfma_f32_32x32x2_f32)",
+                         "launches": dn, "avg_launch_ms": round(dms / max(dn, 1), 4),
+                         "algorithmic_gflop_per_launch": round(dflops / max(dn, 1) / 1e9, 2),
+                         "all_conv_launches": {"achieved": round(all_tf, 2), "frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                               "ms_per_step": round(ms / args.steps, 3), "launches": len(log)},
                          "per_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in per_kind.items()},
                          "per_kind_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in per_kind.items()}},
         }
