@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   float* As = reinterpret_cast<float*>(smem_raw);             // [2][BM][LDR]
   float* Bs = As + 2 * BM * LDR;                              // [2][BN][LDR]
   int4* taptab = reinterpret_cast<int4*>(Bs + 2 * BN * LDR);  // [ntaps] {offd, offh, offw, delta}
-  long long* rowaddr = reinterpret_cast<long long*>(taptab + MAX_TAPS + 1);  // [BM]
+  long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nTd * p.nTh * p.nTw + 1);  // [BM]
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -352,7 +352,11 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
         for (int e = 0; e < 16; ++e) {
           const int rl = wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
           const long long addr = rowaddr[rl];
+#ifdef RSP_TUNE
+          if (addr >= 0 && !((p.tune & 256) && acc[i][j][e] != 12345.f)) dst[addr + col] = acc[i][j][e] + bv;
+#else
           if (addr >= 0) dst[addr + col] = acc[i][j][e] + bv;
+#endif
         }
     }
   }
@@ -488,12 +492,16 @@ __global__ void pack_weight_kernel(const PackParams p) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
 int launch_cfg(const IgemmParams& p, hipStream_t s) {
-  const size_t lds = (size_t)2 * (BM + BN) * (VEC == 4 ? BK : LDK) * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) +
-                     BM * sizeof(long long);
+  // LDS: two tile buffers + tap table (sized by the actual tap count: short-K layers are latency-bound and want a
+  // third workgroup per CU) + output-row address table
+  const size_t lds = (size_t)2 * (BM + BN) * (VEC == 4 ? BK : LDK) * sizeof(float) +
+                     (size_t)(p.nTd * p.nTh * p.nTw + 1) * sizeof(int4) + BM * sizeof(long long);
   static bool attr_set = false;
   if (!attr_set) {
+    const size_t lds_max = (size_t)2 * (BM + BN) * (VEC == 4 ? BK : LDK) * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) +
+                           BM * sizeof(long long);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     attr_set = true;
   }
   dim3 grid(p.m_tiles * p.n_tiles, p.splitk);

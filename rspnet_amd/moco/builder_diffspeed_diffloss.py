@@ -168,17 +168,32 @@ class MoCoDiffLossTwoFc(nn.Module):
         self.encoder_k.weights_changed()
 
     def _cpu_pg(self):
+        """Host-side side channel for the 2 KB permutation (single node: loopback).  Returns None when a gloo group
+        cannot be created next to the RCCL one; the permutation then travels through the device (one small sync)."""
         if self._cpu_group is None:
-            backend = dist.get_backend()
-            self._cpu_group = dist.new_group(backend="gloo") if backend != "gloo" else dist.group.WORLD
-        return self._cpu_group
+            if dist.get_backend() == "gloo":
+                self._cpu_group = dist.group.WORLD
+            else:
+                import os
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                try:
+                    self._cpu_group = dist.new_group(backend="gloo")
+                except Exception:      # noqa: BLE001 - any rendezvous / interface problem: fall back, stay correct
+                    self._cpu_group = False
+        return self._cpu_group or None
 
     def _draw_shuffle(self, n: int) -> np.ndarray:
         """idx_shuffle: drawn on the CPU by every rank, rank 0's wins (:372-378) — exchanged host-side."""
         idx = torch.randperm(n)
         rank, ws = _world()
         if ws > 1:
-            dist.broadcast(idx, src=0, group=self._cpu_pg())
+            group = self._cpu_pg()
+            if group is not None:
+                dist.broadcast(idx, src=0, group=group)
+            else:
+                dev_idx = idx.to(self.queue.device)
+                dist.broadcast(dev_idx, src=0)
+                idx = dev_idx.cpu()
         return idx.numpy().astype(np.int64)
 
     @torch.no_grad()
