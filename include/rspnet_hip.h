@@ -120,9 +120,11 @@ int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t
 
 /* S3D-G self-gating (models/s3dg.py:63-72): out = x * sigmoid(W·mean_p(x) + b); x:[N][P][C] (pitch in_ld), W (C,C)
  * = excitation.weight viewed (C,C,1,1,1), b (C).  Saves mean [N][C] and gate [N][C] for backward. */
+size_t rsp_gate_fwd_workspace(int32_t N, int32_t P, int32_t C);
 int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* w, const float* b,
-                 float* out, int32_t out_ld, float* mean, float* gate, void* stream);
-size_t rsp_gate_bwd_workspace(int32_t N, int32_t C);
+                 float* out, int32_t out_ld, float* mean, float* gate, void* workspace, size_t workspace_bytes,
+                 void* stream);
+size_t rsp_gate_bwd_workspace(int32_t N, int32_t P, int32_t C);
 int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_t C, int32_t x_ld, int32_t dout_ld,
                  const float* w, const float* mean, const float* gate, float* dx, int32_t dx_ld, float* dw, float* db,
                  void* workspace, size_t workspace_bytes, void* stream);

@@ -75,20 +75,47 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const MPParams p) {
 }
 
 // ---- S3D-G gating ---------------------------------------------------------------------------------------------------
-// mean over positions per (sample, channel): block = (sample, 64-channel group), 4 position lanes
-__global__ __launch_bounds__(256) void spatial_mean_kernel(const float* __restrict__ x, int P, int C, int ld,
-                                                           float* __restrict__ mean) {
+// sum over a slice of positions per (sample, channel): block = (sample*S + slice, 64-channel group), 4 position lanes.
+// Two deterministic stages so that a (16, 8x112x112, 64) tensor is reduced by thousands of workgroups, not sixteen.
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const float* __restrict__ x, const float* __restrict__ x2, int P,
+                                                          int C, int ld, int ld2, int S, float* __restrict__ part) {
   __shared__ float red[4][64];
-  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int n = blockIdx.x / S, sl = blockIdx.x % S;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int per = (P + S - 1) / S;
+  const int p0 = sl * per, p1 = min(P, p0 + per);
   float s = 0.f;
-  if (c < C)
-    for (int pp = pl; pp < P; pp += 4) s += x[((long long)n * P + pp) * ld + c];
+  if (c < C) {
+    if (x2) {
+      for (int pp = p0 + pl; pp < p1; pp += 4) {
+        const long long row = (long long)n * P + pp;
+        s = fmaf(x[row * ld + c], x2[row * ld2 + c], s);
+      }
+    } else {
+      for (int pp = p0 + pl; pp < p1; pp += 4) s += x[((long long)n * P + pp) * ld + c];
+    }
+  }
   red[pl][threadIdx.x & 63] = s;
   __syncthreads();
   if (pl == 0 && c < C) {
     const int l = threadIdx.x;
-    mean[(long long)n * C + c] = (red[0][l] + red[1][l] + red[2][l] + red[3][l]) / (float)P;
+    part[((long long)n * S + sl) * C + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
   }
+}
+// out[n][c] = scale * sum_s part[n][s][c]  (* g*(1-g) when gate != null: the sigmoid derivative of the gating backward)
+__global__ void spatial_sum_final_kernel(const float* __restrict__ part, int N, int C, int S, float scale,
+                                         const float* __restrict__ gate, float* __restrict__ out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)N * C) return;
+  const int n = (int)(i / C), c = (int)(i % C);
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += part[((long long)n * S + k) * C + c];
+  s *= scale;
+  if (gate) {
+    const float g = gate[i];
+    s *= g * (1.f - g);
+  }
+  out[i] = s;
 }
 
 // gate[n][co] = sigmoid(b[co] + sum_ci w[co][ci] * mean[n][ci]) ; one wave per output
@@ -117,28 +144,7 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
   }
 }
 
-// backward: dx = dout*gate + (dmean/P) ; dmean[n][ci] = sum_co dpre[n][co] w[co][ci];
-//           dpre[n][c] = (sum_p dout*x) * gate*(1-gate)
-__global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                              const float* __restrict__ gate, int P, int C, int x_ld,
-                                                              int dout_ld, float* __restrict__ dpre) {
-  __shared__ float red[4][64];
-  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < C)
-    for (int pp = pl; pp < P; pp += 4) {
-      const long long row = (long long)n * P + pp;
-      s = fmaf(dout[row * dout_ld + c], x[row * x_ld + c], s);
-    }
-  red[pl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (pl == 0 && c < C) {
-    const int l = threadIdx.x;
-    const float g = gate[(long long)n * C + c];
-    dpre[(long long)n * C + c] = (red[0][l] + red[1][l] + red[2][l] + red[3][l]) * g * (1.f - g);
-  }
-}
-
+// backward: dx = dout*gate + (dmean/P); dpre[n][c] = (sum_p dout*x) * gate*(1-gate)  (spatial_sum kernels above)
 // dw[co][ci] = sum_n dpre[n][co]*mean[n][ci]; db[co] = sum_n dpre[n][co]; dmean[n][ci] = sum_co dpre[n][co] w[co][ci]
 __global__ void gate_bwd_param_kernel(const float* __restrict__ dpre, const float* __restrict__ mean, int N, int C,
                                       float* __restrict__ dw, float* __restrict__ db) {
@@ -186,6 +192,10 @@ bool mp_ok(const rsp_pool3d_desc* d) {
   if ((long long)d->Di * d->Hi * d->Wi >= (1ll << 31)) return false;
   return true;
 }
+int gate_splits(int P) {
+  const int s = (P + 255) / 256;
+  return s > 64 ? 64 : (s < 1 ? 1 : s);
+}
 int grid_for(long long total) {
   long long b = (total + 255) / 256;
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -217,13 +227,26 @@ int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t
   return rsp_check_launch("maxpool_bwd_kernel");
 }
 
+size_t rsp_gate_fwd_workspace(int32_t N, int32_t P, int32_t C) { return (size_t)N * gate_splits(P) * C * sizeof(float); }
+
 int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* w, const float* b,
-                 float* out, int32_t out_ld, float* mean, float* gate, void* stream) {
-  RSP_REQUIRE(x && w && b && out && mean && gate, "rsp_gate_fwd: null pointer");
+                 float* out, int32_t out_ld, float* mean, float* gate, void* workspace, size_t workspace_bytes,
+                 void* stream) {
+  RSP_REQUIRE(x && w && b && out && mean && gate && workspace, "rsp_gate_fwd: null pointer");
   RSP_REQUIRE(N > 0 && P > 0 && C > 0 && in_ld >= C && out_ld >= C, "rsp_gate_fwd: bad size");
+  if (workspace_bytes < rsp_gate_fwd_workspace(N, P, C)) {
+    rsp_set_error("rsp_gate_fwd: workspace too small");
+    return RSP_EWORKSPACE;
+  }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(spatial_mean_kernel, dim3(N, rsp_cdiv(C, 64)), dim3(256), 0, s, x, P, C, in_ld, mean);
-  int rc = rsp_check_launch("spatial_mean_kernel");
+  const int S = gate_splits(P);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(spatial_sum_kernel, dim3(N * S, rsp_cdiv(C, 64)), dim3(256), 0, s, x, (const float*)nullptr, P, C, in_ld, 0, S, part);
+  int rc = rsp_check_launch("spatial_sum_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(spatial_sum_final_kernel, dim3(rsp_cdiv((long long)N * C, 256)), dim3(256), 0, s, part, N, C, S, 1.f / (float)P,
+                     (const float*)nullptr, mean);
+  rc = rsp_check_launch("spatial_sum_final_kernel");
   if (rc != RSP_OK) return rc;
   hipLaunchKernelGGL(gate_fc_kernel, dim3(rsp_cdiv((long long)N * C, 4)), dim3(256), 0, s, mean, w, b, N, C, gate);
   rc = rsp_check_launch("gate_fc_kernel");
@@ -233,22 +256,29 @@ int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld,
   return rsp_check_launch("gate_apply_kernel");
 }
 
-size_t rsp_gate_bwd_workspace(int32_t N, int32_t C) { return (size_t)2 * N * C * sizeof(float); }
+size_t rsp_gate_bwd_workspace(int32_t N, int32_t P, int32_t C) {
+  return (size_t)(2 + gate_splits(P)) * N * C * sizeof(float);
+}
 
 int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_t C, int32_t x_ld, int32_t dout_ld,
                  const float* w, const float* mean, const float* gate, float* dx, int32_t dx_ld, float* dw, float* db,
                  void* workspace, size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(x && dout && w && mean && gate && dx && dw && db && workspace, "rsp_gate_bwd: null pointer");
   RSP_REQUIRE(N > 0 && P > 0 && C > 0 && x_ld >= C && dout_ld >= C && dx_ld >= C, "rsp_gate_bwd: bad size");
-  if (workspace_bytes < rsp_gate_bwd_workspace(N, C)) {
+  if (workspace_bytes < rsp_gate_bwd_workspace(N, P, C)) {
     rsp_set_error("rsp_gate_bwd: workspace too small");
     return RSP_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
   float* dpre = reinterpret_cast<float*>(workspace);
   float* dmean = dpre + (size_t)N * C;
-  hipLaunchKernelGGL(gate_bwd_reduce_kernel, dim3(N, rsp_cdiv(C, 64)), dim3(256), 0, s, x, dout, gate, P, C, x_ld, dout_ld, dpre);
-  int rc = rsp_check_launch("gate_bwd_reduce_kernel");
+  const int S = gate_splits(P);
+  float* part = dmean + (size_t)N * C;
+  hipLaunchKernelGGL(spatial_sum_kernel, dim3(N * S, rsp_cdiv(C, 64)), dim3(256), 0, s, dout, x, P, C, dout_ld, x_ld, S, part);
+  int rc = rsp_check_launch("spatial_sum_kernel(bwd)");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(spatial_sum_final_kernel, dim3(rsp_cdiv((long long)N * C, 256)), dim3(256), 0, s, part, N, C, S, 1.f, gate, dpre);
+  rc = rsp_check_launch("spatial_sum_final_kernel(bwd)");
   if (rc != RSP_OK) return rc;
   hipLaunchKernelGGL(gate_bwd_param_kernel, dim3(rsp_cdiv((long long)C * C, 256)), dim3(256), 0, s, dpre, mean, N, C, dw, db);
   rc = rsp_check_launch("gate_bwd_param_kernel");

@@ -257,8 +257,11 @@ class HipOps:
             out = torch.empty_like(x)
         mean = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
         gate = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        wsb = self.lib.rsp_gate_fwd_workspace(N, P, Cc)
+        ws = self._workspace(x.device, wsb)
         _lib.check(self.lib.rsp_gate_fwd(_ptr(x), N, P, Cc, Cc, _ptr(_chk(w, "w")), _ptr(_chk(b, "b")), _ptr(out),
-                                         _rows_ld(out, "out"), _ptr(mean), _ptr(gate), _stream()), "rsp_gate_fwd")
+                                         _rows_ld(out, "out"), _ptr(mean), _ptr(gate), _ptr(ws), wsb, _stream()),
+                   "rsp_gate_fwd")
         return out, mean, gate
 
     def gate_bwd(self, x, dout, w, mean, gate, dw_out, db_out):
@@ -266,7 +269,7 @@ class HipOps:
         N, D, H, W, Cc = x.shape
         P = D * H * W
         dx = torch.empty_like(x)
-        wsb = self.lib.rsp_gate_bwd_workspace(N, Cc)
+        wsb = self.lib.rsp_gate_bwd_workspace(N, P, Cc)
         ws = self._workspace(x.device, wsb)
         _lib.check(self.lib.rsp_gate_bwd(_ptr(x), _ptr(dout), N, P, Cc, Cc, _rows_ld(dout, "dout"), _ptr(w), _ptr(mean),
                                          _ptr(gate), _ptr(dx), Cc, _ptr(dw_out), _ptr(db_out), _ptr(ws), wsb, _stream()),
