@@ -422,6 +422,16 @@ int rsp_head_fwd(const float* feat, int32_t B, int32_t P, int32_t C, int32_t fea
   RSP_REQUIRE(feat && w1 && b1 && w2 && b2 && out1 && out2 && pooled && raw, "rsp_head_fwd: null pointer");
   RSP_REQUIRE(B > 0 && P > 0 && C > 0 && dim > 0 && feat_ld >= C && (5 * C + 2 * dim) * 4 <= 64 * 1024,
               "rsp_head_fwd: bad size");
+  if (P > 8) {
+    // pool with B x C/64 workgroups first (one workgroup per sample would serialise ~P*C/256 dependent loads), then run
+    // the head on the pooled vector (P = 1)
+    hipLaunchKernelGGL(smean_kernel, dim3(B, rsp_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, feat, P, C, feat_ld, pooled);
+    int rc = rsp_check_launch("smean_kernel");
+    if (rc != RSP_OK) return rc;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)(5 * C + 2 * dim) * 4, (hipStream_t)stream, pooled, B, 1, C,
+                       C, w1, b1, w2, b2, dim, out1, out2, pooled, raw);
+    return rsp_check_launch("head_fwd_kernel");
+  }
   hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)(5 * C + 2 * dim) * 4, (hipStream_t)stream, feat, B, P, C,
                      feat_ld, w1, b1, w2, b2, dim, out1, out2, pooled, raw);
   return rsp_check_launch("head_fwd_kernel");
