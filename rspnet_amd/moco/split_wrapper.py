@@ -137,4 +137,7 @@ class MultiTaskWrapper(nn.Module):
         xn = be.clip_gather(x.contiguous(), src, step, x.shape[2], max(x.shape[1], INPUT_CHANNEL_PAD))
         with torch.no_grad():
             x1, x2, _ = self.forward_ndhwc(xn, keep=False)
+            for mod in self.modules():      # train-mode BN bookkeeping (inside the pretext model this is one fused add)
+                if isinstance(mod, nn.modules.batchnorm._BatchNorm):
+                    mod.num_batches_tracked += 1
         return x1, x2

@@ -45,3 +45,15 @@ def test_ops_fail_loudly_without_gpu_tensors():
     be = ops.HipOps()
     with pytest.raises(_lib.RspError):
         be.momentum_update(torch.zeros(8), torch.zeros(8), 0.9)
+
+
+def test_missing_library_is_a_hard_error(monkeypatch):
+    """No CPU / eager fallback: without the built .so every op backend construction raises."""
+    import pytest
+    from rspnet_amd import ops
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librspnet_hip.so")
+    with pytest.raises(_lib.RspError):
+        _lib.load()
+    with pytest.raises(_lib.RspError):
+        ops.HipOps()

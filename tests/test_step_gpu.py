@@ -35,3 +35,25 @@ def test_step_matches_golden(arch, seed, optimizer):
     assert worst <= grad_tol(arch), worst
     print(f"\n{arch} seed {seed} [{optimizer}] rel errs: " + ", ".join(f"{k}={v:.2e}" for k, v in errs.items())
           + f", grads={worst:.2e}")
+
+
+def test_wrapper_forward_ncdhw_matches_oracle():
+    """MultiTaskWrapper.forward(x) with the reference's NCDHW input (split_wrapper.py:128-152) vs the restatement."""
+    import numpy as np
+    from golden_util import load_spec
+    from model_util import make_cfg
+    from oracle import portable as P
+    from oracle import restatement as S
+    from rspnet_amd.moco import ModelFactory
+    dev = torch.device("cuda", 0)
+    model = ModelFactory(make_cfg("c3d", 64)).build_moco_diffloss(device=dev).module
+    state = P.fill_state(load_spec("c3d"), 5)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    x = torch.from_numpy(P.clips(5, 0, (4, 3, 16, 32, 32))[0])
+    a, m = model.encoder_q(x.to(dev))
+    sd = {k: torch.from_numpy(v.copy()) for k, v in state.items()}
+    ra, rm, _ = S.encoder_forward("c3d", sd, "encoder_q", x)
+    assert float((a.cpu() - ra).abs().max()) < 1e-4 and float((m.cpu() - rm).abs().max()) < 1e-4
+    # train-mode BN side effect: running stats moved like the restatement's
+    got = model.state_dict()["encoder_q.encoder.bn5b.running_mean"].cpu()
+    assert float((got - sd["encoder_q.encoder.bn5b.running_mean"]).abs().max()) < 1e-5
