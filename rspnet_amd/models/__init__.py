@@ -11,7 +11,7 @@ def get_model_class(**kwargs) -> Callable[[int], nn.Module]:
     if arch == "c3d":
         from .c3d import C3D
         return C3D
-    if arch in ("resnet18", "resnet34"):
+    if arch in ("resnet18", "resnet34", "resnet50"):
         from . import resnet
         return getattr(resnet, arch)
     if arch == "s3dg":

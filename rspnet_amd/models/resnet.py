@@ -27,13 +27,29 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
 
+class Bottleneck(nn.Module):
+    """1x1x1 -> 3x3x3 (stride) -> 1x1x1 (x4 channels), models/resnet.py:80-116."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = _conv(planes, planes, 3, stride, 1)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = nn.BatchNorm3d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
 class ResNet(nn.Module):
     classifier_names = ("fc",)
 
     def __init__(self, block, layers, sample_size=112, sample_duration=16, shortcut_type="B", num_classes=400):
         super().__init__()
-        if block is not BasicBlock or shortcut_type != "B":
-            raise NotImplementedError("only BasicBlock / shortcut type B nets (resnet18/34) are on the pretext path")
+        if shortcut_type != "B":
+            raise NotImplementedError("shortcut type A (zero-padded identity) is not used by the pretext configs")
         self.inplanes = 64
         self.conv1 = _conv(3, 64, 7, (1, 2, 2), (3, 3, 3))
         self.bn1 = nn.BatchNorm3d(64)
@@ -66,15 +82,23 @@ class ResNet(nn.Module):
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 s = (blk.stride,) * 3
-                mid, out = nxt, nxt + 1
-                nxt += 2
-                nodes.append(ConvBN(blk.conv1, blk.bn1, cur, mid, (3, 3, 3), s, (1, 1, 1), relu=True))
+                one, zero = (1, 1, 1), (0, 0, 0)
                 res = cur
                 if blk.downsample is not None:
                     res = nxt
                     nxt += 1
-                    nodes.append(ConvBN(blk.downsample[0], blk.downsample[1], cur, res, (1, 1, 1), s, (0, 0, 0), relu=False))
-                nodes.append(ConvBN(blk.conv2, blk.bn2, mid, out, (3, 3, 3), (1, 1, 1), (1, 1, 1), relu=True, residual=res))
+                    nodes.append(ConvBN(blk.downsample[0], blk.downsample[1], cur, res, one, s, zero, relu=False))
+                if isinstance(blk, Bottleneck):
+                    a, b, out = nxt, nxt + 1, nxt + 2
+                    nxt += 3
+                    nodes.append(ConvBN(blk.conv1, blk.bn1, cur, a, one, one, zero, relu=True))
+                    nodes.append(ConvBN(blk.conv2, blk.bn2, a, b, (3, 3, 3), s, one, relu=True))
+                    nodes.append(ConvBN(blk.conv3, blk.bn3, b, out, one, one, zero, relu=True, residual=res))
+                else:
+                    mid, out = nxt, nxt + 1
+                    nxt += 2
+                    nodes.append(ConvBN(blk.conv1, blk.bn1, cur, mid, (3, 3, 3), s, one, relu=True))
+                    nodes.append(ConvBN(blk.conv2, blk.bn2, mid, out, (3, 3, 3), one, one, relu=True, residual=res))
                 cur = out
         return Plan(nodes, input_slot=0, output_slot=cur)
 
@@ -85,3 +109,7 @@ def resnet18(**kwargs):
 
 def resnet34(**kwargs):
     return ResNet(BasicBlock, [3, 4, 6, 3], **kwargs)
+
+
+def resnet50(**kwargs):
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)

@@ -20,7 +20,7 @@ def cpu_backend():
 
 _C3D = cases_for("c3d", 1)
 CASES = [(_C3D[0][0], _C3D[0][2], "fused"), (_C3D[1][0], _C3D[1][2], "torch")] + [
-    (a, s, "fused") for arch in ("resnet18", "r2plus1d-vcop", "s3dg", "c3d:mlp") for a, w, s in cases_for(arch, 1)]
+    (a, s, "fused") for arch in ("resnet18", "r2plus1d-vcop", "s3dg", "c3d:mlp", "resnet50") for a, w, s in cases_for(arch, 1)]
 
 
 @pytest.mark.parametrize("arch,seed,optimizer", CASES)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-CASES = [(a, s, "fused") for arch in ("c3d", "resnet18", "r2plus1d-vcop", "s3dg", "c3d:mlp") for a, w, s in cases_for(arch, 1)] + [
+CASES = [(a, s, "fused") for arch in ("c3d", "resnet18", "r2plus1d-vcop", "s3dg", "c3d:mlp", "resnet50") for a, w, s in cases_for(arch, 1)] + [
     ("c3d", cases_for("c3d", 1)[0][2], "torch")]
 
 
