@@ -73,6 +73,28 @@ class PoolGeom:
                              in_ld or self.C, out_ld or self.C, res_ld or self.C)
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=4096)
+def _conv_plan(lib_id, g: "ConvGeom", in_ld, out_ld):
+    """ctypes descriptor + geometry-derived sizes of one conv application, built once per distinct geometry (the
+    per-launch host cost matters for the small-layer backbones: ~700-2500 launches per step)."""
+    lib = _lib.load()
+    d = g.desc(in_ld=in_ld, out_ld=out_ld)
+    ref = C.byref(d)
+    return (d, ref, lib.rsp_conv3d_stat_tiles(ref), lib.rsp_conv3d_fwd_workspace(ref), lib.rsp_conv3d_dgrad_workspace(ref),
+            lib.rsp_conv3d_wgrad_workspace(ref), g.out_dims)
+
+
+@functools.lru_cache(maxsize=4096)
+def _pool_plan(lib_id, pg: "PoolGeom", in_ld, out_ld, res_ld):
+    lib = _lib.load()
+    d = pg.desc(in_ld=in_ld, out_ld=out_ld, res_ld=res_ld)
+    ref = C.byref(d)
+    return d, ref, lib.rsp_bn_bwd_workspace(ref), pg.out_dims
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -154,18 +176,15 @@ class HipOps:
     def conv_fwd(self, g: ConvGeom, x, w_packed, bias, want_stats: bool, out: Optional[torch.Tensor] = None,
                  out_ld: Optional[int] = None, in_ld: Optional[int] = None):
         _chk(x, "x")
-        d = g.desc(in_ld=in_ld, out_ld=out_ld)
-        do, ho, wo = g.out_dims
+        d, dref, tiles, wsb, _, _, (do, ho, wo) = _conv_plan(0, g, in_ld, out_ld)
         if out is None:
             out = torch.empty((g.N, do, ho, wo, g.Cout), dtype=torch.float32, device=x.device)
         stats = None
         if want_stats:
-            tiles = self.lib.rsp_conv3d_stat_tiles(C.byref(d))
             stats = torch.empty((tiles, g.Cout, 2), dtype=torch.float32, device=x.device)
-        wsb = self.lib.rsp_conv3d_fwd_workspace(C.byref(d))
         ws = self._workspace(x.device, wsb) if wsb else None
         e0 = self._ev()
-        _lib.check(self.lib.rsp_conv3d_fwd(C.byref(d), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
+        _lib.check(self.lib.rsp_conv3d_fwd(dref, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
                                            _ptr(ws), wsb, _stream()), "rsp_conv3d_fwd")
         self._log("conv_fwd", g.flops, e0)
         return out, stats
@@ -173,12 +192,11 @@ class HipOps:
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):
         _chk(dy, "dy")
         _chk(w_ref, "w_ref")
-        d = g.desc()
+        d, dref, _, _, wsb, _, _ = _conv_plan(0, g, None, None)
         dx = torch.empty((g.N, g.Di, g.Hi, g.Wi, g.Cin), dtype=torch.float32, device=dy.device)
-        wsb = self.lib.rsp_conv3d_dgrad_workspace(C.byref(d))
         ws = self._workspace(dy.device, wsb)
         e0 = self._ev()
-        _lib.check(self.lib.rsp_conv3d_dgrad(C.byref(d), _ptr(dy), _ptr(w_ref), _ptr(dx), _ptr(ws), wsb, _stream()),
+        _lib.check(self.lib.rsp_conv3d_dgrad(dref, _ptr(dy), _ptr(w_ref), _ptr(dx), _ptr(ws), wsb, _stream()),
                    "rsp_conv3d_dgrad")
         self._log("conv_dgrad", g.flops, e0)
         return dx
@@ -188,11 +206,10 @@ class HipOps:
         _chk(x, "x")
         _chk(dy, "dy")
         _chk(dw_out, "dw_out")
-        d = g.desc()
-        wsb = self.lib.rsp_conv3d_wgrad_workspace(C.byref(d))
+        d, dref, _, _, _, wsb, _ = _conv_plan(0, g, None, None)
         ws = self._workspace(x.device, wsb)
         e0 = self._ev()
-        _lib.check(self.lib.rsp_conv3d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
+        _lib.check(self.lib.rsp_conv3d_wgrad(dref, _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
                                              _stream()), "rsp_conv3d_wgrad")
         self._log("conv_wgrad", g.flops, e0)
 
@@ -203,7 +220,7 @@ class HipOps:
         tiles, Cc, _ = stats.shape
         mi = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
         ss = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
-        wsb = self.lib.rsp_bn_finalize_workspace(tiles, Cc)
+        wsb = (64 if tiles >= 4096 else (16 if tiles >= 64 else 1)) * Cc * 16   # == rsp_bn_finalize_workspace(tiles, Cc)
         ws = self._workspace(stats.device, wsb)
         _lib.check(self.lib.rsp_bn_finalize(_ptr(stats), tiles, Cc, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta), eps,
                                             momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi), _ptr(ss), _ptr(ws),
@@ -212,23 +229,22 @@ class HipOps:
 
     def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu: bool, out=None):
         _chk(y, "y")
-        do, ho, wo = pg.out_dims
         if out is None:
+            do, ho, wo = pg.out_dims
             out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
-        d = pg.desc(out_ld=_rows_ld(out, "out"), res_ld=None if residual is None else _rows_ld(residual, "residual"))
-        _lib.check(self.lib.rsp_bn_act_pool_fwd(C.byref(d), _ptr(y), _ptr(scale_shift), _ptr(residual), int(relu), _ptr(out),
+        d, dref, _, _ = _pool_plan(0, pg, None, _rows_ld(out, "out"), None if residual is None else _rows_ld(residual, "residual"))
+        _lib.check(self.lib.rsp_bn_act_pool_fwd(dref, _ptr(y), _ptr(scale_shift), _ptr(residual), int(relu), _ptr(out),
                                                 _stream()), "rsp_bn_act_pool_fwd")
         return out
 
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu: bool,
                         want_dres: bool, dgamma_out, dbeta_out):
         _chk(y, "y")
-        d = pg.desc(out_ld=_rows_ld(dout, "dout"), res_ld=None if residual is None else _rows_ld(residual, "residual"))
+        d, dref, wsb, _ = _pool_plan(0, pg, None, _rows_ld(dout, "dout"), None if residual is None else _rows_ld(residual, "residual"))
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if want_dres else None
-        wsb = self.lib.rsp_bn_bwd_workspace(C.byref(d))
         ws = self._workspace(y.device, wsb)
-        _lib.check(self.lib.rsp_bn_act_pool_bwd(C.byref(d), _ptr(y), _ptr(residual), _ptr(dout), _ptr(gamma),
+        _lib.check(self.lib.rsp_bn_act_pool_bwd(dref, _ptr(y), _ptr(residual), _ptr(dout), _ptr(gamma),
                                                 _ptr(mean_invstd), _ptr(scale_shift), int(relu), _ptr(dy), _ptr(dres),
                                                 _ptr(dgamma_out), _ptr(dbeta_out), _ptr(ws), wsb, _stream()),
                    "rsp_bn_act_pool_bwd")
