@@ -15,6 +15,7 @@
 // against 8 x 16-B global loads per thread: staging hides completely behind the matrix pipe; tap re-reads of the
 // input are served by L2 (27 x re-read of conv2's 411 MB input = 1.6 TB/s of L2 traffic, L2 peak 34 TB/s).
 #include "common.h"
+#include "conv_stem.h"
 
 namespace {
 
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nTd * p.nTh * p.nTw + 1);  // [BM]
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) become SALU arithmetic
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
@@ -500,7 +502,7 @@ int launch_cfg(const IgemmParams& p, hipStream_t s) {
   if (!attr_set) {
     const size_t lds_max = (size_t)2 * (BM + BN) * (VEC == 4 ? BK : LDK) * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) +
                            BM * sizeof(long long);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     attr_set = true;
   }
@@ -657,6 +659,7 @@ extern "C" {
 
 size_t rsp_conv3d_packed_fwd_elems(const rsp_conv3d_desc* d) {
   if (!desc_ok(d)) return 0;
+  if (rsp_stem_applicable(d)) return rsp_stem_packed_elems(d);
   const size_t K = (size_t)d->kT * d->kH * d->kW * d->Cin;
   return (size_t)d->Cout * rsp_align_up(K, 4);
 }
@@ -664,6 +667,7 @@ size_t rsp_conv3d_packed_fwd_elems(const rsp_conv3d_desc* d) {
 int rsp_conv3d_pack_fwd(const rsp_conv3d_desc* d, const float* w_ref, float* w_packed, void* stream) {
   RSP_REQUIRE(desc_ok(d), "rsp_conv3d_pack_fwd: bad descriptor");
   RSP_REQUIRE(w_ref && w_packed, "rsp_conv3d_pack_fwd: null pointer");
+  if (rsp_stem_applicable(d)) return rsp_stem_pack(d, w_ref, w_packed, (hipStream_t)stream);
   PackParams p;
   p.w = w_ref; p.out = w_packed;
   p.Cout = d->Cout; p.Cin = d->Cin; p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
@@ -680,11 +684,13 @@ int rsp_conv3d_pack_fwd(const rsp_conv3d_desc* d, const float* w_ref, float* w_p
 
 int32_t rsp_conv3d_stat_tiles(const rsp_conv3d_desc* d) {
   if (!desc_ok(d)) return 0;
+  if (rsp_stem_applicable(d)) return rsp_stem_tiles(d);
   return rsp_cdiv((long long)d->N * d->Do * d->Ho * d->Wo, 128);
 }
 
 size_t rsp_conv3d_fwd_workspace(const rsp_conv3d_desc* d) {
   if (!desc_ok(d)) return 0;
+  if (rsp_stem_applicable(d)) return 0;
   return igemm_partial_bytes((long long)d->N * d->Do * d->Ho * d->Wo, d->Cout, d->kT * d->kH * d->kW * d->Cin);
 }
 
@@ -693,6 +699,7 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   RSP_REQUIRE(desc_ok(d), "rsp_conv3d_fwd: bad descriptor");
   RSP_REQUIRE(x && w_packed && y, "rsp_conv3d_fwd: null pointer");
   RSP_REQUIRE(rsp_aligned16(w_packed), "rsp_conv3d_fwd: packed weight must be 16-byte aligned");
+  if (rsp_stem_applicable(d)) return rsp_stem_fwd(d, x, w_packed, bias, y, stat_partials, (hipStream_t)stream);
   IgemmParams p;
   memset(&p, 0, sizeof p);
   p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.stat = stat_partials;
@@ -760,9 +767,9 @@ int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_r
     // some input positions receive no gradient at all (kernel smaller than stride, e.g. 1x1x1 stride 2)
     const size_t rows = (size_t)d->N * d->Di * d->Hi * d->Wi;
     if (d->in_ld == d->Cin) {
-      hipMemsetAsync(dx, 0, rows * d->Cin * sizeof(float), s);
+      (void)hipMemsetAsync(dx, 0, rows * d->Cin * sizeof(float), s);
     } else {
-      hipMemset2DAsync(dx, (size_t)d->in_ld * 4, 0, (size_t)d->Cin * 4, rows, s);
+      (void)hipMemset2DAsync(dx, (size_t)d->in_ld * 4, 0, (size_t)d->Cin * 4, rows, s);
     }
   }
 

@@ -1,0 +1,12 @@
+// Internal interface of the direct "stem" convolution (conv_stem.hip), used by the rsp_conv3d_* entry points in
+// conv_igemm.hip.  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+// true when rsp_conv3d_{packed_fwd_elems,pack_fwd,stat_tiles,fwd} take the stem path for this descriptor
+bool rsp_stem_applicable(const rsp_conv3d_desc* d);
+int rsp_stem_tiles(const rsp_conv3d_desc* d);            // stat-partial tiles written by rsp_stem_fwd
+size_t rsp_stem_packed_elems(const rsp_conv3d_desc* d);  // floats in the stem weight layout
+int rsp_stem_pack(const rsp_conv3d_desc* d, const float* w_ref, float* w_packed, hipStream_t s);
+int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                 float* stat_partials, hipStream_t s);

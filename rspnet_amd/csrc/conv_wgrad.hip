@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   float* Bt = At + 2 * RK * BM;                    // [2][RK][BN]
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) become SALU arithmetic
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
@@ -256,6 +257,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // k-tile) is produced once per chunk by 32 lanes into a 3-deep LDS ring, so the other 224 threads spend ~4 VALU per
 // 16-byte copy instead of ~40: on this fp32 MFMA loop every VALU issue slot comes straight out of the matrix pipe's.
 // ------------------------------------------------------------------------------------------------------------------
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+template <int T> struct FragVec;
+template <> struct FragVec<1> {
+  typedef float type;
+  static __device__ __forceinline__ float get(const type& v, int) { return v; }
+  static __device__ __forceinline__ void set(type& v, int, float x) { v = x; }
+};
+template <> struct FragVec<2> {
+  typedef floatx2 type;
+  static __device__ __forceinline__ float get(const type& v, int i) { return v[i]; }
+  static __device__ __forceinline__ void set(type& v, int i, float x) { v[i] = x; }
+};
+template <> struct FragVec<4> {
+  typedef floatx4 type;
+  static __device__ __forceinline__ float get(const type& v, int i) { return v[i]; }
+  static __device__ __forceinline__ void set(type& v, int i, float x) { v[i] = x; }
+};
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -273,7 +292,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   int4* taptile = reinterpret_cast<int4*>(rowtab + 3 * RK);     // [<=33] {offd, offh, offw, -}
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) become SALU arithmetic
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
     const int rbase = row_begin + chunk * RK;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const bool ok = acol_ok && rbase + arow + i * ARP < row_end;
+      const bool ok = acol_ok & (rbase + arow + i * ARP < row_end);
       const unsigned off = ok ? aoff[i] : 0xffffffffu;
       aoff[i] += astep;
       float* dst = At + buf * RK * BM + i * ARP * BM + wave * 256;
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const bool ok = bok && ((rt[i].y >> mybit) & 1u);
+      const bool ok = bok & (((rt[i].y >> mybit) & 1u) != 0u);   // '&': no short-circuit branch
       const unsigned off = ok ? rt[i].x + bdelta4 : 0xffffffffu;
       float* dst = Bt + buf * RK * BN + i * BRP * BN + wave * 256;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
@@ -412,21 +432,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   int buf = 0;
   for (int c = 0; c < nchunk; ++c) {
     const bool more = c + 1 < nchunk;
-    // 1. every LDS access of this iteration first (hipcc orders LDS accesses behind pending LDS-DMA)
-    const float* a = At + buf * RK * BM + wm * WM + l32;
-    const float* b = Bt + buf * RK * BN + wn * WN + l32;
-    float af[RK / 2][TM], bf[RK / 2][TN];
+    // 1. every LDS access of this iteration first (hipcc orders LDS accesses behind pending LDS-DMA); the row table goes
+    //    first so that the copies' address math does not wait for the whole fragment burst
+    if (more) read_rowtab((c + 1) % 3);
+    const float* a = At + buf * RK * BM + wm * WM + TM * l32;
+    const float* b = Bt + buf * RK * BN + wn * WN + TN * l32;
+    // MFMA row m of sub-tile i is channel TM*m + i (columns likewise), so a lane's TM (TN) operands for one k-step are
+    // adjacent floats: one ds_read_b64 instead of two ds_read_b32 (the epilogue undoes the interleave)
+    typename FragVec<TM>::type af[RK / 2];
+    typename FragVec<TN>::type bf[RK / 2];
 #pragma unroll
     for (int s2 = 0; s2 < RK / 2; ++s2) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[s2][i] = a[(2 * s2 + h) * BM + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[s2][j] = b[(2 * s2 + h) * BN + j * 32];
+      af[s2] = *reinterpret_cast<const typename FragVec<TM>::type*>(a + (2 * s2 + h) * BM);
+      bf[s2] = *reinterpret_cast<const typename FragVec<TN>::type*>(b + (2 * s2 + h) * BN);
     }
-    if (more) read_rowtab((c + 1) % 3);
+#ifdef RSP_TUNE
+    if (!(p.tune & 512)) produce(c + 2, (c + 2) % 3);
+    if (more && !(p.tune & 1024)) issue(c + 1, buf ^ 1);
+#else
     produce(c + 2, (c + 2) % 3);
     // 2. next chunk's copies in flight under this chunk's MFMAs
     if (more) issue(c + 1, buf ^ 1);
+#endif
     // 3. MFMAs
 #pragma unroll
     for (int s2 = 0; s2 < RK / 2; ++s2)
@@ -434,25 +461,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FragVec<TM>::get(af[s2], i), FragVec<TN>::get(bf[s2], j), acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef RSP_TUNE
+    if (!(p.tune & 2048)) __syncthreads();
+#else
     __syncthreads();
+#endif
     buf ^= 1;
   }
 
   float* dst = p.partial + (long long)z * p.Cout * p.Kld;
+  const int k = k0 + wn * WN + TN * l32;   // TN adjacent columns per lane; Kld % 4 == 0 and k % TN == 0
+  if (k < p.Kld) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int k = k0 + wn * WN + j * 32 + l32;
-    if (k < p.Kld) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * WM + TM * ((e >> 2) * 8 + h * 4 + (e & 3)) + i;
+        if (co < p.Cout) {
+          typename FragVec<TN>::type v;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int co = co0 + wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
-          if (co < p.Cout) dst[(long long)co * p.Kld + k] = acc[i][j][e];
+          for (int j = 0; j < TN; ++j) FragVec<TN>::set(v, j, acc[i][j][e]);
+          *reinterpret_cast<typename FragVec<TN>::type*>(dst + (long long)co * p.Kld + k) = v;
         }
-    }
+      }
   }
 }
 

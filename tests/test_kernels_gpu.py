@@ -49,6 +49,13 @@ CONV_CASES = [
     (2, 4, 7, 7, 192, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # S3D-G pointwise to 16 ch (BN=32 tile)
     (2, 4, 7, 7, 16, 48, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # S3D-G (1,3,3), Cout=48
     (1, 1, 5, 5, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # tiny: M=25 < one tile
+    # 4-channel (zero-padded RGB) stems: direct LDS-halo kernel (conv_stem.hip)
+    (2, 4, 12, 12, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # C3D conv1: all 3 time-slices resident, 14-tap chunks
+    (2, 5, 18, 20, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),        # R3D stem: ring of 3 time-slices, stride 2 de-interleave
+    (1, 3, 23, 17, 4, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)),        # R(2+1)D stem: Cout=45, ragged patches
+    (1, 4, 9, 9, 4, 64, (1, 7, 7), (2, 2, 2), (0, 3, 3)),          # S3D-G stem: stride 2 in T too
+    (2, 2, 16, 8, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),         # narrow frame: 16x8 patches
+    (1, 2, 33, 35, 4, 32, (3, 5, 5), (1, 1, 2), (1, 2, 2)),        # mixed strides, 5x5, Cout=32
 ]
 
 

@@ -13,10 +13,14 @@ ap.add_argument("--tune", type=int, default=None)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--what", default="fwd,dgrad,wgrad")
+ap.add_argument("--stems", action="store_true", help="the four backbone stems (Cin padded to 4) instead of the C3D stack")
+ap.add_argument("--no-stem-kernel", action="store_true", help="ablation build only: route stems through the implicit-GEMM kernel")
 args = ap.parse_args()
 if args.tune is not None:
     os.environ["RSPNET_HIP_LIB"] = os.path.join(ROOT, "tools", "librspnet_hip_tune.so")
     os.environ["RSP_TUNE"] = str(args.tune)
+if args.no_stem_kernel:
+    os.environ["RSP_NO_STEM"] = "1"
 
 import torch
 from rspnet_amd import ops
@@ -41,12 +45,18 @@ def timeit(fn):
     return e0.elapsed_time(e1) / args.iters
 
 
+STEMS = [("c3d-stem", 16, 112, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)), ("r3d-stem", 16, 112, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),
+         ("r21d-stem", 16, 112, 4, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)), ("s3dg-stem", 16, 224, 4, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3))]
+if args.stems:
+    LAYERS = STEMS
 tot = {}
-for name, T, HW, cin, cout in LAYERS:
-    g = ConvGeom(B, T, HW, HW, cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+for L in LAYERS:
+    name, T, HW, cin, cout = L[:5]
+    k, s, p = L[5:] if len(L) > 5 else ((3, 3, 3), (1, 1, 1), (1, 1, 1))
+    g = ConvGeom(B, T, HW, HW, cin, cout, k, s, p)
     x = torch.randn(B, T, HW, HW, cin, device=dev)
-    w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
-    dy = torch.randn(B, T, HW, HW, cout, device=dev)
+    w = torch.randn(cout, cin, *k, device=dev) * 0.05
+    dy = torch.randn(B, *g.out_dims, cout, device=dev)
     wp = be.conv_pack_fwd(g, w)
     dw = torch.empty_like(w)
     line = f"{name:7s} {g.flops / 1e9:8.1f} GF"
