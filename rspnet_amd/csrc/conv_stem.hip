@@ -2,8 +2,9 @@
 // models/resnet.py:124, the (1,7,7) stems of S3D-G models/s3dg.py:207 and R(2+1)D models/r2plus1d_vcop.py:70).
 //
 // With Cin = 4 the implicit-GEMM gather moves one 16-byte pixel per lane per tap: every K-chunk re-derives 4 bounds
-// checks per copy and the texture path sees 64 unrelated addresses per instruction, so the generic kernel sits at ~40%
-// of the MFMA peak on these layers.  Here the im2col expansion happens at LDS-read time instead:
+// checks per copy and the texture path sees 64 unrelated addresses per instruction; on the short-K stems (27..49 taps)
+// that, plus the per-tile prologue/epilogue, holds the generic kernel at 57-82 TFLOP/s (profiles/r01/stem_kernel.txt).
+// Here the im2col expansion happens at LDS-read time instead:
 //
 //   * a workgroup owns a TH x TW (8x16 or 16x8) patch of one output frame = 128 GEMM rows, all (<= 64) output channels;
 //   * the input halo of that patch is copied ONCE per kernel-time-slice into LDS by LDS-DMA, as whole pixel rows

@@ -31,6 +31,7 @@ struct WgradParams {
   int co_tiles, k_tiles;
   const float* __restrict__ zero;  // >= 64 B of zeros
   unsigned x_bytes, dy_bytes;      // extents for the buffer descriptors of the DMA variant
+  const uint2* __restrict__ rowgeom;  // [M] row geometry (DMA variant)
   int tune;
 };
 
@@ -252,10 +253,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (Cin % 4 == 0, Cout % 4 == 0, tensors < 4 GiB): both tiles are filled by buffer_load ... lds with
-// 32-bit offsets (out-of-range => hardware zero fill).  Row geometry (input byte offset + a validity bit per tap of this
-// k-tile) is produced once per chunk by 32 lanes into a 3-deep LDS ring, so the other 224 threads spend ~4 VALU per
-// 16-byte copy instead of ~40: on this fp32 MFMA loop every VALU issue slot comes straight out of the matrix pipe's.
+// LDS-DMA variant (Cin % 4 == 0, Cout % 4 == 0, tensors < 4 GiB, kernel dims <= 8): both tiles are filled by
+// buffer_load ... lds with 32-bit offsets (out-of-range => hardware zero fill).  The per-row geometry -- input byte
+// offset of the row's window origin and one validity bit per kernel index and dimension -- does not depend on the k-tile,
+// so a tiny pre-pass (rowgeom_kernel) writes it once per call and every workgroup streams it through a 3-deep LDS ring
+// with one 256-byte copy per chunk: the copy threads then spend ~4 VALU per 16-byte copy instead of ~40, and no wave
+// carries row arithmetic (on this fp32 MFMA loop every VALU issue slot comes straight out of the matrix pipe's).
 // ------------------------------------------------------------------------------------------------------------------
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 template <int T> struct FragVec;
@@ -275,6 +278,28 @@ template <> struct FragVec<4> {
   static __device__ __forceinline__ void set(type& v, int i, float x) { v[i] = x; }
 };
 
+struct RowGeomParams {
+  uint2* __restrict__ out;   // [M] {byte offset of x[n, gd*sD, gh*sH, gw*sW, 0] (mod 2^32), validity bits}
+  int M, Gd, Gh, Gw, Di, Hi, Wi, in_ld, sD, sH, sW, kT, kH, kW, pT, pH, pW;
+};
+
+__global__ void rowgeom_kernel(const RowGeomParams p) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.M) return;
+  const int gw = r % p.Gw;
+  int q = r / p.Gw;
+  const int gh = q % p.Gh;
+  q /= p.Gh;
+  const int gd = q % p.Gd;
+  const int n = q / p.Gd;
+  const int id0 = gd * p.sD, ih0 = gh * p.sH, iw0 = gw * p.sW;
+  unsigned m = 0;
+  for (int k = 0; k < p.kT; ++k) m |= (unsigned)((unsigned)(id0 + k - p.pT) < (unsigned)p.Di) << k;
+  for (int k = 0; k < p.kH; ++k) m |= (unsigned)((unsigned)(ih0 + k - p.pH) < (unsigned)p.Hi) << (8 + k);
+  for (int k = 0; k < p.kW; ++k) m |= (unsigned)((unsigned)(iw0 + k - p.pW) < (unsigned)p.Wi) << (16 + k);
+  p.out[r] = make_uint2((unsigned)(((((long long)n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0) * p.in_ld * 4), m);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -283,13 +308,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   constexpr int ARP = 256 / ACOLS, BRP = 256 / BCOLS;
   constexpr int AR = RK / ARP, BR = RK / BRP;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(RK == 32, "row-geometry ring: 32 rows x 8 B = 16 lanes x 16 B per chunk");
   typedef __attribute__((address_space(3))) void* lptr_t;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* At = reinterpret_cast<float*>(smem_raw);          // [2][RK][BM]
   float* Bt = At + 2 * RK * BM;                            // [2][RK][BN]
-  uint2* rowtab = reinterpret_cast<uint2*>(Bt + 2 * RK * BN);   // [3][RK] {input byte offset, tap validity bits}
-  int4* taptile = reinterpret_cast<int4*>(rowtab + 3 * RK);     // [<=33] {offd, offh, offw, -}
+  uint2* rowtab = reinterpret_cast<uint2*>(Bt + 2 * RK * BN);   // [3][RK] ring of row geometry
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -306,18 +331,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
 
   __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-
-  // taps covered by this k-tile
-  const int ntaps = p.kT * p.kH * p.kW;
-  const int tap_lo = k0 / p.Cin;
-  const int tap_hi = min(ntaps - 1, (k0 + BN - 1) / p.Cin);
-  const int ntl = tap_hi - tap_lo + 1;   // <= 32 (host-checked)
-  if (t < ntl) {
-    const int tap = tap_lo + t;
-    const int kw = tap % p.kW, q = tap / p.kW;
-    const int kh = q % p.kH, kt = q / p.kH;
-    taptile[t] = make_int4(kt - p.pT, kh - p.pH, kw - p.pW, 0);
-  }
+  __amdgpu_buffer_rsrc_t rsrc_rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(p.rowgeom), 0, (int)((unsigned)p.M * 8u), 0x00020000);
 
   // A side (dy)
   const int acol = (t % ACOLS) * 4, arow = t / ACOLS;
@@ -327,63 +341,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   for (int i = 0; i < AR; ++i)
     aoff[i] = ((unsigned)(row_begin + arow + i * ARP) * (unsigned)p.dy_ld + (unsigned)(co0 + acol)) * 4u;
   const unsigned astep = (unsigned)RK * (unsigned)p.dy_ld * 4u;
-  // B side (im2col x): this thread's k -> tap bit and byte delta
+  // B side (im2col x): this thread's k -> the three validity bits it needs and the byte delta of its (tap, ci)
   const int bcol = (t % BCOLS) * 4, brow = t / BCOLS;
   const int kk = k0 + bcol;
   const bool bok = kk < p.K;
-  int mybit = 0;
-  unsigned bdelta4 = 0;
+  unsigned mymask = 0, bdelta4 = 0;
   {
     const int k1 = bok ? kk : k0;
     const int tap = k1 / p.Cin, ci = k1 - tap * p.Cin;
     const int kw = tap % p.kW, q = tap / p.kW;
     const int kh = q % p.kH, kt = q / p.kH;
-    mybit = tap - tap_lo;
+    mymask = (1u << kt) | (1u << (8 + kh)) | (1u << (16 + kw));
     bdelta4 = (unsigned)(((((kt - p.pT) * p.Hi + (kh - p.pH)) * p.Wi + (kw - p.pW)) * p.in_ld + ci) * 4);
   }
 
-  // producer state: lane t < RK owns row (chunk base + t)
-  RowPos pos;
-  {
-    const int r = row_begin + (t & (RK - 1));
-    pos.gw = r % p.Gw;
-    int q = r / p.Gw;
-    pos.gh = q % p.Gh;
-    q /= p.Gh;
-    pos.gd = q % p.Gd;
-    pos.n = q / p.Gd;
-  }
-  const int st_w = RK % p.Gw, st_h = (RK / p.Gw) % p.Gh, st_d = (RK / (p.Gw * p.Gh)) % p.Gd,
-            st_n = RK / (p.Gw * p.Gh * p.Gd);
-  __syncthreads();   // taptile visible
-
-  auto produce = [&](int chunk, int slot) {   // lanes t < RK: geometry of row (row_begin + chunk*RK + t)
-    if (t < RK) {
-      const int r = row_begin + chunk * RK + t;
-      uint2 e = make_uint2(0u, 0u);
-      if (r < row_end) {
-        const int id0 = pos.gd * p.sD, ih0 = pos.gh * p.sH, iw0 = pos.gw * p.sW;
-        e.x = (unsigned)(((((long long)pos.n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0) * p.in_ld * 4);
-        unsigned m = 0;
-        for (int j = 0; j < ntl; ++j) {
-          const int4 tt = taptile[j];
-          const int id = id0 + tt.x, ih = ih0 + tt.y, iw = iw0 + tt.z;
-          if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) m |= 1u << j;
-        }
-        e.y = m;
-      }
-      rowtab[slot * RK + t] = e;
-      // advance to the row RK further on (branch-free mixed-radix add)
-      pos.gw += st_w;
-      int c = pos.gw >= p.Gw;
-      pos.gw -= c ? p.Gw : 0;
-      pos.gh += st_h + c;
-      c = pos.gh >= p.Gh;
-      pos.gh -= c ? p.Gh : 0;
-      pos.gd += st_d + c;
-      c = pos.gd >= p.Gd;
-      pos.gd -= c ? p.Gd : 0;
-      pos.n += st_n + c;
+  // row geometry of chunk `chunk` -> ring slot: 16 lanes of wave 0 copy 32 rows x 8 B (rows >= M read as zeros = invalid;
+  // rows >= row_end are cancelled on the dy side)
+  auto fetch_rows = [&](int chunk, int slot) {
+    if (t < 16) {
+      const unsigned off = ((unsigned)(row_begin + chunk * RK) + 2u * (unsigned)t) * 8u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_rg, (lptr_t)(rowtab + slot * RK), 16, off, 0, 0, 0);
     }
   };
 
@@ -404,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const bool ok = bok & (((rt[i].y >> mybit) & 1u) != 0u);   // '&': no short-circuit branch
+      const bool ok = bok & ((rt[i].y & mymask) == mymask);   // '&': no short-circuit branch
       const unsigned off = ok ? rt[i].x + bdelta4 : 0xffffffffu;
       float* dst = Bt + buf * RK * BN + i * BRP * BN + wave * 256;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
@@ -420,8 +397,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nchunk = (row_end - row_begin + RK - 1) / RK;
-  produce(0, 0);
-  produce(1, 1);
+  fetch_rows(0, 0);
+  fetch_rows(1, 1);
   __syncthreads();
   if (nchunk > 0) {
     read_rowtab(0);
@@ -447,10 +424,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
       bf[s2] = *reinterpret_cast<const typename FragVec<TN>::type*>(b + (2 * s2 + h) * BN);
     }
 #ifdef RSP_TUNE
-    if (!(p.tune & 512)) produce(c + 2, (c + 2) % 3);
+    if (!(p.tune & 512)) fetch_rows(c + 2, (c + 2) % 3);
     if (more && !(p.tune & 1024)) issue(c + 1, buf ^ 1);
 #else
-    produce(c + 2, (c + 2) % 3);
+    fetch_rows(c + 2, (c + 2) % 3);
     // 2. next chunk's copies in flight under this chunk's MFMAs
     if (more) issue(c + 1, buf ^ 1);
 #endif
@@ -547,7 +524,7 @@ int launch_w(const WgradParams& p, hipStream_t s) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_w_dma(const WgradParams& p, hipStream_t s) {
-  const size_t lds = (size_t)2 * RK * (BM + BN) * sizeof(float) + 3 * RK * sizeof(uint2) + 34 * sizeof(int4);
+  const size_t lds = (size_t)2 * RK * (BM + BN) * sizeof(float) + 3 * RK * sizeof(uint2);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N>),
@@ -583,7 +560,7 @@ bool wdesc_ok(const rsp_conv3d_desc* d) {
 
 struct WPlan {
   int bm, bn, co_tiles, k_tiles, splitm, rows_per_split, Kld;
-  size_t partial_bytes, colsum_bytes;
+  size_t partial_bytes, colsum_bytes, rowgeom_bytes;
 };
 
 WPlan wplan(const rsp_conv3d_desc* d) {
@@ -606,6 +583,7 @@ WPlan wplan(const rsp_conv3d_desc* d) {
   w.splitm = (int)((M + rps - 1) / rps);
   w.partial_bytes = rsp_align_up((size_t)w.splitm * d->Cout * w.Kld * sizeof(float), 256);
   w.colsum_bytes = rsp_align_up((size_t)rsp_cdiv(M, 1024) * d->Cout * sizeof(float), 256);
+  w.rowgeom_bytes = rsp_align_up((size_t)M * sizeof(uint2), 256);
   return w;
 }
 
@@ -616,7 +594,7 @@ extern "C" {
 size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d) {
   if (!wdesc_ok(d)) return 0;
   const WPlan w = wplan(d);
-  return w.partial_bytes + w.colsum_bytes;
+  return w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes;
 }
 
 int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
@@ -625,7 +603,7 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad: null pointer");
   RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_wgrad: workspace must be 16-byte aligned");
   const WPlan w = wplan(d);
-  if (workspace_bytes < w.partial_bytes + w.colsum_bytes) {
+  if (workspace_bytes < w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes) {
     rsp_set_error("rsp_conv3d_wgrad: workspace too small");
     return RSP_EWORKSPACE;
   }
@@ -662,11 +640,21 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   const unsigned long long dyb = (unsigned long long)p.M * d->out_ld * 4ull;
   p.x_bytes = (unsigned)xb;
   p.dy_bytes = (unsigned)dyb;
-  bool dma = va && vb && xb < (1ull << 32) && dyb < (1ull << 32) && (w.bn + d->Cin - 1) / d->Cin + 1 <= 32;
+  bool dma = va && vb && xb < (1ull << 32) && dyb < (1ull << 32) && d->kT <= 8 && d->kH <= 8 && d->kW <= 8;
 #ifdef RSP_TUNE
   if (p.tune & 128) dma = false;
 #endif
   int rc;
+  if (dma) {
+    RowGeomParams g;
+    g.out = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(workspace) + w.partial_bytes + w.colsum_bytes);
+    g.M = p.M; g.Gd = p.Gd; g.Gh = p.Gh; g.Gw = p.Gw; g.Di = p.Di; g.Hi = p.Hi; g.Wi = p.Wi; g.in_ld = p.in_ld;
+    g.sD = p.sD; g.sH = p.sH; g.sW = p.sW; g.kT = p.kT; g.kH = p.kH; g.kW = p.kW; g.pT = p.pT; g.pH = p.pH; g.pW = p.pW;
+    hipLaunchKernelGGL(rowgeom_kernel, dim3(rsp_cdiv(p.M, 256)), dim3(256), 0, s, g);
+    rc = rsp_check_launch("rowgeom_kernel");
+    if (rc != RSP_OK) return rc;
+    p.rowgeom = g.out;
+  }
   if (dma && w.bm == 128 && w.bn == 128) rc = launch_w_dma<128, 128, 2, 2>(p, s);
   else if (dma && w.bm == 128) rc = launch_w_dma<128, 64, 2, 2>(p, s);
   else if (dma && w.bn == 128) rc = launch_w_dma<64, 128, 2, 2>(p, s);
