@@ -44,7 +44,9 @@ struct IgemmParams {
   int off0d, off0h, off0w;      // first tap offset per dim
   int offstep;                  // +1 forward, -1 dgrad
   int K, Kld, nchunks;
-  int splitk, chunks_per_split;
+  int splitk, chunks_per_split;   // K split of the TAIL tiles (tile id >= full_tiles); splitk == 1: none
+  int full_tiles;                 // tiles [0, full_tiles) run whole-K and write y directly
+  int tail_row0;                  // first GEMM row of the tail tiles (partial buffer is [splitk][M - tail_row0][Cout])
   int m_tiles, n_tiles;
   const float* __restrict__ zero;  // >= 64 B of zeros (g_zero)
   unsigned x_bytes, w_bytes;       // extents for the buffer descriptors of the DMA path (< 4 GiB)
@@ -78,12 +80,24 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const int tile = rsp_xcd_remap(blockIdx.x, gridDim.x);
+  // Blocks [0, full_tiles) own one whole-K tile each.  The remaining tiles -- the part of the grid that would otherwise
+  // run as a mostly empty last round on the 256 CUs -- are cut along K into `splitk` units each (unit u: tile u % R,
+  // K-slice u / R, so neighbouring units share the weight slice in L2) and leave fp32 partials for splitk_reduce_kernel.
+  int tile, z = 0;
+  bool is_partial = false;
+  if ((int)blockIdx.x < p.full_tiles) {
+    tile = rsp_xcd_remap(blockIdx.x, p.full_tiles);
+  } else {
+    const int R = p.m_tiles * p.n_tiles - p.full_tiles;
+    const int u = rsp_xcd_remap(blockIdx.x - p.full_tiles, (int)gridDim.x - p.full_tiles);
+    z = u / R;
+    tile = p.full_tiles + (u - z * R);
+    is_partial = p.splitk > 1;
+  }
   const int m_tile = tile / p.n_tiles, n_tile = tile - m_tile * p.n_tiles;
   const int m0 = m_tile * BM, n0 = n_tile * BN;
-  const int z = blockIdx.y;
-  const int kc_begin = z * p.chunks_per_split;
-  const int kc_end = min(p.nchunks, kc_begin + p.chunks_per_split);
+  const int kc_begin = is_partial ? z * p.chunks_per_split : 0;
+  const int kc_end = is_partial ? min(p.nchunks, kc_begin + p.chunks_per_split) : p.nchunks;
 
   // ---- tap table --------------------------------------------------------------------------------------
   const int ntaps = p.nTd * p.nTh * p.nTw;
@@ -325,8 +339,8 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
     const int r = m0 + t;
     long long addr = -1;
     if (r < p.M) {
-      if (p.partial) {
-        addr = ((long long)z * p.M + r) * p.Cout;
+      if (is_partial) {
+        addr = ((long long)z * (p.M - p.tail_row0) + (r - p.tail_row0)) * p.Cout;
       } else {
         const int gw = r % p.Gw;
         int q = r / p.Gw;
@@ -342,12 +356,12 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   }
   __syncthreads();
 
-  float* dst = p.partial ? p.partial : p.y;
+  float* dst = is_partial ? p.partial : p.y;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WN + j * 32 + l32;
     if (col < p.Cout) {
-      const float bv = (p.bias && !p.partial) ? p.bias[col] : 0.f;
+      const float bv = (p.bias && !is_partial) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
     }
   }
 
-  if (p.stat && !p.partial) {
+  if (p.stat && !is_partial) {
     // per-channel (sum, sumsq) of the bias-free conv output per 128-row block; rows >= M contributed zeros.
     constexpr int SB = BM / 128;             // stat blocks per tile
     constexpr int WPB = WAVES_M / SB;        // waves (along M) per stat block
@@ -413,13 +427,14 @@ struct ReduceParams {
   float* __restrict__ y;
   float* __restrict__ stat;
   int M, Cout, splitk;
+  int row0;   // first row covered by the partials ([splitk][M - row0][Cout]); a multiple of 128
   int Gd, Gh, Gw, oDm, oHm, oWm, oSd, oSh, oSw, oOd, oOh, oOw, out_ld;
 };
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
   // block = one 128-row tile x 64 channels; thread = (row group of 4 lanes.., channel)
   __shared__ float red[4][64][2];
-  const int m_tile = blockIdx.x, c0 = blockIdx.y * 64;
+  const int m_tile = p.row0 / 128 + blockIdx.x, c0 = blockIdx.y * 64;
   const int c = c0 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;  // 0..3 -> rows rg, rg+4, ...
   float s = 0.f, ss = 0.f;
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
       const int r = m_tile * 128 + rl;
       if (r >= p.M) break;
       float v = 0.f;
-      for (int z = 0; z < p.splitk; ++z) v += p.partial[((long long)z * p.M + r) * p.Cout + c];
+      for (int z = 0; z < p.splitk; ++z) v += p.partial[((long long)z * (p.M - p.row0) + (r - p.row0)) * p.Cout + c];
       const int gw = r % p.Gw;
       int q = r / p.Gw;
       const int gh = q % p.Gh;
@@ -506,7 +521,7 @@ int launch_cfg(const IgemmParams& p, hipStream_t s) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     attr_set = true;
   }
-  dim3 grid(p.m_tiles * p.n_tiles, p.splitk);
+  dim3 grid(p.full_tiles + (p.m_tiles * p.n_tiles - p.full_tiles) * p.splitk);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("igemm_kernel");
 }
@@ -517,7 +532,7 @@ int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   p.m_tiles = rsp_cdiv(p.M, 128);
   p.n_tiles = rsp_cdiv(p.Cout, bn);
 #ifdef RSP_TUNE
-  if (bn == 128 && vec4 && (p.tune & 8) && p.splitk == 1) {   // experiment: one 256x128 workgroup per CU, 1 wave per SIMD
+  if (bn == 128 && vec4 && (p.tune & 8) && p.splitk == 1 && false) {   // experiment: one 256x128 workgroup per CU, 1 wave per SIMD
     p.m_tiles = rsp_cdiv(p.M, 256);
     return launch_cfg<256, 128, 2, 2, 4, 1>(p, s);
   }
@@ -527,23 +542,45 @@ int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   return vec4 ? launch_cfg<128, 32, 4, 1, 4>(p, s) : launch_cfg<128, 32, 4, 1, 1>(p, s);
 }
 
-// Split-K by a small cost model.  256 CUs x 2 resident workgroups = 512 slots; equal-sized tiles run in
-// ceil(units/512) rounds, so e.g. C3D conv4 (784 tiles) wastes 1/4 of the machine unsplit.  Splitting K by S makes the
-// rounds shorter (and more numerous) at the price of an fp32 partial round trip + reduce launch.
-int choose_splitk(int tiles, int nchunks, long long M, int Cout) {
-  if (tiles >= 4096 || nchunks < 8) return 1;
-  const double t_chunk2 = 4.7e-6, t_chunk1 = 2.7e-6;   // measured per-chunk time with 2 / 1 workgroups on a CU
-  int best = 1;
-  double best_t = 1e30;
-  for (int S = 1; S <= 16 && S * 4 <= nchunks; ++S) {
+// Tail split by a small cost model.  A CU holds `wpc` workgroups of this tile shape, so the machine has 256*wpc slots and
+// equal-sized tiles run in ceil(tiles/slots) rounds: C3D conv3 (3136 tiles, 512 slots) spends 1/8 of its time in a last
+// round that is 1/8 full, conv4 (784 tiles) half of it in a round that is half full.  The plan keeps the whole rounds as
+// they are and cuts only the remainder R along K into S slices each (S*R units of ceil(nchunks/S) chunks), at the price
+// of an fp32 partial round trip + one reduce launch for those tiles.
+struct SplitPlan {
+  int full_tiles;   // multiple of n_tiles
+  int splitk;       // S (1: no split)
+  int cps;          // chunks per slice
+};
+
+SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, int Cout) {
+  const int tiles = m_tiles * n_tiles;
+  // resident workgroups per CU of igemm_kernel<128, bn, .., VEC>: LDS-limited (DMA variants) or VGPR-limited (scalar gather)
+  const int wpc = vec4 ? (bn >= 128 ? 2 : 3) : (bn >= 64 ? 2 : 3);
+  const int slots = 256 * wpc;
+  SplitPlan best = {tiles, 1, nchunks};
+  if (nchunks < 8) return best;
+  const double t_chunk = 2.35e-6 * wpc * bn / 128.0, t_chunk1 = 2.7e-6 * bn / 128.0;   // measured on the 128x128 tile
+  const double ovh = 3.0;   // prologue + epilogue of a unit, in chunk times
+  auto round_time = [&](long long units, int chunks) {
+    if (units <= 0) return 0.0;
+    if (units <= 256) return (chunks + ovh) * t_chunk1;            // one workgroup per CU: no sharing of the matrix pipe
+    return (double)rsp_cdiv(units, slots) * (chunks + ovh) * t_chunk;
+  };
+  int full = tiles / slots * slots;
+  full -= full % n_tiles;
+  const int R = tiles - full;
+  if (R == 0) return best;
+  // only the tail differs between candidates (the whole rounds cost the same under every plan)
+  double best_t = round_time(R, nchunks);
+  for (int S = 2; S <= 16 && S * 4 <= nchunks; ++S) {
     const int cps = rsp_cdiv(nchunks, S), Se = rsp_cdiv(nchunks, cps);
     if (Se != S) continue;
-    const long long units = (long long)tiles * Se;
-    double t = units <= 256 ? (cps + 3) * t_chunk1 : (double)rsp_cdiv(units, 512) * (cps + 3) * t_chunk2;
-    if (Se > 1) t += 4e-6 + (double)(Se + 1) * M * Cout * 4.0 / 3.0e12;
-    if (t < best_t * 0.97) {
+    double t = round_time((long long)R * Se, cps);
+    t += 4e-6 + (double)(Se + 1) * ((double)R / n_tiles * 128.0) * Cout * 4.0 / 3.0e12;
+    if (t < best_t * 0.98) {
       best_t = t;
-      best = Se;
+      best = {full, Se, cps};
     }
   }
   return best;
@@ -572,11 +609,20 @@ void fill_reduce(ReduceParams& r, const IgemmParams& p) {
   r.M = p.M;
   r.Cout = p.Cout;
   r.splitk = p.splitk;
+  r.row0 = p.tail_row0;
   r.Gd = p.Gd; r.Gh = p.Gh; r.Gw = p.Gw;
   r.oDm = p.oDm; r.oHm = p.oHm; r.oWm = p.oWm;
   r.oSd = p.oSd; r.oSh = p.oSh; r.oSw = p.oSw;
   r.oOd = p.oOd; r.oOh = p.oOh; r.oOw = p.oOw;
   r.out_ld = p.out_ld;
+}
+
+inline int tile_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+
+size_t split_partial_bytes(const SplitPlan& sp, long long M, int n_tiles, int Cout) {
+  if (sp.splitk <= 1) return 0;
+  const long long row0 = (long long)(sp.full_tiles / n_tiles) * 128;
+  return (size_t)sp.splitk * (size_t)(M - row0) * Cout * sizeof(float);
 }
 
 int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
@@ -597,22 +643,40 @@ int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipSt
   }
 #endif
   p.nchunks = rsp_cdiv(p.K, BK);
-  const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
-  const int tiles = rsp_cdiv(p.M, 128) * rsp_cdiv(p.Cout, bn);
-  int sk = choose_splitk(tiles, p.nchunks, p.M, p.Cout);
-  if (sk > 1) {
-    const size_t need = (size_t)sk * p.M * p.Cout * sizeof(float);
-    if (!workspace || ws_bytes < need) sk = 1;  // degrade gracefully: still correct
+  const int bn = tile_bn(p.Cout);
+  const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
+  SplitPlan sp = plan_split(m_tiles, n_tiles, bn, vec4, p.nchunks, p.Cout);
+#ifdef RSP_TUNE
+  if (p.tune & 4096) sp = {m_tiles * n_tiles, 1, p.nchunks};   // ablation: no tail split
+  if (const char* e = getenv("RSP_SPLIT")) {                    // sweep: force S on the tail (RSP_FULL=0: split every tile)
+    const int S = atoi(e);
+    const char* f = getenv("RSP_FULL");
+    int full = sp.full_tiles == m_tiles * n_tiles ? (m_tiles * n_tiles) / 512 * 512 : sp.full_tiles;
+    if (f && atoi(f) == 0) full = 0;
+    const int cps = rsp_cdiv(p.nchunks, S);
+    sp = {S > 1 ? full : m_tiles * n_tiles, rsp_cdiv(p.nchunks, cps), cps};
+    if (sp.full_tiles >= m_tiles * n_tiles || sp.splitk <= 1) sp = {m_tiles * n_tiles, 1, p.nchunks};
+    static int once = 0;
+    if (!(once++)) fprintf(stderr, "[tune] tiles %d full %d S %d cps %d\n", m_tiles * n_tiles, sp.full_tiles, sp.splitk, sp.cps);
+  } else {
+    static long long last = -1;
+    const long long key = (long long)m_tiles * 1000003 + p.nchunks * 17 + n_tiles;
+    if (key != last) { last = key; fprintf(stderr, "[plan] tiles %d full %d S %d cps %d (nchunks %d)\n", m_tiles * n_tiles, sp.full_tiles, sp.splitk, sp.cps, p.nchunks); }
   }
-  p.chunks_per_split = rsp_cdiv(p.nchunks, sk);
-  p.splitk = rsp_cdiv(p.nchunks, p.chunks_per_split);
+#endif
+  if (sp.splitk > 1 && (!workspace || ws_bytes < split_partial_bytes(sp, p.M, n_tiles, p.Cout)))
+    sp = {m_tiles * n_tiles, 1, p.nchunks};   // degrade gracefully: still correct
+  p.full_tiles = sp.full_tiles;
+  p.splitk = sp.splitk;
+  p.chunks_per_split = sp.cps;
+  p.tail_row0 = sp.full_tiles / n_tiles * 128;
   p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   int rc = launch_igemm(p, vec4, s);
   if (rc != RSP_OK) return rc;
   if (p.splitk > 1) {
     ReduceParams r;
     fill_reduce(r, p);
-    dim3 grid(rsp_cdiv(p.M, 128), rsp_cdiv(p.Cout, 64));
+    dim3 grid(rsp_cdiv(p.M - p.tail_row0, 128), rsp_cdiv(p.Cout, 64));
     hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, r);
     rc = rsp_check_launch("splitk_reduce_kernel");
   }
@@ -620,9 +684,15 @@ int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipSt
 }
 
 size_t igemm_partial_bytes(long long M, int Cout, int K) {
-  const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-  const int sk = choose_splitk(rsp_cdiv(M, 128) * rsp_cdiv(Cout, bn), rsp_cdiv(K, BK), M, Cout);
-  return sk > 1 ? (size_t)sk * M * Cout * sizeof(float) : 0;
+#ifdef RSP_TUNE
+  if (getenv("RSP_SPLIT")) return (size_t)16 * M * Cout * sizeof(float);   // room for any forced split
+#endif
+  const int bn = tile_bn(Cout);
+  const int m_tiles = rsp_cdiv(M, 128), n_tiles = rsp_cdiv(Cout, bn);
+  // the gather variant (hence the plan) depends on pointer alignment, unknown here: size for the larger of the two
+  const size_t a = split_partial_bytes(plan_split(m_tiles, n_tiles, bn, true, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
+  const size_t b = split_partial_bytes(plan_split(m_tiles, n_tiles, bn, false, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
+  return a > b ? a : b;
 }
 
 static inline int mod_pos(int a, int m) { return ((a % m) + m) % m; }
