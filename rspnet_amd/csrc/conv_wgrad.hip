@@ -467,21 +467,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
 }
 
 // dw_ref[co][ci][tap] = sum_z partial[z][co][tap*Cin + ci]   (fixed summation order)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int splitm, int Cout,
-                                    int Cin, int taps, int Kld) {
-  const long long total = (long long)Cout * taps * Cin;
+// Block = one output channel x up to 32 input channels: partials are read along k (contiguous ci runs per tap), summed
+// over the slabs with 4 loads in flight, transposed through LDS and written as one contiguous run of dw_ref.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int splitm, int Cout, int Cin, int taps, int Kld) {
+  extern __shared__ float wr_tile[];   // [cit][taps]
+  const int cit = Cin < 32 ? Cin : 32;
+  const int ci0 = blockIdx.x * cit, co = blockIdx.y;
+  const int nci = min(cit, Cin - ci0);
   const long long slab = (long long)Cout * Kld;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int K = taps * Cin;
-    const int co = (int)(i / K);
-    const int k = (int)(i - (long long)co * K);
-    const int tap = k / Cin, ci = k - tap * Cin;
-    const float* src = partial + (long long)co * Kld + k;
-    float s = 0.f;
-    for (int z = 0; z < splitm; ++z) s += src[z * slab];
-    dw[((long long)co * Cin + ci) * taps + tap] = s;
+  const float* base = partial + (long long)co * Kld;
+  for (int e = threadIdx.x; e < nci * taps; e += 256) {
+    const int tap = e / nci, cil = e - tap * nci;
+    const float* src = base + tap * Cin + ci0 + cil;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= splitm; z += 4) {
+      s0 += src[(long long)z * slab];
+      s1 += src[(long long)(z + 1) * slab];
+      s2 += src[(long long)(z + 2) * slab];
+      s3 += src[(long long)(z + 3) * slab];
+    }
+    for (; z < splitm; ++z) s0 += src[(long long)z * slab];
+    wr_tile[cil * taps + tap] = (s0 + s1) + (s2 + s3);
   }
+  __syncthreads();
+  float* out = dw + ((long long)co * Cin + ci0) * taps;
+  for (int e = threadIdx.x; e < nci * taps; e += 256) out[e] = wr_tile[e];
 }
 
 // Column sums of a [rows][C] (pitch ld) matrix, two deterministic stages.
@@ -686,10 +698,10 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   else rc = launch_w_vec<64, 64, 2, 2>(p, va, vb, s);
   if (rc != RSP_OK) return rc;
   {
-    const long long total = (long long)d->Cout * p.K;
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, dw_ref, p.splitm, d->Cout, d->Cin,
-                       d->kT * d->kH * d->kW, p.Kld);
+    const int taps = d->kT * d->kH * d->kW;
+    const int cit = d->Cin < 32 ? d->Cin : 32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rsp_cdiv(d->Cin, cit), d->Cout), dim3(256), (size_t)cit * taps * sizeof(float), s,
+                       p.partial, dw_ref, p.splitm, d->Cout, d->Cin, taps, p.Kld);
     rc = rsp_check_launch("wgrad_reduce_kernel");
     if (rc != RSP_OK) return rc;
   }
