@@ -137,7 +137,7 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
-        # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event) per MFMA launch
+        # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, gemm_n) per MFMA launch
         # group, recorded on the stream the kernels run on (torch's current stream).
         self.event_log = None
 
@@ -148,11 +148,13 @@ class HipOps:
         e.record()
         return e
 
-    def _log(self, kind, flops, e0):
+    def _log(self, kind, flops, e0, ncols=0):
+        # ncols = GEMM N of the launch (Cout forward, Cin dgrad): > 64 runs igemm_kernel<128,128>, else the 64/32-wide tile
+        # or the 4-channel stem kernel
         if e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.event_log.append((kind, flops, e0, e1))
+            self.event_log.append((kind, flops, e0, e1, ncols))
 
     # one grow-only scratch buffer per device; kernels on one stream are serialised so it can be shared
     def _workspace(self, dev, nbytes: int) -> torch.Tensor:
@@ -186,7 +188,7 @@ class HipOps:
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_fwd(dref, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
                                            _ptr(ws), wsb, _stream()), "rsp_conv3d_fwd")
-        self._log("conv_fwd", g.flops, e0)
+        self._log("conv_fwd", g.flops, e0, g.Cout)
         return out, stats
 
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):
@@ -198,7 +200,7 @@ class HipOps:
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_dgrad(dref, _ptr(dy), _ptr(w_ref), _ptr(dx), _ptr(ws), wsb, _stream()),
                    "rsp_conv3d_dgrad")
-        self._log("conv_dgrad", g.flops, e0)
+        self._log("conv_dgrad", g.flops, e0, g.Cin)
         return dx
 
     def conv_wgrad(self, g: ConvGeom, x, dy, dw_out: torch.Tensor, dbias_out: Optional[torch.Tensor] = None):
