@@ -16,9 +16,13 @@ import json
 import logging
 import math
 import os
+import re
 import socket
+import sys
 import time
+from datetime import datetime
 from pathlib import Path
+from shlex import quote
 
 import torch
 import torch.distributed as dist
@@ -154,8 +158,68 @@ def _free_port():
     return port
 
 
+RUN_DIR_NAME_REGEX = re.compile(r"^run_(\d+)_")
+
+
+def resolve_run_dir(args) -> Path:
+    """EXP/run_{id}_{timestamp}: id = 1 + the highest existing run id (framework/arguments.py:64-78)."""
+    if args.run_dir is not None:
+        return Path(args.run_dir)
+    exp = Path(args.experiment_dir)
+    run_id = -1
+    if exp.exists():
+        for prev in exp.iterdir():
+            m = RUN_DIR_NAME_REGEX.match(prev.name)
+            if m is not None:
+                run_id = max(run_id, int(m.group(1)))
+    return exp / f"run_{run_id + 1}_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+
+
+def resolve_continue(args):
+    """--continue: newest run's config.json and EXP/checkpoint.pth.tar (arguments.py:59-86)."""
+    if not args.cont:
+        return
+    exp = Path(args.experiment_dir)
+    if not exp.exists():
+        raise EnvironmentError(f'Experiment directory "{exp}" does not exists.')
+    if args.config is None:
+        best = -1
+        for run in exp.iterdir():
+            m = RUN_DIR_NAME_REGEX.match(run.name)
+            if m is not None and int(m.group(1)) > best and run.is_dir() and (run / "config.json").exists():
+                best = int(m.group(1))
+                args.config = str(run / "config.json")
+        if args.config is None:
+            raise EnvironmentError("No previous run config found")
+        logger.info('Continue using previous config: "%s"', args.config)
+    if args.load_checkpoint is None:
+        ckpt = exp / "checkpoint.pth.tar"
+        if ckpt.exists():
+            args.load_checkpoint = str(ckpt)
+            logger.info('Continue using previous checkpoint: "%s"', ckpt)
+        else:
+            logger.warning("No previous checkpoint found")
+
+
+def save_run_files(args, cfg: dict):
+    """run dir contents: config.json (framework/config.py:78-81), run.sh (framework/arguments.py:49-58), experiment.log."""
+    run_dir = Path(args.run_dir)
+    run_dir.mkdir(parents=True, exist_ok=True)
+    with open(run_dir / "config.json", "w") as f:
+        json.dump(cfg, f, indent=2)
+    with open(run_dir / "run.sh", "w") as f:
+        f.write(f"cd {quote(os.getcwd())}\n")
+        for env in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+            if os.environ.get(env) is not None:
+                f.write(f"export {env}={quote(os.environ[env])}\n")
+        f.write(sys.executable + " " + " ".join(quote(a) for a in sys.argv) + "\n")
+
+
 def main_worker(local_rank: int, args, dist_url: str):
     logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO, format="%(asctime)s %(message)s")
+    if local_rank == 0 and args.run_dir is not None:
+        Path(args.run_dir).mkdir(parents=True, exist_ok=True)
+        logging.getLogger().addHandler(logging.FileHandler(Path(args.run_dir) / "experiment.log"))   # framework/logging.py:31
     torch.manual_seed(args.seed + local_rank)                       # pretrain.py:266-267
     torch.cuda.set_device(local_rank)
     if args.world_size > 1:
@@ -168,8 +232,7 @@ def main_worker(local_rank: int, args, dist_url: str):
     replace_moco_k_in_config(cfg)
     if local_rank == 0:
         Path(args.experiment_dir).mkdir(parents=True, exist_ok=True)
-        with open(Path(args.experiment_dir) / "config.json", "w") as f:
-            json.dump(cfg, f, indent=2)
+        save_run_files(args, cfg)
     engine = Engine(args, cfg, local_rank)
     if args.load_model is not None:
         engine.load_model(args.load_model)
@@ -192,7 +255,7 @@ def _merge(base: dict, over: dict):
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser(description="RSPNet pretext training on MI355X (flag names follow the reference's arguments.py)")
-    ap.add_argument("-c", "--config", required=True, help="resolved config JSON (e.g. rspnet_amd/config/pretrain/c3d.json)")
+    ap.add_argument("-c", "--config", default=None, help="resolved config JSON (e.g. rspnet_amd/config/pretrain/c3d.json)")
     ap.add_argument("-x", "--ext-config", action="append", help="JSON object merged over the config (may repeat)")
     ap.add_argument("-e", "--experiment-dir", required=True)
     ap.add_argument("--load-checkpoint", default=None)
@@ -202,7 +265,13 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-scale-lr", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=100, help="synthetic loader length")
+    ap.add_argument("--run-dir", default=None, help="default: EXP/run_{id}_{timestamp}")
+    ap.add_argument("--continue", dest="cont", action="store_true", help="use the previous run's config and EXP/checkpoint.pth.tar")
     args = ap.parse_args(argv)
+    resolve_continue(args)
+    if args.config is None:
+        ap.error("-c/--config is required (or --continue with a previous run)")
+    args.run_dir = str(resolve_run_dir(args))     # resolved once, before the workers are spawned
     if args.world_size is None:
         args.world_size = torch.cuda.device_count()
     return args

@@ -16,7 +16,8 @@ def _args(tmp_path, **kw):
     p = tmp_path / "cfg.json"
     json.dump(cfg, open(p, "w"))
     a = dict(config=str(p), ext_config=None, experiment_dir=str(tmp_path / "exp"), load_checkpoint=None, load_model=None,
-             debug=False, world_size=1, seed=0, no_scale_lr=False, steps_per_epoch=3)
+             debug=False, world_size=1, seed=0, no_scale_lr=False, steps_per_epoch=3, run_dir=str(tmp_path / "exp" / "run_0_t"),
+             cont=False)
     a.update(kw)
     return types.SimpleNamespace(**a)
 
@@ -27,7 +28,9 @@ def test_pretrain_runs_checkpoints_and_resumes(tmp_path):
     assert stats["loss"] == stats["loss"] and stats["clips_per_s"] > 0
     ck = torch.load(tmp_path / "exp" / "checkpoint.pth.tar", weights_only=False)
     assert set(ck) == {"epoch", "arch", "model", "best_loss", "optimizer", "scheduler"} and ck["epoch"] == 2
-    assert (tmp_path / "exp" / "model_best.pth.tar").exists() and (tmp_path / "exp" / "config.json").exists()
+    assert (tmp_path / "exp" / "model_best.pth.tar").exists()
+    run = tmp_path / "exp" / "run_0_t"                       # run dir layout (framework/arguments.py:60-81)
+    assert {"config.json", "run.sh", "experiment.log"} <= {f.name for f in run.iterdir()}
     assert ck["model"]["queue_ptr"].item() == (2 * 3 * 4) % 64
     assert ck["model"]["encoder_q.encoder.bn1.num_batches_tracked"].item() == 6      # q: +1 per step
     assert ck["model"]["encoder_k.encoder.bn1.num_batches_tracked"].item() == 12     # k: +2 per step (two key passes)

@@ -61,3 +61,21 @@ def test_state_dict_feeds_finetune_and_retrieval_loaders(arch):
     ft = {k[len("encoder_q."):]: v for k, v in sd.items() if k.startswith("encoder_q.")
           and not any(b in k for b in ("fc.", "linear", "head", "new_fc", "fc8", "encoder_fuse"))}
     assert ft and all(k.startswith(("encoder.", "fc1.", "fc2.")) for k in ft)
+
+
+def test_run_dir_numbering_and_continue(tmp_path):
+    """EXP/run_{id}_{timestamp}/config.json + run.sh; --continue picks the newest run's config and EXP/checkpoint.pth.tar
+    (framework/arguments.py:49-81, arguments.py:59-86)."""
+    from rspnet_amd import pretrain
+    exp = tmp_path / "exp"
+    a = pretrain.parse_args(["-c", "rspnet_amd/config/pretrain/c3d.json", "-e", str(exp), "--ws", "1"])
+    assert pretrain.RUN_DIR_NAME_REGEX.match(pretrain.Path(a.run_dir).name).group(1) == "0"
+    pretrain.save_run_files(a, {"arch": "c3d"})
+    assert sorted(f.name for f in pretrain.Path(a.run_dir).iterdir()) == ["config.json", "run.sh"]
+    (exp / "checkpoint.pth.tar").write_bytes(b"")
+    b = pretrain.parse_args(["-e", str(exp), "--continue", "--ws", "1"])
+    assert b.config == str(pretrain.Path(a.run_dir) / "config.json")
+    assert b.load_checkpoint == str(exp / "checkpoint.pth.tar")
+    assert pretrain.RUN_DIR_NAME_REGEX.match(pretrain.Path(b.run_dir).name).group(1) == "1"
+    with pytest.raises(EnvironmentError):
+        pretrain.parse_args(["-e", str(tmp_path / "nope"), "--continue", "--ws", "1"])
