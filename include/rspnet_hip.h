@@ -49,13 +49,15 @@ typedef struct rsp_conv3d_desc {
   int32_t out_ld;  /* same for y */
 } rsp_conv3d_desc;
 
-/* Number of floats of the packed forward weight ([Cout][taps][Cin], K padded to a multiple of 4). */
+/* Number of floats of the packed forward weight.  The layout is private to the library and chosen per descriptor
+ * ([Cout][taps][Cin] with K padded to a multiple of 4 for the implicit-GEMM kernel, [taps][64][4] for the 4-channel stem
+ * kernel); pack and forward must be called with the same descriptor. */
 size_t rsp_conv3d_packed_fwd_elems(const rsp_conv3d_desc* d);
 /* (Cout,Cin,kT,kH,kW) -> forward-packed. */
 int rsp_conv3d_pack_fwd(const rsp_conv3d_desc* d, const float* w_ref, float* w_packed, void* stream);
 
-/* Number of 128-row tiles of the output grid: stat partials are [tiles][Cout][2] (sum, sum of squares of the
- * bias-free conv output) — consumed by rsp_bn_finalize.  */
+/* Number of stat tiles of the output grid (128-row tiles, or 8x16 output patches on the stem path): stat partials are
+ * [tiles][Cout][2] (sum, sum of squares of the bias-free conv output) — consumed by rsp_bn_finalize.  */
 int32_t rsp_conv3d_stat_tiles(const rsp_conv3d_desc* d);
 size_t rsp_conv3d_fwd_workspace(const rsp_conv3d_desc* d);
 /* y = conv(x, w) + bias.  bias and stat_partials may be NULL. */
@@ -199,6 +201,38 @@ int rsp_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, floa
 
 /* rows gather: out[j][:] = in[idx[j]][:]  (feature un-shuffle, :389-406). */
 int rsp_rows_gather(const float* in, const int32_t* idx, int32_t n, int32_t width, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Per-clip GPU augmentation of the pretext data path, fused into one pass:
+ *   ToTensorVideo -> Resize(size, bilinear, align_corners=False) -> RandomGrayScale -> ColorJitter (brightness, contrast,
+ *   saturation, hue in a per-clip random order) -> RandomHorizontalFlipVideo -> NormalizeVideo
+ * (datasets/classification/__init__.py:189-202; transforms_spatial.py:16-25; transforms_tensor.py:12-34,52-143;
+ *  functional_tensor.py:89-162,254-417; applied clip by clip in SequentialGPUCollateFn, transforms_tensor.py:207-233).
+ * The random draws stay on the host (Python's `random`, same order as the reference); each clip is described by one
+ * rsp_augment_clip_desc in DEVICE memory.  src is the uint8 (T,h,w,3) crop produced by RawVideoRandomCrop
+ * (transforms_spatial.py:28-80), addressed through pitches so it may also point into a larger decoded frame.
+ * out: float32 (n_clips, 3, T, size, size) -- the model's NCDHW input -- with `out_clip_stride` floats between clips.
+ * ------------------------------------------------------------------------------------------------------- */
+#define RSP_AUG_BRIGHTNESS 0
+#define RSP_AUG_CONTRAST 1
+#define RSP_AUG_SATURATION 2
+#define RSP_AUG_HUE 3
+typedef struct rsp_augment_clip_desc {
+  const uint8_t* src;
+  int64_t frame_pitch;   /* bytes between frames */
+  int32_t row_pitch;     /* bytes between rows (pixels are 3 packed bytes) */
+  int32_t h, w;          /* region height / width */
+  int32_t gray, flip;    /* RandomGrayScale / RandomHorizontalFlipVideo hit */
+  int32_t n_ops;         /* 0..4 colour ops, applied in this order */
+  int32_t op[4];         /* RSP_AUG_* */
+  float factor[4];       /* (float)ratio, or the hue shift */
+  float one_minus[4];    /* (float)(1.0 - ratio), evaluated in double as Python does (functional_tensor.py:103-106) */
+} rsp_augment_clip_desc;
+size_t rsp_augment_workspace(int32_t n_clips, int32_t T, int32_t size);
+/* mean3 / std3: HOST pointers to 3 floats each (read during the call). */
+int rsp_augment_batch(const rsp_augment_clip_desc* descs, int32_t n_clips, int32_t T, int32_t size, const float* mean3,
+                      const float* std3, float* out, int64_t out_clip_stride, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,13 @@ class PoolDesc(C.Structure):
         "in_ld", "out_ld", "res_ld")]
 
 
+class AugmentClipDesc(C.Structure):
+    """rsp_augment_clip_desc (88 bytes)"""
+    _fields_ = [("src", C.c_void_p), ("frame_pitch", C.c_int64), ("row_pitch", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("gray", C.c_int32), ("flip", C.c_int32), ("n_ops", C.c_int32), ("op", C.c_int32 * 4),
+                ("factor", C.c_float * 4), ("one_minus", C.c_float * 4)]
+
+
 _PD = C.POINTER(ConvDesc)
 _PP = C.POINTER(PoolDesc)
 _sz = C.c_size_t
@@ -87,6 +94,8 @@ SIGNATURES = {
     "rsp_momentum_update": (C.c_int, [_p, _p, _i64, _f, _p]),
     "rsp_sgd_step": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _f, C.c_int, _p]),
     "rsp_rows_gather": (C.c_int, [_p, _p, _i32, _i32, _p, _p]),
+    "rsp_augment_workspace": (_sz, [_i32, _i32, _i32]),
+    "rsp_augment_batch": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _i64, _p, _sz, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -443,6 +443,20 @@ class HipOps:
         _lib.check(self.lib.rsp_rows_gather(_ptr(x), _ptr(idx), n, width, _ptr(out), _stream()), "rsp_rows_gather")
         return out
 
+    # ---- clip augmentation ---------------------------------------------------------------------------
+    def augment_batch(self, descs, n_clips, T, size, mean, std, out):
+        """descs: uint8 device tensor holding n_clips rsp_augment_clip_desc records; out: (n_clips, 3, T, size, size) f32."""
+        _chk(descs, "descs", torch.uint8)
+        _chk(out, "out")
+        assert descs.numel() >= n_clips * C.sizeof(_lib.AugmentClipDesc) and out.is_contiguous()
+        assert out.numel() == n_clips * 3 * T * size * size
+        nbytes = int(self.lib.rsp_augment_workspace(n_clips, T, size))
+        ws = self._workspace(out.device, nbytes)
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        _lib.check(self.lib.rsp_augment_batch(_ptr(descs), n_clips, T, size, m3, s3, _ptr(out), 3 * T * size * size, _ptr(ws),
+                                              ws.numel(), _stream()), "rsp_augment_batch")
+        return out
+
 
 _backend = None
 
