@@ -1,0 +1,153 @@
+"""GPU: BASELINE-size checks (C3D, B=32 clips of 3x16x112x112, K=16384) through size-independent properties — the oracle
+needs ~70 s per step at this size, so instead of a value comparison the kernels are held to identities that any correct
+implementation satisfies at any size:
+
+  * adjointness  <conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)>      (forward / dgrad / wgrad are one bilinear form)
+  * linearity    conv(a x1 + b x2) = a conv(x1) + b conv(x2)
+  * train-mode BN output has per-channel mean 0 / variance 1 (before the affine), running stats move by the batch moments
+  * the step's bookkeeping: momentum update and SGD obey their formulas element-wise, the queue slab holds unit-norm keys,
+    the pointer advances by B, |logits| <= 1/T, and the whole step is run-to-run deterministic.
+"""
+import pytest
+import torch
+
+from rspnet_amd.ops import ConvGeom, PoolGeom
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+B = 32
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rspnet_amd import ops
+    assert ops.backend().name == "hip"
+    return ops.backend()
+
+
+def ddot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+# C3D layers at B=32: (name, T, HW, Cin, Cout); conv1 runs on the 4-channel padded clip (stem kernel)
+LAYERS = [("conv1", 16, 112, 4, 64), ("conv2", 16, 56, 64, 128), ("conv3b", 8, 28, 256, 256), ("conv4b", 4, 14, 512, 512),
+          ("conv5b", 2, 7, 512, 512)]
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=lambda l: l[0])
+def test_conv_adjoint_identities_at_full_size(hip, layer):
+    name, T, HW, cin, cout = layer
+    g = ConvGeom(B, T, HW, HW, cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    gen = torch.Generator(device=DEV).manual_seed(hash(name) % 1000)
+    x = torch.randn(B, T, HW, HW, cin, device=DEV, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=gen) * (27 * cin) ** -0.5
+    dy = torch.randn(B, T, HW, HW, cout, device=DEV, generator=gen)
+    y, _ = hip.conv_fwd(g, x, hip.conv_pack_fwd(g, w), None, False)
+    lhs = ddot(y, dy)
+    scale = (float(y.double().pow(2).sum()) * float(dy.double().pow(2).sum())) ** 0.5     # Cauchy-Schwarz bound of |<y,dy>|
+    dw = torch.empty_like(w)
+    hip.conv_wgrad(g, x, dy, dw)
+    assert abs(ddot(w, dw) - lhs) <= 2e-6 * scale, (name, "wgrad", lhs, ddot(w, dw), scale)
+    if cin > 4:
+        dx = hip.conv_dgrad(g, dy, w)
+        assert abs(ddot(x, dx) - lhs) <= 2e-6 * scale, (name, "dgrad", lhs, ddot(x, dx), scale)
+
+
+def test_conv_linearity_and_stat_partials_at_full_size(hip):
+    T, HW, cin, cout = 16, 56, 64, 128                                    # conv2: the largest GEMM of the step
+    g = ConvGeom(B, T, HW, HW, cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    x1 = torch.randn(B, T, HW, HW, cin, device=DEV, generator=gen)
+    x2 = torch.randn(B, T, HW, HW, cin, device=DEV, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=gen) * (27 * cin) ** -0.5
+    wp = hip.conv_pack_fwd(g, w)
+    y1, st1 = hip.conv_fwd(g, x1, wp, None, True)
+    y2, _ = hip.conv_fwd(g, x2, wp, None, False)
+    y12, _ = hip.conv_fwd(g, 0.5 * x1 - 2.0 * x2, wp, None, False)
+    err = float((y12 - (0.5 * y1 - 2.0 * y2)).abs().max())
+    assert err <= 2e-5 * float(y12.abs().max()), err
+    # the BN partials written by the epilogue are the column sums / sums of squares of y
+    s = st1.double().sum(0)
+    ref = torch.stack([y1.double().sum((0, 1, 2, 3)), y1.double().pow(2).sum((0, 1, 2, 3))], dim=1)
+    assert float((s - ref).abs().max() / ref.abs().max()) <= 1e-6
+
+
+def test_batchnorm_normalises_at_full_size(hip):
+    T, HW, cin, C = 16, 56, 64, 128                                       # conv2 + bn2 of C3D
+    rows = B * T * HW * HW
+    g = ConvGeom(B, T, HW, HW, cin, C, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B, T, HW, HW, cin, device=DEV, generator=gen) + 0.3
+    w = torch.randn(C, cin, 3, 3, 3, device=DEV, generator=gen) * (27 * cin) ** -0.5
+    y, st = hip.conv_fwd(g, x, hip.conv_pack_fwd(g, w), None, True)
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mi, ss = hip.bn_finalize(st, rows, None, gamma, beta, 1e-5, 0.1, rm, rv)
+    out = hip.bn_act_pool_fwd(PoolGeom(B, T, HW, HW, C), y, ss, None, False)
+    m = out.double().mean((0, 1, 2, 3))
+    v = out.double().var((0, 1, 2, 3), unbiased=False)
+    assert float(m.abs().max()) <= 1e-5 and float((v - 1).abs().max()) <= 1e-4
+    bm = y.double().mean((0, 1, 2, 3))
+    bv = y.double().var((0, 1, 2, 3), unbiased=True)
+    assert float((rm.double() - 0.1 * bm).abs().max()) <= 1e-6                      # nn.BatchNorm3d momentum 0.1 (models/c3d.py:22)
+    assert float((rv.double() - (0.9 + 0.1 * bv)).abs().max()) <= 1e-5
+    # ReLU + MaxPool3d(2,2,2) fused behind it: equals pooling the normalised tensor
+    pooled = hip.bn_act_pool_fwd(PoolGeom(B, T, HW, HW, C, (2, 2, 2), (2, 2, 2)), y, ss, None, True)
+    ref = out.clamp_min(0).view(B, T // 2, 2, HW // 2, 2, HW // 2, 2, C).amax((2, 4, 6))
+    assert torch.equal(pooled, ref)
+
+
+def test_full_size_step_bookkeeping_and_determinism():
+    from rspnet_amd.moco import Loss, ModelFactory
+    from rspnet_amd.optim import SGD
+    K, T_, m_, lr, wd = 16384, 0.07, 0.999, 0.05, 1e-4
+    cfg = {"model": {"arch": "c3d"}, "moco": {"dim": 128, "k": K, "m": m_, "t": T_, "fc_type": "linear", "diff_speed": [2]}}
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    im_q = torch.randn(B, 3, 32, 112, 112, device=DEV, generator=gen)
+    im_k = im_q + 0.1 * torch.randn(B, 3, 32, 112, 112, device=DEV, generator=gen)
+
+    def one_step():
+        import random
+        torch.manual_seed(5)
+        random.seed(5)
+        wrapped = ModelFactory(cfg).build_moco_diffloss(device=DEV)
+        model = wrapped.module
+        model.train()
+        params = [p for p in wrapped.parameters() if p.requires_grad]
+        opt = SGD(params, lr=lr, momentum=0.9, dampening=0.0, weight_decay=wd, nesterov=False)
+        q0 = {n: p.detach().clone() for n, p in model.encoder_q.named_parameters()}
+        k0 = {n: p.detach().clone() for n, p in model.encoder_k.named_parameters()}
+        queue0 = model.queue.clone()
+        out, tgt, rl, rt = wrapped(im_q, im_k)
+        loss, la, lm = Loss(margin=2.0, A=1.0, M=1.0)(out, tgt, rl, rt)
+        opt.zero_grad()
+        loss.backward()
+        grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.encoder_q.named_parameters()}
+        opt.step()
+        torch.cuda.synchronize()
+        return model, out, rl, (loss, la, lm), q0, k0, queue0, grads
+
+    model, out, rl, losses, q0, k0, queue0, grads = one_step()
+    assert all(torch.isfinite(v).all() for v in (*out, *rl, *losses))
+    assert out[0].shape == (B, 1 + K) and float(out[0].detach().abs().max()) <= 1 / T_ * (1 + 1e-5)     # unit-norm dot products / T
+    assert float(losses[0]) == pytest.approx(float(losses[1]) + float(losses[2]), rel=1e-6)
+    # momentum update (builder_diffspeed_diffloss.py:337-343) happened BEFORE the optimizer step, on every key parameter
+    for n, p in model.encoder_k.named_parameters():
+        want = k0[n] * m_ + q0[n] * (1 - m_)
+        assert float((p - want).abs().max()) <= 1e-7 * max(1.0, float(want.abs().max())), n
+    # first SGD step with zero momentum buffers: p <- p - lr (g + wd p); parameters without a gradient are untouched
+    for n, p in model.encoder_q.named_parameters():
+        if grads[n] is None:
+            assert torch.equal(p, q0[n]), n
+        else:
+            want = q0[n] - lr * (grads[n] + wd * q0[n])
+            assert float((p - want).abs().max()) <= 2e-7 * max(1.0, float(want.abs().max())), n
+    # queue (:345-359): the first B columns are the new unit-norm keys, the rest is untouched, ptr advanced by B
+    assert int(model.queue_ptr) == B
+    assert float((model.queue[:, :B].norm(dim=0) - 1).abs().max()) <= 1e-5
+    assert torch.equal(model.queue[:, B:], queue0[:, B:])
+    # the whole step is reproducible bit for bit (fixed-order reductions everywhere, no atomics)
+    model2, out2, rl2, losses2, *_ = one_step()
+    assert torch.equal(out[0], out2[0]) and torch.equal(out[1], out2[1]) and torch.equal(losses[0], losses2[0])
+    for (n, p), (_, p2) in zip(model.encoder_q.named_parameters(), model2.encoder_q.named_parameters()):
+        assert torch.equal(p, p2), n
