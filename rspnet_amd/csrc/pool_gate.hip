@@ -74,6 +74,77 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const MPParams p) {
   }
 }
 
+// float4 variants (C % 4 == 0, pitches % 4 == 0, 16-byte aligned bases): one thread owns 4 channels of one position, so the
+// position decode and the window bounds are computed once per 16 bytes and every access is a 16-byte transaction.
+typedef int intx4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  const int C4 = d.C >> 2;
+  const long long total = (long long)d.N * d.Do * d.Ho * d.Wo * C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % C4) * 4;
+    int q = (int)(i / C4);
+    const int ow = q % d.Wo; q /= d.Wo;
+    const int oh = q % d.Ho; q /= d.Ho;
+    const int od = q % d.Do;
+    const int n = q / d.Do;
+    floatx4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    intx4 bi = {-1, -1, -1, -1};
+    const float* xn = p.x + (long long)n * d.Di * d.Hi * d.Wi * d.in_ld + c;
+    for (int kt = 0; kt < d.kT; ++kt) {
+      const int id = od * d.sT - d.pT + kt;
+      if ((unsigned)id >= (unsigned)d.Di) continue;
+      for (int kh = 0; kh < d.kH; ++kh) {
+        const int ih = oh * d.sH - d.pH + kh;
+        if ((unsigned)ih >= (unsigned)d.Hi) continue;
+        for (int kw = 0; kw < d.kW; ++kw) {
+          const int iw = ow * d.sW - d.pW + kw;
+          if ((unsigned)iw >= (unsigned)d.Wi) continue;
+          const int lin = (id * d.Hi + ih) * d.Wi + iw;
+          const floatx4 v = *reinterpret_cast<const floatx4*>(xn + (long long)lin * d.in_ld);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (v[e] > best[e] || bi[e] < 0) { best[e] = v[e]; bi[e] = lin; }   // first maximum in scan order
+        }
+      }
+    }
+    const long long o = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
+    *reinterpret_cast<floatx4*>(p.out + o * d.out_ld + c) = best;
+    if (p.idx) *reinterpret_cast<intx4*>(p.idx + o * d.C + c) = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const MPParams p) {
+  const rsp_pool3d_desc& d = p.d;
+  const int C4 = d.C >> 2;
+  const long long total = (long long)d.N * d.Di * d.Hi * d.Wi * C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % C4) * 4;
+    int q = (int)(i / C4);
+    const int iw = q % d.Wi; q /= d.Wi;
+    const int ih = q % d.Hi; q /= d.Hi;
+    const int id = q % d.Di;
+    const int n = q / d.Di;
+    const int lin = (id * d.Hi + ih) * d.Wi + iw;
+    floatx4 g = {0.f, 0.f, 0.f, 0.f};
+    const int od0 = max(0, (id + d.pT - d.kT + d.sT) / d.sT), od1 = min(d.Do - 1, (id + d.pT) / d.sT);
+    const int oh0 = max(0, (ih + d.pH - d.kH + d.sH) / d.sH), oh1 = min(d.Ho - 1, (ih + d.pH) / d.sH);
+    const int ow0 = max(0, (iw + d.pW - d.kW + d.sW) / d.sW), ow1 = min(d.Wo - 1, (iw + d.pW) / d.sW);
+    for (int od = od0; od <= od1; ++od)
+      for (int oh = oh0; oh <= oh1; ++oh)
+        for (int ow = ow0; ow <= ow1; ++ow) {
+          const long long o = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
+          const intx4 a = *reinterpret_cast<const intx4*>(p.idx + o * d.C + c);
+          const floatx4 v = *reinterpret_cast<const floatx4*>(p.dout + o * d.out_ld + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (a[e] == lin) g[e] += v[e];
+        }
+    *reinterpret_cast<floatx4*>(p.dx + ((long long)n * d.Di * d.Hi * d.Wi + lin) * d.in_ld + c) = g;
+  }
+}
+
 // ---- S3D-G gating ---------------------------------------------------------------------------------------------------
 // sum over a slice of positions per (sample, channel): block = (sample*S + slice, 64-channel group), 4 position lanes.
 // Two deterministic stages so that a (16, 8x112x112, 64) tensor is reduced by thousands of workgroups, not sixteen.
@@ -211,8 +282,14 @@ int rsp_maxpool3d_fwd(const rsp_pool3d_desc* d, const float* x, float* out, int3
   MPParams p;
   memset(&p, 0, sizeof p);
   p.d = *d; p.x = x; p.out = out; p.idx = argmax;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * d->C)), dim3(256), 0,
-                     (hipStream_t)stream, p);
+  const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(x) && rsp_aligned16(out) &&
+                   (!argmax || rsp_aligned16(argmax)) && (long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4) < (1ll << 31);
+  if (vec)
+    hipLaunchKernelGGL(maxpool_fwd_vec_kernel, dim3(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * d->C)), dim3(256), 0,
+                       (hipStream_t)stream, p);
   return rsp_check_launch("maxpool_fwd_kernel");
 }
 
@@ -222,8 +299,14 @@ int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t
   MPParams p;
   memset(&p, 0, sizeof p);
   p.d = *d; p.dout = dout; p.idx = const_cast<int*>(argmax); p.dx = dx;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)d->N * d->Di * d->Hi * d->Wi * d->C)), dim3(256), 0,
-                     (hipStream_t)stream, p);
+  const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(dout) && rsp_aligned16(dx) &&
+                   rsp_aligned16(argmax) && (long long)d->N * d->Di * d->Hi * d->Wi * (d->C / 4) < (1ll << 31);
+  if (vec)
+    hipLaunchKernelGGL(maxpool_bwd_vec_kernel, dim3(grid_for((long long)d->N * d->Di * d->Hi * d->Wi * (d->C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)d->N * d->Di * d->Hi * d->Wi * d->C)), dim3(256), 0,
+                       (hipStream_t)stream, p);
   return rsp_check_launch("maxpool_bwd_kernel");
 }
 
