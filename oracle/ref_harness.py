@@ -216,3 +216,63 @@ def run_reference_step(model, state: Dict[str, np.ndarray], im_q: np.ndarray, im
     res["momentum_post"] = {names[id(p)]: opt.state[p]["momentum_buffer"].numpy().copy()
                             for p in params if "momentum_buffer" in opt.state[p]}
     return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fine-tune model
+# ----------------------------------------------------------------------------------------------------------------------
+def build_reference_finetune(arch: str, num_classes: int):
+    """models/__init__.py:125-133 minus .cuda()/DDP: MultiTaskWrapper(model_class, num_classes, finetune=True)."""
+    _install_shims()
+    from moco.split_wrapper import MultiTaskWrapper
+    from models import get_model_class
+    return MultiTaskWrapper(get_model_class(arch=arch), num_classes=num_classes, finetune=True)
+
+
+def register_margin_hooks(root):
+    """The knife-edge guard of run_reference_step as a reusable pair (handles, margins): smallest |ReLU input| and smallest
+    top-2 gap of disjoint max-pool windows over the small (<= 256 positions) late layers of `root`."""
+    import torch.nn.functional as F
+    margins = []
+
+    def relu_hook(_mod, inp):
+        x = inp[0]
+        if x.dim() == 5 and x.numel() // x.shape[1] <= 256:
+            margins.append(float(x.detach().abs().min()))
+
+    def pool_hook(mod, inp):
+        x = inp[0].detach()
+        ks = mod.kernel_size if isinstance(mod.kernel_size, tuple) else (mod.kernel_size,) * 3
+        st = mod.stride if isinstance(mod.stride, tuple) else (mod.stride,) * 3
+        if x.dim() == 5 and x.numel() // x.shape[1] <= 256 and tuple(ks) == tuple(st):
+            m1, idx = F.max_pool3d(x, mod.kernel_size, mod.stride, mod.padding, return_indices=True)
+            x2 = x.flatten(2).scatter(2, idx.flatten(2), float("-inf")).view_as(x)
+            gap = (m1 - F.max_pool3d(x2, mod.kernel_size, mod.stride, mod.padding))[m1 > 0]
+            if gap.numel():
+                margins.append(float(gap.min()))
+
+    handles = [m.register_forward_pre_hook(relu_hook) for m in root.modules() if isinstance(m, torch.nn.ReLU)]
+    handles += [m.register_forward_pre_hook(pool_hook) for m in root.modules() if isinstance(m, torch.nn.MaxPool3d)]
+    return handles, margins
+
+
+def run_reference_finetune(model, state: Dict[str, np.ndarray], x: np.ndarray, target: np.ndarray):
+    """eval-mode logits from the given state, then one train-mode forward + CrossEntropyLoss + backward from the same state
+    (finetune.py:95-116,326-338).  Returns logits_eval, logits, loss, grads {param name: array or None}, post-forward state."""
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    xt, tt = torch.from_numpy(x), torch.from_numpy(target)
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(xt).numpy().copy()
+    model.train()
+    model.zero_grad()
+    handles, margins = register_margin_hooks(model)
+    logits = model(xt)
+    for h in handles:
+        h.remove()
+    loss = torch.nn.CrossEntropyLoss()(logits, tt)
+    loss.backward()
+    grads = {n: (None if p.grad is None else p.grad.detach().numpy().copy()) for n, p in model.named_parameters()}
+    post = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    post["__margin__"] = np.float64(min(margins) if margins else 1.0)
+    return logits_eval, logits.detach().numpy().copy(), float(loss.detach()), grads, post

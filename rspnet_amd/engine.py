@@ -127,10 +127,23 @@ def _view(t, into, C):
     return t if into is None else t[..., into[1]:into[1] + C]
 
 
-def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool) -> Tuple[torch.Tensor, Optional[ForwardCtx]]:
-    """Execute `plan` on x (N,D,H,W,C).  keep=True records what backward needs.  BN is always in train mode
-    (the pretext step never runs eval-mode BN: pretrain.py:225)."""
+def _eval_scale_shift(bn, bias) -> torch.Tensor:
+    """Eval-mode BatchNorm folded into the (scale, shift) pair the fused BN kernel consumes: y = conv + b,
+    out = (y - running_mean) / sqrt(running_var + eps) * gamma + beta  =  conv * scale + shift."""
+    scale = bn.weight.data * torch.rsqrt(bn.running_var + float(bn.eps))
+    shift = bn.bias.data - bn.running_mean * scale
+    if bias is not None:
+        shift = shift + bias.data * scale
+    return torch.stack([scale, shift]).contiguous()
+
+
+def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, training: bool = True
+                ) -> Tuple[torch.Tensor, Optional[ForwardCtx]]:
+    """Execute `plan` on x (N,D,H,W,C).  keep=True records what backward needs.  training=True: batch-statistics BN (the
+    pretext step never runs anything else: pretrain.py:225); training=False: running-statistics BN for the fine-tune /
+    validation forward (finetune.py:333-345), no backward."""
     be = _ops.backend()
+    assert training or not keep, "eval-mode forward keeps nothing for backward"
     slots: Dict[int, torch.Tensor] = {plan.input_slot: x}
     ctx = ForwardCtx() if keep else None
     for ni, node in enumerate(plan.nodes):
@@ -140,10 +153,14 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool) 
             w = node.conv.weight
             cg = ConvGeom(N, D, H, W, Cin, w.shape[0], node.k, node.s, node.p, Cin_alg=w.shape[1])
             bias = getattr(node.conv, "bias", None)
-            y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), None if bias is None else bias.data, True)
             bn = node.bn
-            mi, ss = be.bn_finalize(stats, cg.rows, None if bias is None else bias.data, bn.weight.data, bn.bias.data,
-                                    float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var)
+            if training:
+                y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), None if bias is None else bias.data, True)
+                mi, ss = be.bn_finalize(stats, cg.rows, None if bias is None else bias.data, bn.weight.data, bn.bias.data,
+                                        float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var)
+            else:
+                y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), None, False)     # bias folded into the shift
+                mi, ss = None, _eval_scale_shift(bn, bias)
             do, ho, wo = cg.out_dims
             pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
             pg = PoolGeom(N, do, ho, wo, cg.Cout, pk, ps, (0, 0, 0))

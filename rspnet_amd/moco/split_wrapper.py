@@ -1,8 +1,13 @@
 """MultiTaskWrapper: backbone + two projection heads (A-VID, RSP), L2-normalised outputs.
 
 Mirror of /root/reference/moco/split_wrapper.py:66-190 for the pretext configuration (finetune=False, groups=1,
-fc_type 'linear').  Heads keep the reference's Sequential(pool, Flatten, Linear) container so the state-dict keys are
-``fc1.2.weight`` etc.; the pool+linear+normalize arithmetic is one HIP kernel (rsp_head_fwd).
+fc_type 'linear' / 'mlp').  Heads keep the reference's Sequential(pool, Flatten, Linear) container so the state-dict keys
+are ``fc1.2.weight`` etc.; the pool+linear+normalize arithmetic is one HIP kernel (rsp_head_fwd).
+
+finetune=True (split_wrapper.py:104-106,131-135, built by models/__init__.py:125-143) is the downstream
+classifier: backbone -> AdaptiveAvgPool3d(1) -> Linear(feat, num_classes).  Its forward is a regular autograd node
+(`_FinetuneFn`) over the module's parameters, so `nn.CrossEntropyLoss`, any torch optimizer and DistributedDataParallel
+work on it exactly as finetune.py uses them; `model.eval()` switches BatchNorm to its running statistics.
 """
 from typing import Callable
 
@@ -22,8 +27,6 @@ class MultiTaskWrapper(nn.Module):
     def __init__(self, base_encoder: Callable[[int], nn.Module], num_classes: int = 128, finetune: bool = False,
                  fc_type: str = "linear", groups: int = 1):
         super().__init__()
-        if finetune:
-            raise NotImplementedError("finetune=True is the downstream path (finetune.py), outside the pretext hot path")
         if groups != 1:
             raise NotImplementedError("groups != 1 is not used by any shipped pretext config")
         if fc_type not in ("linear", "mlp"):
@@ -38,9 +41,13 @@ class MultiTaskWrapper(nn.Module):
 
         self.encoder = base_encoder(num_classes=1)
         feat_dim = self._get_feat_dim(self.encoder)
-        make = self._get_linear_fc if fc_type == "linear" else self._get_mlp_fc
-        self.fc1 = make(feat_dim, self.moco_dim)
-        self.fc2 = make(feat_dim, self.moco_dim)
+        if finetune:
+            self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1))
+            self.fc = nn.Linear(feat_dim, num_classes)
+        else:
+            make = self._get_linear_fc if fc_type == "linear" else self._get_mlp_fc
+            self.fc1 = make(feat_dim, self.moco_dim)
+            self.fc2 = make(feat_dim, self.moco_dim)
 
         self._plan = None
         self._packed = PackedWeights()
@@ -127,17 +134,79 @@ class MultiTaskWrapper(nn.Module):
             after_param_grads(-1)
         run_backward(self.plan(), ctx, dfeat, grad_of, after_param_grads)
 
-    def forward(self, x: Tensor):
-        """Reference signature: x is NCDHW (B,3,T,H,W); returns the two unit-norm embeddings (no autograd here —
-        inside the pretext model gradients flow through MoCoDiffLossTwoFc's own autograd node)."""
+    def _to_ndhwc(self, x: Tensor) -> Tensor:
         be = _ops.backend()
         B = x.shape[0]
         src = torch.arange(B, dtype=torch.int32, device=x.device)
         step = torch.ones(B, dtype=torch.int32, device=x.device)
-        xn = be.clip_gather(x.contiguous(), src, step, x.shape[2], max(x.shape[1], INPUT_CHANNEL_PAD))
+        return be.clip_gather(x.contiguous(), src, step, x.shape[2], max(x.shape[1], INPUT_CHANNEL_PAD))
+
+    def _bump_bn_counters(self):
+        for mod in self.modules():          # train-mode BN bookkeeping (inside the pretext model this is one fused add)
+            if isinstance(mod, nn.modules.batchnorm._BatchNorm):
+                mod.num_batches_tracked += 1
+
+    def forward(self, x: Tensor):
+        """Reference signature: x is NCDHW (B,3,T,H,W).  Pretext wrapper: returns the two unit-norm embeddings (no autograd
+        here — inside the pretext model gradients flow through MoCoDiffLossTwoFc's own autograd node).  finetune=True:
+        returns the (B, num_classes) logits as an autograd node over this module's parameters."""
+        if self.finetune:
+            params = [p for p in self.parameters()]
+            return _FinetuneFn.apply(self, torch.is_grad_enabled(), x, *params)
+        xn = self._to_ndhwc(x)
         with torch.no_grad():
             x1, x2, _ = self.forward_ndhwc(xn, keep=False)
-            for mod in self.modules():      # train-mode BN bookkeeping (inside the pretext model this is one fused add)
-                if isinstance(mod, nn.modules.batchnorm._BatchNorm):
-                    mod.num_batches_tracked += 1
+            self._bump_bn_counters()
         return x1, x2
+
+
+class _FinetuneFn(torch.autograd.Function):
+    """logits = Linear(mean_{T,H,W}(backbone(x)))  (split_wrapper.py:131-135) on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, module: MultiTaskWrapper, grad_on: bool, x: Tensor, *params):
+        be = _ops.backend()
+        training = module.encoder.training                 # BatchNorm mode (only_train_fc keeps the backbone in eval mode)
+        names = [n for n, _ in module.named_parameters()]
+        backbone_grad = grad_on and any(need for n, need in zip(names, ctx.needs_input_grad[3:]) if n.startswith("encoder."))
+        keep = training and backbone_grad
+        ctx.backbone_grad = backbone_grad
+        # weights may have been stepped by any optimizer since the last call: re-pack when their version counters moved
+        ver = sum(p._version for p in params)
+        if ver != getattr(module, "_packed_version", None):
+            module._packed.invalidate()
+            module._packed_version = ver
+        xn = module._to_ndhwc(x)
+        feat, ectx = run_forward(module.plan(), xn, module._packed, keep, training=training)
+        module.feat = feat
+        if training:
+            module._bump_bn_counters()
+        pooled = be.spatial_mean_fwd(feat)
+        logits = be.linear_fwd(pooled, module.fc.weight.data, module.fc.bias.data, False)
+        ctx.module, ctx.ectx, ctx.params = module, ectx, params
+        ctx.head = (pooled, logits)
+        ctx.feat_shape = tuple(feat.shape)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits: Tensor):
+        be = _ops.backend()
+        module, params = ctx.module, ctx.params
+        grads = {}
+
+        def grad_of(p):
+            g = torch.empty_like(p)
+            grads[id(p)] = g
+            return g
+
+        pooled, logits = ctx.head
+        dpooled = be.linear_bwd(pooled, logits, dlogits.contiguous(), module.fc.weight.data, False, grad_of(module.fc.weight),
+                                grad_of(module.fc.bias))
+        if ctx.ectx is None and ctx.backbone_grad:
+            raise RuntimeError("backward through an eval-mode backbone (BatchNorm on running statistics) is not implemented: "
+                               "freeze the backbone (only_train_fc) or call model.train()")
+        if ctx.ectx is not None:                          # `only_train_fc` (models/__init__.py:82-104) stops at the classifier
+            dfeat = be.spatial_mean_bwd(dpooled, ctx.feat_shape)
+            run_backward(module.plan(), ctx.ectx, dfeat, grad_of)
+        ctx.ectx = None
+        return (None, None, None) + tuple(grads.get(id(p)) if p.requires_grad else None for p in params)
