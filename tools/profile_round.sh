@@ -13,3 +13,8 @@ cd $R; ls gpurun_out/prof_$TAG/*/ gpurun_out/pmc_fetch_$TAG/*/ gpurun_out/pmc_wr
 # keep only the small files (the kernel trace of 7 steps is a few MB; counter CSVs can be large)
 find gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG -name "*.csv" -size +30M -delete
 tail -1 gpurun_out/bench_under_rocprof_$TAG.json
+# MFMA utilisation: matrix-pipe busy cycles vs elapsed shader clocks, own pass (SQ + GRBM slots only)
+cd /tmp
+rm -rf $R/gpurun_out/pmc_mfma_$TAG
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $R; find gpurun_out/pmc_mfma_$TAG -name "*.csv" -size +30M -delete; ls gpurun_out/pmc_mfma_$TAG/*/
