@@ -21,15 +21,12 @@ struct Rgb {
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 __device__ __forceinline__ float gray_of(const Rgb& p) { return (0.2989f * p.r + 0.5870f * p.g) + 0.1140f * p.b; }
 
-// torch.remainder(a, 1.0)
-__device__ __forceinline__ float mod1(float a) {
-  float m = fmodf(a, 1.0f);
-  if (m != 0.f && m < 0.f) m += 1.0f;
-  return m;
-}
+// torch.remainder(a, 1.0) = fmod(a, 1) (+1 when negative).  fmod(a, 1) = a - trunc(a) is exact, so both forms round the same real
+// number a - floor(a) exactly once: a - floorf(a) is bit-identical and needs no fmod sequence.
+__device__ __forceinline__ float mod1(float a) { return a - floorf(a); }
 
 // ToTensorVideo + Resize: bilinear sample of output pixel (y, x) of frame t (upsample_bilinear2d, align_corners=False)
-__device__ __forceinline__ Rgb sample(const rsp_augment_clip_desc& d, int t, int y, int x, int S) {
+__device__ __forceinline__ Rgb sample(const rsp_augment_clip_desc& d, const float* __restrict__ lut, int t, int y, int x, int S) {
   const float sh = (float)d.h / (float)S, sw = (float)d.w / (float)S;
   float sy = sh * ((float)y + 0.5f) - 0.5f;
   if (sy < 0.f) sy = 0.f;
@@ -45,8 +42,8 @@ __device__ __forceinline__ Rgb sample(const rsp_augment_clip_desc& d, int t, int
   float v[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float v00 = (float)r0[x0 * 3 + c] / 255.0f, v01 = (float)r0[x1 * 3 + c] / 255.0f;
-    const float v10 = (float)r1[x0 * 3 + c] / 255.0f, v11 = (float)r1[x1 * 3 + c] / 255.0f;
+    const float v00 = lut[r0[x0 * 3 + c]], v01 = lut[r0[x1 * 3 + c]];   // lut[u] = (float)u / 255.0f (ToTensorVideo)
+    const float v10 = lut[r1[x0 * 3 + c]], v11 = lut[r1[x1 * 3 + c]];
     v[c] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
   }
   return Rgb{v[0], v[1], v[2]};
@@ -114,9 +111,12 @@ __device__ __forceinline__ int contrast_index(const rsp_augment_clip_desc& d) {
 __global__ __launch_bounds__(256) void augment_mean_kernel(const rsp_augment_clip_desc* __restrict__ descs, int T, int S,
                                                            float* __restrict__ partial, int nblk) {
   __shared__ float red[4];
+  __shared__ float lut[256];
   const rsp_augment_clip_desc d = descs[blockIdx.y];
   const int ci = contrast_index(d);
   if (ci < 0) return;
+  lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  __syncthreads();
   const int npix = T * S * S;
   float s = 0.f;
 #pragma unroll
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void augment_mean_kernel(const rsp_augment_cli
     if (p < npix) {
       const int x = p % S, q = p / S;
       const int y = q % S, t = q / S;
-      Rgb v = sample(d, t, y, x, S);   // the mean is flip-invariant: no need to mirror here
+      Rgb v = sample(d, lut, t, y, x, S);   // the mean is flip-invariant: no need to mirror here
       if (d.gray) {
         const float g = gray_of(v);
         v = Rgb{g, g, g};
@@ -159,6 +159,9 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const rsp_augment_cl
                                                             const float* __restrict__ mean, float m0, float m1, float m2,
                                                             float s0, float s1, float s2, float* __restrict__ out,
                                                             long long clip_stride) {
+  __shared__ float lut[256];
+  lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  __syncthreads();
   const rsp_augment_clip_desc d = descs[blockIdx.y];
   const int npix = T * S * S;
   const float cm = mean[blockIdx.y];
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const rsp_augment_cl
     if (p < npix) {
       const int x = p % S, q = p / S;
       const int y = q % S, t = q / S;
-      Rgb v = sample(d, t, y, d.flip ? S - 1 - x : x, S);
+      Rgb v = sample(d, lut, t, y, d.flip ? S - 1 - x : x, S);
       if (d.gray) {
         const float g = gray_of(v);
         v = Rgb{g, g, g};
