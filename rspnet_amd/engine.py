@@ -39,6 +39,10 @@ class ConvBN:
     pool: Optional[Tuple[Triple, Triple]] = None   # (kernel, stride), disjoint windows only
     residual: Optional[int] = None                 # slot added before the ReLU
     into: Optional[Tuple[int, int, int]] = None    # (concat slot, channel offset, total channels): write a slice
+    cout_pad: int = 0                              # run with Cout zero-padded to this many channels (0: as is).  R(2+1)D's
+    #   mid-channel counts (83, 230, 921 ...) are not multiples of 4; padded, this conv's output and the next conv's input are
+    #   16-byte rows and both take the LDS-DMA kernels instead of the scalar gather.  Pad channels carry zero weights and
+    #   gamma = beta = 0, so they are exactly 0 after BN+ReLU and contribute nothing downstream; their gradients are dropped.
 
 
 @dataclass
@@ -97,7 +101,7 @@ class PackedWeights:
         key = id(node.conv)
         w = self._cache.get(key)
         if w is None:
-            w = _ops.backend().conv_pack_fwd(cg, pad_in_channels(node.conv.weight.data, cg.Cin))
+            w = _ops.backend().conv_pack_fwd(cg, pad_weight(node.conv.weight.data, cg.Cout, cg.Cin))
             self._cache[key] = w
         return w
 
@@ -109,6 +113,21 @@ def pad_in_channels(w: torch.Tensor, cin: int) -> torch.Tensor:
         return w
     out = torch.zeros((w.shape[0], cin) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
     out[:, :w.shape[1]] = w
+    return out
+
+
+def pad_weight(w: torch.Tensor, cout: int, cin: int) -> torch.Tensor:
+    """(Cout,Cin,k..) weight zero-padded to (cout, cin, k..)."""
+    if w.shape[0] == cout:
+        return pad_in_channels(w, cin)
+    out = torch.zeros((cout, cin) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+    out[:w.shape[0], :w.shape[1]] = w
+    return out
+
+
+def _pad_vec(v: torch.Tensor, n: int, fill: float = 0.0) -> torch.Tensor:
+    out = torch.full((n,), fill, dtype=v.dtype, device=v.device)
+    out[:v.shape[0]] = v
     return out
 
 
@@ -151,16 +170,29 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             xin = slots[node.src]
             N, D, H, W, Cin = xin.shape
             w = node.conv.weight
-            cg = ConvGeom(N, D, H, W, Cin, w.shape[0], node.k, node.s, node.p, Cin_alg=w.shape[1])
+            Cout = w.shape[0]
+            Cp = node.cout_pad if node.cout_pad > Cout else Cout
+            cg = ConvGeom(N, D, H, W, Cin, Cp, node.k, node.s, node.p, Cin_alg=w.shape[1])
             bias = getattr(node.conv, "bias", None)
             bn = node.bn
+            bias_d = None if bias is None else (bias.data if Cp == Cout else _pad_vec(bias.data, Cp))
             if training:
-                y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), None if bias is None else bias.data, True)
-                mi, ss = be.bn_finalize(stats, cg.rows, None if bias is None else bias.data, bn.weight.data, bn.bias.data,
-                                        float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var)
+                y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_d, True)
+                if Cp == Cout:
+                    mi, ss = be.bn_finalize(stats, cg.rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps),
+                                            float(bn.momentum), bn.running_mean, bn.running_var)
+                else:
+                    rm, rv = _pad_vec(bn.running_mean, Cp), _pad_vec(bn.running_var, Cp, 1.0)
+                    mi, ss = be.bn_finalize(stats, cg.rows, bias_d, _pad_vec(bn.weight.data, Cp), _pad_vec(bn.bias.data, Cp),
+                                            float(bn.eps), float(bn.momentum), rm, rv)
+                    bn.running_mean.copy_(rm[:Cout])
+                    bn.running_var.copy_(rv[:Cout])
             else:
                 y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), None, False)     # bias folded into the shift
-                mi, ss = None, _eval_scale_shift(bn, bias)
+                ss = _eval_scale_shift(bn, bias)
+                mi = None
+                if Cp != Cout:
+                    ss = torch.cat([ss, torch.zeros((2, Cp - Cout), dtype=ss.dtype, device=ss.device)], dim=1).contiguous()
             do, ho, wo = cg.out_dims
             pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
             pg = PoolGeom(N, do, ho, wo, cg.Cout, pk, ps, (0, 0, 0))
@@ -221,8 +253,18 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             else:
                 dout = dslots.pop(node.dst)
             bn = node.bn
-            dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
-                                          node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
+            Cout, Cp = node.conv.weight.shape[0], sv.cg.Cout
+            if Cp == Cout:
+                dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
+                                              node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
+            else:
+                dgam = torch.empty(Cp, dtype=torch.float32, device=dout.device)
+                dbet = torch.empty(Cp, dtype=torch.float32, device=dout.device)
+                dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, _pad_vec(bn.weight.data, Cp), sv.mi, sv.ss, node.relu,
+                                              node.residual is not None, dgam, dbet)
+                for g, src in ((grad_of(bn.weight), dgam), (grad_of(bn.bias), dbet)):
+                    if g is not None:
+                        g.copy_(src[:Cout])
             if node.residual is not None:
                 add_grad(node.residual, dres)
             bias = getattr(node.conv, "bias", None)
@@ -233,16 +275,16 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                     # batch mean); the reference's autograd produces ~1e-8 rounding noise there.
                     gb.zero_()
             gw = grad_of(node.conv.weight)
-            if gw is not None and gw.shape[1] != sv.cg.Cin:      # channel-padded stem: drop the pad channel's gradient
-                gpad = torch.empty((gw.shape[0], sv.cg.Cin) + tuple(gw.shape[2:]), dtype=gw.dtype, device=gw.device)
+            if gw is not None and (gw.shape[1] != sv.cg.Cin or gw.shape[0] != Cp):   # channel-padded: drop the pad gradients
+                gpad = torch.empty((Cp, sv.cg.Cin) + tuple(gw.shape[2:]), dtype=gw.dtype, device=gw.device)
                 be.conv_wgrad(sv.cg, sv.x, dy, gpad)
-                gw.copy_(gpad[:, :gw.shape[1]])
+                gw.copy_(gpad[:gw.shape[0], :gw.shape[1]])
             else:
                 be.conv_wgrad(sv.cg, sv.x, dy, gw)
             if after_param_grads is not None:
                 after_param_grads(ni)
             if node.src != plan.input_slot:
-                add_grad(node.src, be.conv_dgrad(sv.cg, dy, pad_in_channels(node.conv.weight.data, sv.cg.Cin)))
+                add_grad(node.src, be.conv_dgrad(sv.cg, dy, pad_weight(node.conv.weight.data, Cp, sv.cg.Cin)))
             del dy, dout, sv
         elif isinstance(node, Pool):
             pg, idx = ctx.saved.pop(ni)

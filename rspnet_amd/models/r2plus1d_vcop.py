@@ -77,7 +77,8 @@ class R2Plus1DNet(nn.Module):
             """factored conv followed by the BN that the caller applies to its output; returns the output slot"""
             (sk, ss, sp), (tk, ts, tp) = conv.geom
             mid, dst = new(), new()
-            nodes.append(ConvBN(conv.spatial_conv, conv.bn, src, mid, sk, ss, sp, relu=True))
+            m = conv.spatial_conv.weight.shape[0]
+            nodes.append(ConvBN(conv.spatial_conv, conv.bn, src, mid, sk, ss, sp, relu=True, cout_pad=(m + 3) // 4 * 4))
             nodes.append(ConvBN(conv.temporal_conv, outer_bn, mid, dst, tk, ts, tp, relu=relu, residual=residual))
             return dst
 
