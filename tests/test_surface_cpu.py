@@ -79,3 +79,14 @@ def test_run_dir_numbering_and_continue(tmp_path):
     assert pretrain.RUN_DIR_NAME_REGEX.match(pretrain.Path(b.run_dir).name).group(1) == "1"
     with pytest.raises(EnvironmentError):
         pretrain.parse_args(["-e", str(tmp_path / "nope"), "--continue", "--ws", "1"])
+
+
+def test_smoke_fixture_exists():
+    """__graft_entry__.smoke() replays the first single-rank C3D fixture of tests/golden/index.json: it must be there."""
+    import os
+    from golden_util import GOLDEN, cases_for
+    from oracle.gen_golden import case_name
+    arch, ws, seed = cases_for("c3d", 1)[0]
+    assert os.path.exists(os.path.join(GOLDEN, case_name(arch, ws, seed) + ".npz"))
+    import __graft_entry__ as entry
+    assert callable(entry.build) and callable(entry.smoke)
