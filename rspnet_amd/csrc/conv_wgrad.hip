@@ -673,7 +673,8 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   const unsigned long long dyb = (unsigned long long)p.M * d->out_ld * 4ull;
   p.x_bytes = (unsigned)xb;
   p.dy_bytes = (unsigned)dyb;
-  bool dma = va && vb && xb < (1ull << 32) && dyb < (1ull << 32) && d->kT <= 8 && d->kH <= 8 && d->kW <= 8;
+  bool dma = va && vb && xb < (1ull << 32) && dyb < (1ull << 32) && d->kT <= 8 && d->kH <= 8 && d->kW <= 8 &&
+             (unsigned long long)p.M * sizeof(uint2) < (1ull << 32);   // row-geometry table addressed with 32-bit offsets
 #ifdef RSP_TUNE
   if (p.tune & 128) dma = false;
 #endif
