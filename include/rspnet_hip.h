@@ -206,7 +206,8 @@ int rsp_rows_gather(const float* in, const int32_t* idx, int32_t n, int32_t widt
  * Per-clip GPU augmentation of the pretext data path, fused into one pass:
  *   ToTensorVideo -> Resize(size, bilinear, align_corners=False) -> RandomGrayScale -> ColorJitter (brightness, contrast,
  *   saturation, hue in a per-clip random order) -> RandomHorizontalFlipVideo -> NormalizeVideo
- * (datasets/classification/__init__.py:189-202; transforms_spatial.py:16-25; transforms_tensor.py:12-34,52-143;
+ * and the `moco.aug_plus` variant  ... -> RandomApply(ColorJitter) -> RandomGrayScale -> RandomApply(GaussianBlur 3x3) -> ...
+ * (datasets/classification/__init__.py:189-218; transforms_spatial.py:16-25; transforms_tensor.py:12-34,52-143;
  *  functional_tensor.py:89-162,254-417; applied clip by clip in SequentialGPUCollateFn, transforms_tensor.py:207-233).
  * The random draws stay on the host (Python's `random`, same order as the reference); each clip is described by one
  * rsp_augment_clip_desc in DEVICE memory.  src is the uint8 (T,h,w,3) crop produced by RawVideoRandomCrop
@@ -222,17 +223,20 @@ typedef struct rsp_augment_clip_desc {
   int64_t frame_pitch;   /* bytes between frames */
   int32_t row_pitch;     /* bytes between rows (pixels are 3 packed bytes) */
   int32_t h, w;          /* region height / width */
-  int32_t gray, flip;    /* RandomGrayScale / RandomHorizontalFlipVideo hit */
+  int32_t gray, flip;    /* gray: 0 no, 1 RandomGrayScale hit BEFORE the colour ops (default chain), 2 AFTER them (aug_plus chain),
+                            +4 GaussianBlur hit (aug_plus: 3x3 zero-padded blur of the intermediate image, before the flip);
+                            flip: RandomHorizontalFlipVideo hit */
   int32_t n_ops;         /* 0..4 colour ops, applied in this order */
   int32_t op[4];         /* RSP_AUG_* */
   float factor[4];       /* (float)ratio, or the hue shift */
   float one_minus[4];    /* (float)(1.0 - ratio), evaluated in double as Python does (functional_tensor.py:103-106) */
 } rsp_augment_clip_desc;
 size_t rsp_augment_workspace(int32_t n_clips, int32_t T, int32_t size);
-/* mean3 / std3: HOST pointers to 3 floats each (read during the call). */
+/* mean3 / std3 / blur9: HOST pointers to 3 / 3 / 9 floats (read during the call); blur9 = row-major 3x3 kernel of
+ * transforms_tensor.py:GaussianBlur (:146-204), may be NULL when no descriptor has the blur bit. */
 int rsp_augment_batch(const rsp_augment_clip_desc* descs, int32_t n_clips, int32_t T, int32_t size, const float* mean3,
-                      const float* std3, float* out, int64_t out_clip_stride, void* workspace, size_t workspace_bytes,
-                      void* stream);
+                      const float* std3, const float* blur9, float* out, int64_t out_clip_stride, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,8 @@ class ClipParams:
     gray: bool = False
     flip: bool = False
     ops: List[Tuple[int, float]] = field(default_factory=list)     # (opcode, factor) in application order
+    gray_after: bool = False      # aug_plus chain: RandomGrayScale sits behind the colour ops
+    blur: bool = False            # aug_plus chain: GaussianBlur((3,3),(1.5,1.5)) hit
 
 
 def draw_params(p_gray=0.2, brightness=0.4, contrast=0.4, saturation=0.4, hue=0.4, p_flip=0.5) -> ClipParams:
@@ -55,6 +57,30 @@ def draw_params(p_gray=0.2, brightness=0.4, contrast=0.4, saturation=0.4, hue=0.
     random.shuffle(ops)
     flip = random.random() < p_flip
     return ClipParams(gray, flip, ops)
+
+
+def draw_params_plus(p_jitter=0.8, p_gray=0.2, p_blur=0.5, p_flip=0.5) -> ClipParams:
+    """The `moco.aug_plus` chain (datasets/classification/__init__.py:203-218): RandomApply([ColorJitter(.4,.4,.4,.1)], 0.8)
+    -> RandomGrayScale(0.2) -> RandomApply([GaussianBlur], 0.5) -> flip.  torchvision's RandomApply skips when
+    ``p < random.random()``."""
+    ops = []
+    if not (p_jitter < random.random()):
+        ops = [(BRIGHTNESS, random.uniform(0.6, 1.4)), (CONTRAST, random.uniform(0.6, 1.4)), (SATURATION, random.uniform(0.6, 1.4)),
+               (HUE, random.uniform(-0.1, 0.1))]
+        random.shuffle(ops)
+    gray = random.random() < p_gray
+    blur = not (p_blur < random.random())
+    flip = random.random() < p_flip
+    return ClipParams(gray, flip, ops, gray_after=True, blur=blur)
+
+
+def gaussian_kernel2d(ksize=(3, 3), sigma=(1.5, 1.5)) -> torch.Tensor:
+    """functional_tensor.py:420-500 (get_gaussian_kernel2d): normalised 1-D windows, outer product."""
+    def win(n, s):
+        g = torch.stack([torch.exp(torch.tensor(-(x - n // 2) ** 2 / float(2 * s ** 2))) for x in range(n)])
+        return g / g.sum()
+    kx, ky = win(ksize[0], sigma[0]), win(ksize[1], sigma[1])
+    return torch.matmul(kx.unsqueeze(-1), ky.unsqueeze(-1).t())
 
 
 def _gray(img: torch.Tensor) -> torch.Tensor:                       # functional_tensor.py:89-100
@@ -96,7 +122,7 @@ def augment_clip(clip_u8: torch.Tensor, size: int, params: ClipParams, mean: Seq
     """clip_u8: (T,h,w,3) uint8, already cropped.  Returns (3,T,size,size) float32."""
     x = clip_u8.float().permute(3, 0, 1, 2) / 255.0                                   # ToTensorVideo
     x = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)   # transforms_spatial.py:21-25
-    if params.gray:
+    if params.gray and not params.gray_after:
         x = _gray(x)
     for op, f in params.ops:
         if op == BRIGHTNESS:
@@ -109,6 +135,11 @@ def augment_clip(clip_u8: torch.Tensor, size: int, params: ClipParams, mean: Seq
             hsv = _rgb_to_hsv(x)                                                       # :376-417
             hsv = torch.cat([((hsv[0] + f) % 1.0).unsqueeze(0), hsv[1:]])
             x = _hsv_to_rgb(hsv)
+    if params.gray and params.gray_after:
+        x = _gray(x)
+    if params.blur:                                                                   # transforms_tensor.py:146-204
+        k = gaussian_kernel2d().repeat(3, 1, 1, 1)
+        x = torch.nn.functional.conv2d(x.transpose(0, 1), k, padding=(1, 1), stride=1, groups=3).transpose(0, 1).contiguous()
     if params.flip:
         x = x.flip(-1)
     m = torch.tensor(mean, dtype=torch.float32)[:, None, None, None]

@@ -98,6 +98,27 @@ def reference_gpu_transform(size):
     ])
 
 
+def reference_gpu_transform_plus(size):
+    """The `aug_plus` branch (datasets/classification/__init__.py:203-218) from the reference's classes."""
+    install_torchvision_stub()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from datasets.transforms_video import transforms_spatial, transforms_tensor
+    from torchvision.transforms import RandomApply
+    return transforms_tensor.Compose([
+        transforms_spatial.ToTensor(),
+        transforms_spatial.Resize(size),
+        RandomApply([transforms_spatial.ColorJitter(0.4, 0.4, 0.4, 0.1)], p=0.8),
+        transforms_spatial.RandomGrayScale(p=0.2),
+        RandomApply([transforms_tensor.GaussianBlur((3, 3), (1.5, 1.5))], p=0.5),
+        transforms_spatial.RandomHorizontalFlip(),
+        transforms_spatial.Normalize(MEAN, STD, inplace=True),
+    ])
+
+
+PLUS_SEEDS = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import augment as A
@@ -116,6 +137,21 @@ def main():
         print(f"seed {seed}: gray={prm.gray} flip={prm.flip} ops={[(o, round(f, 3)) for o, f in prm.ops]} |ref - restatement| = {err:.2e}")
         out[f"out_{seed}"] = ref.numpy().astype(np.float32)
     assert worst <= 2e-6, worst
+    # aug_plus chain on the geometry of the first case
+    _, T, h, w, size = CASES[0]
+    out["plus_seeds"] = np.array(PLUS_SEEDS, dtype=np.int64)
+    for seed in PLUS_SEEDS:
+        clip = A.synthetic_clip(seed, T, h, w)
+        tf = reference_gpu_transform_plus(size)
+        random.seed(seed)
+        ref = tf(clip.clone())
+        random.seed(seed)
+        prm = A.draw_params_plus()
+        mine = A.augment_clip(clip, size, prm, MEAN, STD)
+        err = (ref - mine).abs().max().item()
+        print(f"plus seed {seed}: gray={prm.gray} blur={prm.blur} flip={prm.flip} n_ops={len(prm.ops)} |ref - restatement| = {err:.2e}")
+        assert err <= 2e-6, err
+        out[f"plus_{seed}"] = ref.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "augment.npz"), **out)
     print("wrote tests/golden/augment.npz; worst restatement error", worst)
 

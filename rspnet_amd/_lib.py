@@ -95,7 +95,8 @@ SIGNATURES = {
     "rsp_sgd_step": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _f, C.c_int, _p]),
     "rsp_rows_gather": (C.c_int, [_p, _p, _i32, _i32, _p, _p]),
     "rsp_augment_workspace": (_sz, [_i32, _i32, _i32]),
-    "rsp_augment_batch": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _i64, _p, _sz, _p]),
+    "rsp_augment_batch": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _i64,
+                                    _p, _sz, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -4,7 +4,7 @@ default (`moco.aug_plus = false`) per-clip transform chain
 
     ToTensor -> Resize(size) -> RandomGrayScale(0.2) -> ColorJitter(0.4, 0.4, 0.4, 0.4) -> RandomHorizontalFlip -> Normalize
 
-executed by ONE batched HIP launch group (`rsp_augment_batch`, rspnet_amd/csrc/augment.hip) instead of ~25 small ATen
+(and, with aug_plus=True, the `moco.aug_plus` chain with RandomApply'd jitter and 3x3 Gaussian blur) executed by ONE batched HIP launch group (`rsp_augment_batch`, rspnet_amd/csrc/augment.hip) instead of ~25 small ATen
 launches per clip in a Python loop.  The random decisions are drawn on the host from Python's `random` in exactly the
 reference's order (clip by clip: gray test, the four uniform factors, the shuffle of the op list, flip test), so a seeded run
 reproduces the reference's augmentations.  Same call contract as the reference collate: a list of
@@ -37,10 +37,25 @@ def _jitter_range(value, center=1.0, clip_first_on_zero=True):
     return None if lo == hi == center else (lo, hi)
 
 
+def _gaussian_kernel2d(ksize=(3, 3), sigma=(1.5, 1.5)) -> torch.Tensor:
+    """The 3x3 kernel GaussianBlur registers (transforms_tensor.py:168-176, functional_tensor.py:420-500), in float32."""
+    def win(n, s):
+        g = torch.stack([torch.exp(torch.tensor(-(x - n // 2) ** 2 / float(2 * s ** 2))) for x in range(n)])
+        return g / g.sum()
+    return torch.matmul(win(ksize[0], sigma[0]).unsqueeze(-1), win(ksize[1], sigma[1]).unsqueeze(-1).t())
+
+
 class FusedGPUCollateFn:
     def __init__(self, size: int, mean: Sequence[float], std: Sequence[float], p_gray: float = 0.2, brightness=0.4, contrast=0.4,
-                 saturation=0.4, hue=0.4, p_flip: float = 0.5, target_transform: bool = True,
-                 device: Optional[torch.device] = None):
+                 saturation=0.4, hue=None, p_flip: float = 0.5, target_transform: bool = True,
+                 device: Optional[torch.device] = None, aug_plus: bool = False, p_jitter: float = 0.8, p_blur: float = 0.5):
+        """aug_plus=False: the default chain above.  aug_plus=True (`moco.aug_plus`, datasets/classification/__init__.py:203-218):
+        RandomApply([ColorJitter(.4,.4,.4,.1)], 0.8) -> RandomGrayScale(0.2) -> RandomApply([GaussianBlur((3,3),(1.5,1.5))], 0.5)
+        -> flip -> normalise.  `hue` defaults to the chain's own value (0.4 / 0.1)."""
+        self.aug_plus, self.p_jitter, self.p_blur = bool(aug_plus), p_jitter, p_blur
+        if hue is None:
+            hue = 0.1 if aug_plus else 0.4
+        self.blur9 = _gaussian_kernel2d().reshape(-1).tolist() if aug_plus else None
         self.size = int(size)
         self.mean, self.std = [float(v) for v in mean], [float(v) for v in std]
         self.p_gray, self.p_flip = p_gray, p_flip
@@ -51,9 +66,7 @@ class FusedGPUCollateFn:
         self.target_transform = target_transform
         self.device = device or torch.device("cuda", torch.cuda.current_device())
 
-    def draw(self):
-        """One clip's random decisions, consuming `random` as the reference's Compose does (transforms_tensor.py:29,107-127)."""
-        gray = random.random() < self.p_gray
+    def _draw_jitter(self):
         op_list = []
         if self.brightness is not None:
             op_list.append((BRIGHTNESS, random.uniform(*self.brightness)))
@@ -64,6 +77,21 @@ class FusedGPUCollateFn:
         if self.hue is not None:
             op_list.append((HUE, random.uniform(*self.hue)))
         random.shuffle(op_list)
+        return op_list
+
+    def draw(self):
+        """One clip's random decisions, consuming `random` as the reference's Compose does (transforms_tensor.py:29,107-127;
+        torchvision's RandomApply skips its transforms when ``p < random.random()``).  Returns (gray code, flip, ops):
+        gray code = rsp_augment_clip_desc.gray (1 grayscale before the ops, 2 after, +4 blur)."""
+        if not self.aug_plus:
+            gray = int(random.random() < self.p_gray)
+            op_list = self._draw_jitter()
+            flip = random.random() < self.p_flip
+            return gray, flip, op_list
+        op_list = [] if self.p_jitter < random.random() else self._draw_jitter()
+        gray = 2 if random.random() < self.p_gray else 0
+        if not (self.p_blur < random.random()):
+            gray += 4
         flip = random.random() < self.p_flip
         return gray, flip, op_list
 
@@ -104,7 +132,8 @@ class FusedGPUCollateFn:
         dbytes = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).pin_memory()
         ddev = dbytes.to(self.device, non_blocking=True)
         out = torch.empty((num_clips, B, 3, T, self.size, self.size), dtype=torch.float32, device=self.device)
-        ops.backend().augment_batch(ddev, B * num_clips, T, self.size, self.mean, self.std, out.view(-1, 3, T, self.size, self.size))
+        ops.backend().augment_batch(ddev, B * num_clips, T, self.size, self.mean, self.std, out.view(-1, 3, T, self.size, self.size),
+                                    blur9=self.blur9)
         # `src` / `ddev` die here, but the caching allocator is stream-ordered: their blocks are only re-issued to work queued
         # behind these kernels on the same stream
         return ([out[i] for i in range(num_clips)], label_tensor, *others)

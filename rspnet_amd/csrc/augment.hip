@@ -107,6 +107,26 @@ __device__ __forceinline__ int contrast_index(const rsp_augment_clip_desc& d) {
   return -1;
 }
 
+struct Blur9 {
+  float k[9];
+};
+
+// the per-pixel chain up to (not including) blur / flip / normalise
+__device__ __forceinline__ Rgb pixel(const rsp_augment_clip_desc& d, const float* __restrict__ lut, int t, int y, int x, int S,
+                                     float mean) {
+  Rgb v = sample(d, lut, t, y, x, S);
+  if ((d.gray & 3) == 1) {
+    const float g = gray_of(v);
+    v = Rgb{g, g, g};
+  }
+  v = run_ops(d, v, 0, d.n_ops, mean);
+  if ((d.gray & 3) == 2) {
+    const float g = gray_of(v);
+    v = Rgb{g, g, g};
+  }
+  return v;
+}
+
 // pass 1 (clips with a contrast op): sum of gray(intermediate image just before the contrast op) per block
 __global__ __launch_bounds__(256) void augment_mean_kernel(const rsp_augment_clip_desc* __restrict__ descs, int T, int S,
                                                            float* __restrict__ partial, int nblk) {
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(256) void augment_mean_kernel(const rsp_augment_cli
       const int x = p % S, q = p / S;
       const int y = q % S, t = q / S;
       Rgb v = sample(d, lut, t, y, x, S);   // the mean is flip-invariant: no need to mirror here
-      if (d.gray) {
+      if ((d.gray & 3) == 1) {
         const float g = gray_of(v);
         v = Rgb{g, g, g};
       }
@@ -157,8 +177,8 @@ __global__ __launch_bounds__(256) void augment_mean_final_kernel(const float* __
 // pass 2: the whole pipeline, written as three (T,S,S) planes per clip
 __global__ __launch_bounds__(256) void augment_apply_kernel(const rsp_augment_clip_desc* __restrict__ descs, int T, int S,
                                                             const float* __restrict__ mean, float m0, float m1, float m2,
-                                                            float s0, float s1, float s2, float* __restrict__ out,
-                                                            long long clip_stride) {
+                                                            float s0, float s1, float s2, const Blur9 blur,
+                                                            float* __restrict__ out, long long clip_stride) {
   __shared__ float lut[256];
   lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
   __syncthreads();
@@ -172,12 +192,24 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const rsp_augment_cl
     if (p < npix) {
       const int x = p % S, q = p / S;
       const int y = q % S, t = q / S;
-      Rgb v = sample(d, lut, t, y, d.flip ? S - 1 - x : x, S);
-      if (d.gray) {
-        const float g = gray_of(v);
-        v = Rgb{g, g, g};
+      const int xs = d.flip ? S - 1 - x : x;
+      Rgb v;
+      if (d.gray & 4) {   // GaussianBlur: conv2d(3x3, zero padding) of the intermediate image = the pipeline at the 9 neighbours
+        v = Rgb{0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int yy = y + i - 1, xx = xs + j - 1;
+            if ((unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) {
+              const Rgb n = pixel(d, lut, t, yy, xx, S, cm);
+              const float k = blur.k[i * 3 + j];
+              v = Rgb{v.r + k * n.r, v.g + k * n.g, v.b + k * n.b};
+            }
+          }
+      } else {
+        v = pixel(d, lut, t, y, xs, S, cm);
       }
-      v = run_ops(d, v, 0, d.n_ops, cm);
       o[p] = (v.r - m0) / s0;
       o[(long long)npix + p] = (v.g - m1) / s1;
       o[2ll * npix + p] = (v.b - m2) / s2;
@@ -196,8 +228,8 @@ size_t rsp_augment_workspace(int32_t n_clips, int32_t T, int32_t size) {
 }
 
 int rsp_augment_batch(const rsp_augment_clip_desc* descs, int32_t n_clips, int32_t T, int32_t size, const float* mean3,
-                      const float* std3, float* out, int64_t out_clip_stride, void* workspace, size_t workspace_bytes,
-                      void* stream) {
+                      const float* std3, const float* blur9, float* out, int64_t out_clip_stride, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(descs && mean3 && std3 && out && workspace, "rsp_augment_batch: null pointer");
   RSP_REQUIRE(n_clips > 0 && n_clips <= 65535 && T > 0 && size > 0, "rsp_augment_batch: bad sizes");
   RSP_REQUIRE((long long)T * size * size < (1ll << 30), "rsp_augment_batch: clip too large");
@@ -220,8 +252,10 @@ int rsp_augment_batch(const rsp_augment_clip_desc* descs, int32_t n_clips, int32
   hipLaunchKernelGGL(augment_mean_final_kernel, dim3(n_clips), dim3(256), 0, s, partial, nblk, npix, mean);
   rc = rsp_check_launch("augment_mean_final_kernel");
   if (rc != RSP_OK) return rc;
+  Blur9 blur;
+  for (int i = 0; i < 9; ++i) blur.k[i] = blur9 ? blur9[i] : (i == 4 ? 1.f : 0.f);
   hipLaunchKernelGGL(augment_apply_kernel, dim3(nblk, n_clips), dim3(256), 0, s, descs, T, size, mean, mean3[0], mean3[1],
-                     mean3[2], std3[0], std3[1], std3[2], out, (long long)out_clip_stride);
+                     mean3[2], std3[0], std3[1], std3[2], blur, out, (long long)out_clip_stride);
   return rsp_check_launch("augment_apply_kernel");
 }
 

@@ -444,7 +444,7 @@ class HipOps:
         return out
 
     # ---- clip augmentation ---------------------------------------------------------------------------
-    def augment_batch(self, descs, n_clips, T, size, mean, std, out):
+    def augment_batch(self, descs, n_clips, T, size, mean, std, out, blur9=None):
         """descs: uint8 device tensor holding n_clips rsp_augment_clip_desc records; out: (n_clips, 3, T, size, size) f32."""
         _chk(descs, "descs", torch.uint8)
         _chk(out, "out")
@@ -453,7 +453,8 @@ class HipOps:
         nbytes = int(self.lib.rsp_augment_workspace(n_clips, T, size))
         ws = self._workspace(out.device, nbytes)
         m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
-        _lib.check(self.lib.rsp_augment_batch(_ptr(descs), n_clips, T, size, m3, s3, _ptr(out), 3 * T * size * size, _ptr(ws),
+        b9 = None if blur9 is None else (C.c_float * 9)(*blur9)
+        _lib.check(self.lib.rsp_augment_batch(_ptr(descs), n_clips, T, size, m3, s3, b9, _ptr(out), 3 * T * size * size, _ptr(ws),
                                               ws.numel(), _stream()), "rsp_augment_batch")
         return out
 

@@ -33,6 +33,16 @@ def test_matches_reference_fixture(case):
     assert err <= TOL, err
 
 
+@pytest.mark.parametrize("seed", [int(v) for v in GOLD["plus_seeds"]])
+def test_aug_plus_matches_reference_fixture(seed):
+    _, T, h, w, size = CASES[0]
+    clip = A.synthetic_clip(seed, T, h, w)
+    random.seed(seed)
+    (out,), _ = collate(size, aug_plus=True)([([clip], 0)])
+    err = (out[0].cpu() - torch.from_numpy(GOLD[f"plus_{seed}"])).abs().max().item()
+    assert err <= TOL, err
+
+
 def test_full_size_batch_against_restatement():
     """B=3 samples x 2 clips, T=32, ragged crops -> 112 (the shipped pretext geometry); draws replayed into the oracle."""
     B, T, size = 3, 32, 112
