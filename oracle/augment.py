@@ -1,4 +1,5 @@
-"""CPU restatement of the reference's per-clip GPU augmentation (pretext path, ``moco.aug_plus = false``).
+"""CPU restatement of the reference's per-clip GPU augmentation (pretext path; the default chain and the ``moco.aug_plus``
+chain, datasets/classification/__init__.py:189-218).
 TEST INFRASTRUCTURE ONLY: imported by tests/, never by the product.
 
 Pipeline restated (datasets/classification/__init__.py:189-202, applied per clip by
@@ -19,7 +20,8 @@ RandomHorizontalFlipVideo = ``clip.flip(-1)`` when ``random.random() < p``, Norm
 Pinned: oracle/gen_golden_augment.py runs the reference's own Resize / RandomGrayScale / ColorJitter classes (imported from
 /root/reference with a torchvision stub carrying the three restated classes) under ``random.seed(s)`` and commits inputs'
 seeds + outputs to tests/golden/augment.npz; tests/test_oracle_augment.py checks this file against them and checks that
-``draw_params`` consumes Python's ``random`` exactly as the reference pipeline does.
+``draw_params`` consumes Python's ``random`` exactly as the reference pipeline does; tests/test_oracle_vs_reference.py
+re-runs the reference classes live on other seeds whenever /root/reference is present.
 """
 from __future__ import annotations
 

@@ -1,4 +1,5 @@
 """Generate tests/golden/augment.npz by running the REFERENCE's augmentation classes (build container only).
+TEST INFRASTRUCTURE ONLY.
 
 The reference modules datasets/transforms_video/{functional_tensor,transforms_tensor,transforms_spatial}.py are imported
 from /root/reference.  They import ``torchvision`` (absent here; requirements.txt pins 0.7.0) for Compose / RandomApply and

@@ -1,4 +1,5 @@
 """Generate tests/golden/finetune_<arch>.npz from the REFERENCE's MultiTaskWrapper(finetune=True) (build container only).
+TEST INFRASTRUCTURE ONLY.
 
     python -m oracle.gen_golden_finetune
 

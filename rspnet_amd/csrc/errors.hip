@@ -20,5 +20,5 @@ const char* rsp_strerror(int code) {
     default: return "unknown error";
   }
 }
-int rsp_version(void) { return 100; }
+int rsp_version(void) { return 110; }
 }
