@@ -50,6 +50,7 @@ CONV_CASES = [
     (2, 4, 7, 7, 16, 48, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # S3D-G (1,3,3), Cout=48
     (1, 1, 5, 5, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # tiny: M=25 < one tile
     (1, 4, 130, 128, 32, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # 520 tiles = one whole round of 512 + a K-split tail of 8
+    (1, 4, 70, 80, 32, 320, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # 175 x 3 tiles: whole rounds end mid-way (510), 3 column tiles
     # 4-channel (zero-padded RGB) stems: direct LDS-halo kernel (conv_stem.hip)
     (2, 4, 12, 12, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # C3D conv1: all 3 time-slices resident, 14-tap chunks
     (2, 5, 18, 20, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),        # R3D stem: ring of 3 time-slices, stride 2 de-interleave
