@@ -29,19 +29,31 @@ def ddot(a, b):
     return float((a.double() * b.double()).sum())
 
 
-# C3D layers at B=32: (name, T, HW, Cin, Cout); conv1 runs on the 4-channel padded clip (stem kernel)
-LAYERS = [("conv1", 16, 112, 4, 64), ("conv2", 16, 56, 64, 128), ("conv3b", 8, 28, 256, 256), ("conv4b", 4, 14, 512, 512),
-          ("conv5b", 2, 7, 512, 512)]
+# (name, batch, T, HW, Cin, Cout, k, s, p): C3D layers at B=32 (conv1 runs on the 4-channel padded clip = stem
+# kernel) and the distinct conv shapes of the other backbones (§A.2-A.4): strided / factored / pointwise, stems via both paths
+K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+LAYERS = [
+    ("c3d-conv1", 32, 16, 112, 4, 64, K3, S1, P1), ("c3d-conv2", 32, 16, 56, 64, 128, K3, S1, P1),
+    ("c3d-conv3b", 32, 8, 28, 256, 256, K3, S1, P1), ("c3d-conv4b", 32, 4, 14, 512, 512, K3, S1, P1),
+    ("c3d-conv5b", 32, 2, 7, 512, 512, K3, S1, P1),
+    ("r3d-stem", 32, 16, 112, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),            # 343 taps: implicit-GEMM path
+    ("r3d-layer2-s2", 32, 8, 28, 64, 128, K3, (2, 2, 2), P1),                    # 8 dgrad parity classes
+    ("r3d-downsample", 32, 8, 28, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),     # positions without gradient
+    ("r21d-spatial", 32, 16, 56, 64, 144, (1, 3, 3), S1, (0, 1, 1)),             # factored pair, mid channels padded to x4
+    ("r21d-temporal", 32, 16, 56, 144, 64, (3, 1, 1), S1, (1, 0, 0)),
+    ("s3dg-stem", 16, 16, 224, 4, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),           # 49 taps, stride 2: stem kernel
+    ("s3dg-pointwise", 16, 8, 28, 192, 96, (1, 1, 1), S1, (0, 0, 0)),
+]
 
 
 @pytest.mark.parametrize("layer", LAYERS, ids=lambda l: l[0])
 def test_conv_adjoint_identities_at_full_size(hip, layer):
-    name, T, HW, cin, cout = layer
-    g = ConvGeom(B, T, HW, HW, cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1))
-    gen = torch.Generator(device=DEV).manual_seed(hash(name) % 1000)
-    x = torch.randn(B, T, HW, HW, cin, device=DEV, generator=gen)
-    w = torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=gen) * (27 * cin) ** -0.5
-    dy = torch.randn(B, T, HW, HW, cout, device=DEV, generator=gen)
+    name, Bn, T, HW, cin, cout, k, st, pd = layer
+    g = ConvGeom(Bn, T, HW, HW, cin, cout, k, st, pd)
+    gen = torch.Generator(device=DEV).manual_seed(sum(map(ord, name)))
+    x = torch.randn(Bn, T, HW, HW, cin, device=DEV, generator=gen)
+    w = torch.randn(cout, cin, *k, device=DEV, generator=gen) * (k[0] * k[1] * k[2] * cin) ** -0.5
+    dy = torch.randn(Bn, *g.out_dims, cout, device=DEV, generator=gen)
     y, _ = hip.conv_fwd(g, x, hip.conv_pack_fwd(g, w), None, False)
     lhs = ddot(y, dy)
     scale = (float(y.double().pow(2).sum()) * float(dy.double().pow(2).sum())) ** 0.5     # Cauchy-Schwarz bound of |<y,dy>|
