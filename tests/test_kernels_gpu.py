@@ -94,6 +94,49 @@ def test_conv_fwd_dgrad_wgrad(hip, case):
     close(db, db_ref, 2e-5, "dbias")
 
 
+def _fuzz_cases(n=48, seed=20261002):
+    """Seeded random conv geometries: odd sizes, mixed kernels / strides / paddings, channel counts on every code path
+    (4-channel stems, scalar-gather fallbacks, 32/64/128-wide tiles, kernels smaller than the stride)."""
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < n:
+        k = tuple(rng.choice((1, 1, 3, 3, 5, 7)) for _ in range(3))
+        s = tuple(rng.choice((1, 1, 2)) for _ in range(3))
+        p = tuple(rng.randint(0, kk // 2) for kk in k)
+        D, H, W = rng.randint(1, 6), rng.randint(3, 21), rng.randint(3, 21)
+        if any((i + 2 * pp - kk) < 0 for i, kk, pp in zip((D, H, W), k, p)):
+            continue
+        cin = rng.choice((3, 4, 4, 8, 16, 20, 32, 64, 83))
+        cout = rng.choice((8, 16, 32, 45, 64, 64, 96, 130))
+        if cin * k[0] * k[1] * k[2] > 6000:
+            continue
+        cases.append((rng.randint(1, 3), D, H, W, cin, cout, k, s, p))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "x".join(map(str, c[:6])) + f"k{c[6]}s{c[7]}p{c[8]}")
+def test_conv_fuzz(hip, case):
+    N, D, H, W, Cin, Cout, k, s, p = case
+    g = ConvGeom(N, D, H, W, Cin, Cout, k, s, p)
+    x = rnd(N, D, H, W, Cin, seed=11)
+    w = rnd(Cout, Cin, *k, seed=12, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    b = rnd(Cout, seed=13)
+    y_ref, st_ref = CPU.conv_fwd(g, x, w, b, True)
+    xd, wd = x.to(DEV), w.to(DEV)
+    y, st = hip.conv_fwd(g, xd, hip.conv_pack_fwd(g, wd), b.to(DEV), True)
+    close(y, y_ref, 2e-5, "conv fwd")
+    close(st.double().sum(0), st_ref.double().sum(0), 5e-5, "stat partials")
+    dy = rnd(*y_ref.shape, seed=14)
+    close(hip.conv_dgrad(g, dy.to(DEV), wd), CPU.conv_dgrad(g, dy, w), 2e-5, "dgrad")
+    dw_ref, db_ref = torch.empty_like(w), torch.empty_like(b)
+    CPU.conv_wgrad(g, x, dy, dw_ref, db_ref)
+    dw, db = torch.empty_like(wd), torch.empty(Cout, device=DEV)
+    hip.conv_wgrad(g, xd, dy.to(DEV), dw, db)
+    close(dw, dw_ref, 2e-5, "wgrad")
+    close(db, db_ref, 2e-5, "dbias")
+
+
 def test_conv_is_run_to_run_deterministic(hip):
     g = ConvGeom(1, 2, 7, 7, 256, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1))   # split-K path
     x, w = rnd(1, 2, 7, 7, 256, seed=5).to(DEV), rnd(512, 256, 3, 3, 3, seed=6).to(DEV)
