@@ -192,7 +192,20 @@ POOL_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "x".join(map(str, c[:5])) + f"k{c[5]}r{int(c[7])}{int(c[8])}")
+def _fuzz_bn_pools(n=20, seed=9):
+    """Seeded random fused BN(+residual)(+ReLU)(+disjoint pool) units: ragged sizes (floor-mode tails), odd channel counts."""
+    import random as _r
+    rng = _r.Random(seed)
+    out = []
+    for _ in range(n):
+        k = tuple(rng.choice((1, 1, 2)) for _ in range(3))
+        D, H, W = (rng.randint(kk, 7) for kk in k)
+        out.append((rng.randint(1, 3), D, H, W, rng.choice((8, 32, 64, 83, 96, 260)), k, k, rng.random() < 0.8,
+                    k == (1, 1, 1) and rng.random() < 0.5))
+    return out
+
+
+@pytest.mark.parametrize("case", POOL_CASES + _fuzz_bn_pools(), ids=lambda c: "x".join(map(str, c[:5])) + f"k{c[5]}r{int(c[7])}{int(c[8])}")
 def test_bn_act_pool_fwd_bwd(hip, case):
     N, D, H, W, C, k, s, relu, use_res = case
     pg = PoolGeom(N, D, H, W, C, k, s, (0, 0, 0))
@@ -333,7 +346,23 @@ MAXPOOL_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", MAXPOOL_CASES, ids=lambda c: "x".join(map(str, c[:5])) + f"k{c[5]}s{c[6]}")
+def _fuzz_pools(n=24, seed=7):
+    """Seeded random MaxPool3d geometries (overlapping / padded / disjoint windows; float4 and scalar channel counts)."""
+    import random as _r
+    rng = _r.Random(seed)
+    out = []
+    while len(out) < n:
+        k = tuple(rng.choice((1, 2, 3)) for _ in range(3))
+        s = tuple(rng.choice((1, 2)) for _ in range(3))
+        p = tuple(rng.randint(0, kk // 2) for kk in k)
+        D, H, W = rng.randint(1, 6), rng.randint(2, 13), rng.randint(2, 13)
+        if any((i + 2 * pp - kk) < 0 for i, kk, pp in zip((D, H, W), k, p)):
+            continue
+        out.append((rng.randint(1, 3), D, H, W, rng.choice((4, 16, 48, 64, 83, 130)), k, s, p))
+    return out
+
+
+@pytest.mark.parametrize("case", MAXPOOL_CASES + _fuzz_pools(), ids=lambda c: "x".join(map(str, c[:5])) + f"k{c[5]}s{c[6]}p{c[7]}")
 def test_maxpool_fwd_bwd(hip, case):
     N, D, H, W, C, k, s, p = case
     pg = PoolGeom(N, D, H, W, C, k, s, p)
