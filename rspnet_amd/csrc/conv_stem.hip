@@ -35,7 +35,7 @@ struct StemParams {
   int npix, npix_r;                // pixels per halo frame, rounded up to a multiple of 64
   int FR;                          // frame ring size
   int ntaps, nchunks;
-  int tiles_h, tiles_w;
+  int tiles_h, tiles_w, tiles;
   unsigned x_bytes, w_bytes;
 };
 
@@ -220,6 +220,179 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   }
 }
 
+// Persistent variant for stems whose whole weight tensor and all kernel time-slices of two halos fit in LDS (C3D conv1:
+// 28 KB + 2 x 9 KB; the (1,7,7) stems: 50 KB + 2 x 13 KB).  A workgroup loads the weights and the tap table once and then walks
+// the patches with stride gridDim.x; the halo of the NEXT patch is copied (LDS-DMA) into the other halo buffer while the last
+// tap chunk of the current patch is on the matrix pipe, so a patch costs neither a weight copy nor an exposed copy latency
+// (PMC before: 46 % of the wave time parked on s_waitcnt / s_barrier).
+template <int G>
+__global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams p) {
+  constexpr int TCH = 2 * G;
+  constexpr int BU = TCH * 64;
+  constexpr int BI = (BU + 255) / 256;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int hsz = p.FR * p.npix_r * 4;                                          // floats per halo buffer
+  float* halo = reinterpret_cast<float*>(smem_raw);                            // [2][FR][npix_r][4]
+  float* Bs = halo + 2 * hsz;                                                  // [nchunks][TCH][64][4]
+  int* taptab = reinterpret_cast<int*>(Bs + p.nchunks * BU * 4);               // [nchunks*TCH]
+  long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nchunks * TCH);  // [128]
+  float* red = reinterpret_cast<float*>(rowaddr + 128);                        // [4 waves][64][2]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l32 = lane & 31, h = lane >> 5;
+  const int TW = 1 << p.tw_shift, TH = 128 >> p.tw_shift;
+
+  for (int i = t; i < p.nchunks * TCH; i += 256) {
+    int off = 0;
+    if (i < p.ntaps) {
+      const int kw = i % p.kW, r = i / p.kW;
+      const int kh = r % p.kH, kt = r / p.kH;
+      const int col = p.sW == 2 ? (kw & 1) * p.WTh + (kw >> 1) : kw;
+      off = ((kt * p.npix_r) + kh * p.WTL + col) * 16;      // FR == kT here: slot = kt
+    }
+    taptab[i] = off;
+  }
+  __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  for (int c = 0; c < p.nchunks; ++c) {
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      if (i * 256 + wave * 64 < BU) {
+        const unsigned off = ((unsigned)c * BU + i * 256 + t) * 16u;
+        float* dst = Bs + (c * BU + i * 256 + wave * 64) * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, off, 0, 0, 0);
+      }
+    }
+  }
+  // this thread's (up to 4) halo pixels in patch-relative coordinates: the same for every patch
+  int hyy[4], wxp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + t;
+    hyy[i] = -(1 << 20);   // "no pixel": fails every range check below
+    wxp[i] = 0;
+    if (q < p.npix) {
+      const int r = q / p.WTL, cc = q - r * p.WTL;
+      const int wx_ = p.sW == 2 ? (cc < p.WTh ? 2 * cc : 2 * (cc - p.WTh) + 1) : cc;
+      if (wx_ < p.WT) {
+        hyy[i] = r;
+        wxp[i] = wx_;
+      }
+    }
+  }
+  auto issue_halo = [&](int tile, int buf) {   // every kernel time-slice of patch `tile` -> halo buffer `buf`
+    const int wb = tile % p.tiles_w;
+    int q0 = tile / p.tiles_w;
+    const int hb = q0 % p.tiles_h;
+    q0 /= p.tiles_h;
+    const int to = q0 % p.Do, n = q0 / p.Do;
+    const int hi0 = hb * TH * p.sH - p.pH, wi0 = wb * TW * p.sW - p.pW;
+    unsigned hrel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hi = hi0 + hyy[i], wi = wi0 + wxp[i];
+      hrel[i] = ((unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) ? (unsigned)((hi * p.Wi + wi) * 16) : 0xffffffffu;
+    }
+    for (int f = 0; f < p.kT; ++f) {
+      const int ti = to * p.sT - p.pT + f;
+      const bool okf = (unsigned)ti < (unsigned)p.Di;
+      const unsigned fbase = (unsigned)(((long long)(n * p.Di + (okf ? ti : 0)) * p.Hi * p.Wi) * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i * 256 + wave * 64 < p.npix_r) {
+          const unsigned off = (okf & (hrel[i] != 0xffffffffu)) ? fbase + hrel[i] : 0xffffffffu;
+          float* dst = halo + buf * hsz + (f * p.npix_r + i * 256 + wave * 64) * 4;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // GEMM row of this lane's A operand: m = 32*wave + l32 -> (hy, wx) inside the patch
+  const int m = wave * 32 + l32;
+  const int rowoff = (((m >> p.tw_shift) * p.sH) * p.WTL + (m & (TW - 1))) * 16;
+
+  int cur = 0;
+  if ((int)blockIdx.x < p.tiles) issue_halo(blockIdx.x, 0);
+  for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+    __syncthreads();   // halo[cur] (and, first time, weights + tap table) landed; the previous patch's epilogue is over
+    const int next = tile + gridDim.x;
+    const char* arow = reinterpret_cast<const char*>(halo + cur * hsz) + rowoff;
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int c = 0; c < p.nchunks; ++c) {
+      floatx4 af[G], bf[G][2];
+#pragma unroll
+      for (int g = 0; g < G; ++g) af[g] = *reinterpret_cast<const floatx4*>(arow + taptab[c * TCH + 2 * g + h]);
+      const float* bb = Bs + c * BU * 4 + (h * 64 + l32) * 4;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[g][j] = *reinterpret_cast<const floatx4*>(bb + (2 * g * 64 + 32 * j) * 4);
+      // all LDS reads of the patch are issued: start the next patch's halo under this (last) chunk's MFMAs
+      if (c == p.nchunks - 1 && next < p.tiles) issue_halo(next, cur ^ 1);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][s], bf[g][j][s], acc[j], 0, 0, 0);
+    }
+    // ---- epilogue (as stem_kernel) ----
+    const int wb = tile % p.tiles_w;
+    int q0 = tile / p.tiles_w;
+    const int hb = q0 % p.tiles_h;
+    q0 /= p.tiles_h;
+    const int to = q0 % p.Do, n = q0 / p.Do;
+    if (t < 128) {
+      const int ho = hb * TH + (t >> p.tw_shift), wo = wb * TW + (t & (TW - 1));
+      rowaddr[t] = (ho < p.Ho && wo < p.Wo) ? ((((long long)n * p.Do + to) * p.Ho + ho) * p.Wo + wo) * p.out_ld : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = 32 * j + l32;
+      const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long long addr = rowaddr[wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3)];
+        const float v = addr >= 0 ? acc[j][e] : 0.f;
+        if (addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
+        s += v;
+        ss = fmaf(v, v, ss);
+      }
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (h == 0) {
+        red[(wave * 64 + col) * 2 + 0] = s;
+        red[(wave * 64 + col) * 2 + 1] = ss;
+      }
+    }
+    if (p.stat) {
+      __syncthreads();
+      if (t < 64 && t < p.Cout) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s += red[(w * 64 + t) * 2 + 0];
+          ss += red[(w * 64 + t) * 2 + 1];
+        }
+        float* o = p.stat + ((long long)tile * p.Cout + t) * 2;
+        o[0] = s;
+        o[1] = ss;
+      }
+    }
+    cur ^= 1;
+  }
+}
+
 __global__ void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int kT, int kH, int kW,
                                  int ntaps, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -237,6 +410,7 @@ __global__ void stem_pack_kernel(const float* __restrict__ w, float* __restrict_
 struct StemPlan {
   bool ok;
   int G, TCH, nchunks, tw_shift, HT, WT, WTh, WTL, npix, npix_r, FR, tiles_h, tiles_w;
+  bool resident;      // stem_resident_kernel: weights + two halos fit in LDS
   long long tiles;
   size_t lds;
 };
@@ -290,7 +464,14 @@ StemPlan stem_plan(const rsp_conv3d_desc* d) {
   s.tiles_w = rsp_cdiv(d->Wo, TW);
   s.tiles = (long long)d->N * d->Do * s.tiles_h * s.tiles_w;
   if (s.tiles >= (1ll << 31)) return s;
-  s.lds = (size_t)s.FR * s.npix_r * 16 + (size_t)2 * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 + 128 * 8;
+  const size_t lds_res = (size_t)2 * d->kT * s.npix_r * 16 + (size_t)s.nchunks * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 +
+                         128 * 8 + 2048;
+  s.resident = d->kT <= 3 && lds_res <= 78 * 1024;      // two workgroups per CU at least
+#ifdef RSP_TUNE
+  if (getenv("RSP_STEM_STREAM")) s.resident = false;
+#endif
+  s.lds = s.resident ? lds_res
+                     : (size_t)s.FR * s.npix_r * 16 + (size_t)2 * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 + 128 * 8;
   if (s.lds > 150 * 1024) return s;
   s.ok = true;
   return s;
@@ -303,6 +484,19 @@ int launch_stem(const StemParams& p, const StemPlan& pl, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
     attr_set = true;
+  }
+  if (pl.resident) {
+    static bool attr_set_r = false;
+    if (!attr_set_r) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_resident_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                80 * 1024);
+      attr_set_r = true;
+    }
+    long long per_cu = (160 * 1024) / (long long)pl.lds;
+    per_cu = per_cu > 3 ? 3 : per_cu;                       // <= 170 VGPRs: three waves per SIMD
+    const long long grid = pl.tiles < 256 * per_cu ? pl.tiles : 256 * per_cu;
+    hipLaunchKernelGGL((stem_resident_kernel<G>), dim3((unsigned)grid), dim3(256), pl.lds, s, p);
+    return rsp_check_launch("stem_resident_kernel");
   }
   hipLaunchKernelGGL((stem_kernel<G>), dim3((unsigned)pl.tiles), dim3(256), pl.lds, s, p);
   return rsp_check_launch("stem_kernel");
@@ -344,7 +538,7 @@ int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed
   p.HT = pl.HT; p.WT = pl.WT; p.WTh = pl.WTh; p.WTL = pl.WTL;
   p.npix = pl.npix; p.npix_r = pl.npix_r; p.FR = pl.FR;
   p.ntaps = d->kT * d->kH * d->kW; p.nchunks = pl.nchunks;
-  p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w;
+  p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles = (int)pl.tiles;
   p.x_bytes = (unsigned)((unsigned long long)d->N * d->Di * d->Hi * d->Wi * 16ull);
   p.w_bytes = (unsigned)((size_t)pl.nchunks * pl.TCH * 1024);
   switch (pl.G) {
