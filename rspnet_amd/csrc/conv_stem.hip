@@ -37,6 +37,7 @@ struct StemParams {
   int ntaps, nchunks;
   int tiles_h, tiles_w, tiles;
   unsigned x_bytes, w_bytes;
+  int tune;   // ablation bits, honoured only in -DRSP_TUNE builds
 };
 
 template <int G>
@@ -364,7 +365,11 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
       for (int e = 0; e < 16; ++e) {
         const long long addr = rowaddr[wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3)];
         const float v = addr >= 0 ? acc[j][e] : 0.f;
+#ifdef RSP_TUNE
+        if (addr >= 0 && col < p.Cout && !((p.tune & 1) && v != 12345.f)) p.y[addr + col] = v + bv;
+#else
         if (addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
+#endif
         s += v;
         ss = fmaf(v, v, ss);
       }
@@ -541,6 +546,9 @@ int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles = (int)pl.tiles;
   p.x_bytes = (unsigned)((unsigned long long)d->N * d->Di * d->Hi * d->Wi * 16ull);
   p.w_bytes = (unsigned)((size_t)pl.nchunks * pl.TCH * 1024);
+#ifdef RSP_TUNE
+  { const char* e = getenv("RSP_TUNE"); p.tune = e ? atoi(e) : 0; }
+#endif
   switch (pl.G) {
     case 8: return launch_stem<8>(p, pl, s);
     case 7: return launch_stem<7>(p, pl, s);
