@@ -52,3 +52,18 @@ def test_two_rank_step_matches_golden(arch, seed):
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, arch, seed, _free_port(), tmp), nprocs=2, join=True)
         assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
+
+
+def test_two_ranks_as_threads_device_broadcast_fallback():
+    """Same 2-rank fixture through PyTorch's in-process threaded process group (the harness of tests/test_two_rank_gpu.py) on
+    the checker backend: there is no gloo side group in that world, so this is the branch that sends the shuffle permutation
+    through the default group as RCCL would when the side group cannot be created."""
+    from cpu_ops import CpuOps
+    from rspnet_amd import ops
+    from test_two_rank_gpu import run_two_ranks
+    prev = ops.set_backend(CpuOps())
+    try:
+        arch, _, seed = cases_for("c3d", 2)[0]
+        run_two_ranks(arch, seed, torch.device("cpu"))
+    finally:
+        ops.set_backend(prev)
