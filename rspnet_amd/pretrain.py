@@ -61,6 +61,47 @@ class SyntheticClips:
             yield self.q, self.k
 
 
+class SyntheticVideoClips:
+    """Decode-free stand-in for the reference's video pipeline that still exercises its GPU half: every step yields B samples
+    of two uint8 (T, h, w, 3) crops -- a fixed pool of synthetic "videos", a RawVideoRandomCrop window (scale 0.4..1, aspect
+    3/4..4/3; transforms_spatial.py:43-80) drawn per clip on the CPU as the reference does -- and hands them to
+    rspnet_amd.augment.FusedGPUCollateFn (ToTensor, Resize, grayscale, colour jitter, flip, normalise in one HIP launch group),
+    i.e. the loader returns (clip_q, clip_k) device tensors exactly like DataLoader(collate_fn=SequentialGPUCollateFn(...))."""
+
+    def __init__(self, batch_size, T, size, steps, device, seed=1234, src_hw=(128, 171), mean=(0.485, 0.456, 0.406),
+                 std=(0.229, 0.224, 0.225), aug_plus=False, pool=8):
+        import random as _random
+        from .augment import FusedGPUCollateFn
+        g = torch.Generator().manual_seed(seed)
+        self.videos = [torch.randint(0, 256, (T, src_hw[0], src_hw[1], 3), dtype=torch.uint8, generator=g) for _ in range(pool)]
+        self.collate = FusedGPUCollateFn(size, mean, std, target_transform=False, device=device, aug_plus=aug_plus)
+        self.batch_size, self.steps = batch_size, steps
+        self.rng = _random.Random(seed)
+
+    def _crop(self, clip):
+        H, W = clip.shape[1], clip.shape[2]
+        for _ in range(10):
+            area = self.rng.uniform(0.4, 1.0) * H * W
+            ar = math.exp(self.rng.uniform(math.log(3 / 4), math.log(4 / 3)))
+            w, h = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
+            if 0 < w <= W and 0 < h <= H:
+                i, j = self.rng.randint(0, H - h), self.rng.randint(0, W - w)
+                return clip[:, i:i + h, j:j + w, :].contiguous()
+        return clip
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            batch = []
+            for _b in range(self.batch_size):
+                v = self.videos[self.rng.randrange(len(self.videos))]
+                batch.append(([self._crop(v), self._crop(v)], 0))
+            (clip_q, clip_k), _ = self.collate(batch)
+            yield clip_q, clip_k
+
+
 class Engine:
     def __init__(self, args, cfg: dict, local_rank: int, train_loader=None):
         self.args, self.cfg, self.local_rank = args, cfg, local_rank
@@ -84,9 +125,12 @@ class Engine:
         self.log_interval = int(cfg["log_interval"])
         self.current_epoch = 0
         self.best_loss = math.inf
-        self.train_loader = train_loader or SyntheticClips(
-            self.batch_size, int(cfg["temporal_transforms"]["size"]), int(cfg["spatial_transforms"]["size"]),
-            args.steps_per_epoch, self.device, seed=args.seed + local_rank)
+        T, size = int(cfg["temporal_transforms"]["size"]), int(cfg["spatial_transforms"]["size"])
+        if train_loader is None and getattr(args, "loader", "tensor") == "uint8":
+            train_loader = SyntheticVideoClips(self.batch_size, T, size, args.steps_per_epoch, self.device,
+                                               seed=args.seed + local_rank, aug_plus=bool(cfg.get("moco", {}).get("aug_plus", False)))
+        self.train_loader = train_loader or SyntheticClips(self.batch_size, T, size, args.steps_per_epoch, self.device,
+                                                           seed=args.seed + local_rank)
 
     # ---- checkpoints (pretrain.py:112-132) ---------------------------------------------------------------------------
     def _load_ckpt_file(self, path):
@@ -265,6 +309,8 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-scale-lr", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=100, help="synthetic loader length")
+    ap.add_argument("--loader", choices=("tensor", "uint8"), default="tensor",
+                    help="tensor: fixed N(0,1) device clips; uint8: synthetic uint8 videos -> CPU random crop -> fused GPU augmentation")
     ap.add_argument("--run-dir", default=None, help="default: EXP/run_{id}_{timestamp}")
     ap.add_argument("--continue", dest="cont", action="store_true", help="use the previous run's config and EXP/checkpoint.pth.tar")
     args = ap.parse_args(argv)

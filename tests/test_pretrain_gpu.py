@@ -42,3 +42,10 @@ def test_pretrain_runs_checkpoints_and_resumes(tmp_path):
     torch.save(ck, tmp_path / "bad.pth.tar")
     with pytest.raises(ValueError):
         main_worker(0, _args(tmp_path, load_model=str(tmp_path / "bad.pth.tar")), "")
+
+
+def test_pretrain_with_uint8_loader_and_fused_augmentation(tmp_path):
+    """uint8 clips -> CPU random crop -> FusedGPUCollateFn -> pretext step: the data path of SURVEY.md §8f-2 feeding §8a."""
+    from rspnet_amd.pretrain import main_worker
+    stats = main_worker(0, _args(tmp_path, loader="uint8"), "")
+    assert stats["loss"] == stats["loss"] and 0 < stats["loss"] < 50 and stats["clips_per_s"] > 0
