@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--what", default="fwd,dgrad,wgrad")
 ap.add_argument("--stems", action="store_true", help="the four backbone stems (Cin padded to 4) instead of the C3D stack")
+ap.add_argument("--r3d", action="store_true", help="R3D-18 residual-stage conv shapes")
 ap.add_argument("--no-stem-kernel", action="store_true", help="ablation build only: route stems through the implicit-GEMM kernel")
 args = ap.parse_args()
 if args.tune is not None:
@@ -47,8 +48,12 @@ def timeit(fn):
 
 STEMS = [("c3d-stem", 16, 112, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)), ("r3d-stem", 16, 112, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),
          ("r21d-stem", 16, 112, 4, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)), ("s3dg-stem", 16, 224, 4, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3))]
+R3D = [("r3d-l1", 8, 28, 64, 64), ("r3d-l2", 4, 14, 128, 128), ("r3d-l3", 2, 7, 256, 256), ("r3d-l4", 1, 4, 512, 512),
+       ("r3d-l2s2", 8, 28, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)), ("r3d-l4s2", 2, 7, 256, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1))]
 if args.stems:
     LAYERS = STEMS
+if args.r3d:
+    LAYERS = R3D
 tot = {}
 for L in LAYERS:
     name, T, HW, cin, cout = L[:5]
