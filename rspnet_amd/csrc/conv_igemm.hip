@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
     const int aw = i % p.nTw, q = i / p.nTw;
     const int ah = q % p.nTh, ad = q / p.nTh;
     const int od = p.off0d + ad * p.offstep, oh = p.off0h + ah * p.offstep, ow = p.off0w + aw * p.offstep;
-    taptab[i] = make_int4(od, oh, ow, ((od * p.Hi + oh) * p.Wi + ow) * p.in_ld);
+    // DMA path: .x = the three validity bits this tap needs from a row's bit set (see rbits below); scalar path: the offsets
+    taptab[i] = DMA ? make_int4((1 << ad) | (1 << (8 + ah)) | (1 << (16 + aw)), 0, 0, ((od * p.Hi + oh) * p.Wi + ow) * p.in_ld)
+                    : make_int4(od, oh, ow, ((od * p.Hi + oh) * p.Wi + ow) * p.in_ld);
   }
 
   // ---- per-thread row geometry for the A (im2col) tile ----------------------------------------------------
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   // the hardware return zeros, so padding taps / tail rows / K tail cost one v_cndmask and no zero page or 64-bit math.
   __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
-  unsigned abase32[AR], wrowoff[BR], rowoff[AR];
+  unsigned abase32[AR], wrowoff[BR], rowoff[AR], rbits[AR];
   bool rowok[AR];
   int last_tap = -1;
 #pragma unroll
@@ -178,6 +180,15 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
     abase32[i] = (unsigned)(abase[i] * 4);
     rowoff[i] = 0;
     rowok[i] = false;
+    // per-row validity, one bit per tap index and dimension (bits 0-7: d, 8-15: h, 16-23: w): whether a tap is inside the
+    // input for this row is then two VALU ops when the lane's tap changes, instead of three range checks per row
+    unsigned m = 0;
+    if (DMA) {
+      for (int a = 0; a < p.nTd; ++a) m |= (unsigned)((unsigned)(aid[i] + p.off0d + a * p.offstep) < (unsigned)p.Di) << a;
+      for (int a = 0; a < p.nTh; ++a) m |= (unsigned)((unsigned)(aih[i] + p.off0h + a * p.offstep) < (unsigned)p.Hi) << (8 + a);
+      for (int a = 0; a < p.nTw; ++a) m |= (unsigned)((unsigned)(aiw[i] + p.off0w + a * p.offstep) < (unsigned)p.Wi) << (16 + a);
+    }
+    rbits[i] = m;
   }
 #pragma unroll
   for (int i = 0; i < BR; ++i) wrowoff[i] = (unsigned)(n0 + arow + 32 * i) * (unsigned)p.Kld * 4u;
@@ -213,10 +224,10 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
         last_tap = ctap[0];
         const int4 tt = ctt[0];
         const bool kok = ctap[0] < ntaps;
+        const unsigned need = (unsigned)tt.x;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-          const int id = aid[i] + tt.x, ih = aih[i] + tt.y, iw = aiw[i] + tt.z;
-          rowok[i] = kok && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+          rowok[i] = kok & ((rbits[i] & need) == need);
           rowoff[i] = abase32[i] + (unsigned)tt.w * 4u;
         }
       }
@@ -855,7 +866,8 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   p.x_bytes = (unsigned)xb;
   p.w_bytes = (unsigned)wb;
   // the LDS-DMA path addresses with 32-bit byte offsets; bigger tensors take the (slower) scalar-gather path
-  const bool vec4 = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x) && xb < (1ull << 32) && wb < (1ull << 32);
+  const bool vec4 = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x) && xb < (1ull << 32) && wb < (1ull << 32) &&
+                    d->kT <= 8 && d->kH <= 8 && d->kW <= 8;   // per-dimension validity bits of the DMA path
   return run_igemm(p, vec4, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -951,7 +963,8 @@ int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_r
     const unsigned long long wb = (unsigned long long)pk.O * pk.Kld * 4ull;
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
-    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && xb < (1ull << 32) && wb < (1ull << 32);
+    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && xb < (1ull << 32) && wb < (1ull << 32) &&
+                      g.nt <= 8 && g.nh <= 8 && g.nw <= 8;
     int rc = run_igemm(p, vec4, part, part_bytes, s);
     if (rc != RSP_OK) return rc;
     woff += (size_t)pk.O * pk.Kld;
