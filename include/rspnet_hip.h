@@ -75,6 +75,11 @@ size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d);
 int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Name of the kernel template instance the library launches for this descriptor (which: 0 forward, 1 dgrad, 2 wgrad;
+ * 16-byte aligned tensors assumed) -- lets bench.py label its roofline block with the kernel that actually dominates a
+ * backbone and match it to the rocprofv3 kernel-trace row.  Static string, never NULL. */
+const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which);
+
 /* ---------------------------------------------------------------------------------------------------------
  * BatchNorm3d (train mode) fused with ReLU / residual add / MaxPool3d:
  * models/c3d.py:22-24 (bn+relu+pool), models/resnet.py:61-77, models/s3dg.py:23,28-33, r2plus1d_vcop.py:59-60,116-123.

@@ -871,6 +871,19 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   return run_igemm(p, vec4, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// Name of the kernel template the library dispatches for this descriptor (16-byte aligned tensors assumed), so that a
+// profiler summary row can be matched to a launch without parsing mangled names.  which: 0 forward, 1 dgrad, 2 wgrad.
+const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
+  if (!desc_ok(d)) return "invalid";
+  if (which == 2) return rsp_wgrad_kernel_name(d);
+  if (which == 0 && rsp_stem_applicable(d)) return rsp_stem_kernel_name(d);
+  const int cin = which == 0 ? d->Cin : d->Cout, ld = which == 0 ? d->in_ld : d->out_ld, cols = which == 0 ? d->Cout : d->Cin;
+  const bool vec4 = cin % 4 == 0 && ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 && d->kW <= 8;
+  const int bn = tile_bn(cols);
+  if (vec4) return bn == 128 ? "igemm_kernel<128,128,2,2,4>" : (bn == 64 ? "igemm_kernel<128,64,2,2,4>" : "igemm_kernel<128,32,4,1,4>");
+  return bn == 128 ? "igemm_kernel<128,128,2,2,1>" : (bn == 64 ? "igemm_kernel<128,64,2,2,1>" : "igemm_kernel<128,32,4,1,1>");
+}
+
 // ---- dgrad ----------------------------------------------------------------------------------------------------
 // dx[i] = sum_{k : (i + p - k) % s == 0} dy[(i + p - k)/s] * w[k]; positions are split into s^3 parity classes,
 // each a dense stride-1 "conv" over dy with its own tap subset; class c writes the strided sub-grid i = s*g + r.

@@ -10,3 +10,5 @@ size_t rsp_stem_packed_elems(const rsp_conv3d_desc* d);  // floats in the stem w
 int rsp_stem_pack(const rsp_conv3d_desc* d, const float* w_ref, float* w_packed, hipStream_t s);
 int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
                  float* stat_partials, hipStream_t s);
+const char* rsp_stem_kernel_name(const rsp_conv3d_desc* d);   // template instance rsp_stem_fwd launches
+const char* rsp_wgrad_kernel_name(const rsp_conv3d_desc* d);  // (conv_wgrad.hip) template instance rsp_conv3d_wgrad launches

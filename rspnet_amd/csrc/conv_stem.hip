@@ -513,6 +513,12 @@ bool rsp_stem_applicable(const rsp_conv3d_desc* d) { return stem_plan(d).ok; }
 
 int rsp_stem_tiles(const rsp_conv3d_desc* d) { return (int)stem_plan(d).tiles; }
 
+const char* rsp_stem_kernel_name(const rsp_conv3d_desc* d) {
+  const StemPlan pl = stem_plan(d);
+  if (pl.resident) return pl.G == 8 ? "stem_resident_kernel<8>" : (pl.G == 7 ? "stem_resident_kernel<7>" : "stem_resident_kernel<5>");
+  return pl.G == 8 ? "stem_kernel<8>" : (pl.G == 7 ? "stem_kernel<7>" : "stem_kernel<5>");
+}
+
 size_t rsp_stem_packed_elems(const rsp_conv3d_desc* d) {
   const StemPlan pl = stem_plan(d);
   return (size_t)pl.nchunks * pl.TCH * 256;

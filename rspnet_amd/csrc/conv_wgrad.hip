@@ -9,6 +9,7 @@
 // The row range is split over grid.y; slabs [split][Cout][Kld] are summed in a fixed order by a second kernel
 // that also transposes to the reference layout (Cout,Cin,kT,kH,kW) => bitwise run-to-run reproducible.
 #include "common.h"
+#include "conv_stem.h"
 
 namespace {
 
@@ -621,6 +622,17 @@ WPlan wplan(const rsp_conv3d_desc* d) {
 }
 
 }  // namespace
+
+const char* rsp_wgrad_kernel_name(const rsp_conv3d_desc* d) {
+  if (!wdesc_ok(d)) return "invalid";
+  const WPlan w = wplan(d);
+  const bool dma = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && d->Cin % 4 == 0 && d->in_ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 &&
+                   d->kW <= 8;
+  if (dma) return w.bm == 128 ? (w.bn == 128 ? "wgrad_dma_kernel<128,128>" : "wgrad_dma_kernel<128,64>")
+                              : (w.bn == 128 ? "wgrad_dma_kernel<64,128>" : "wgrad_dma_kernel<64,64>");
+  return w.bm == 128 ? (w.bn == 128 ? "wgrad_kernel<128,128>" : "wgrad_kernel<128,64>")
+                     : (w.bn == 128 ? "wgrad_kernel<64,128>" : "wgrad_kernel<64,64>");
+}
 
 extern "C" {
 

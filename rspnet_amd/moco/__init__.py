@@ -24,7 +24,14 @@ class DataParallelPretext(nn.Module):
     """Stands where the reference wraps the model in DistributedDataParallel (moco/__init__.py:49-53): exposes
     `.module`, forwards calls, and makes rank 0's initial parameters/buffers global (DDP constructor broadcast).
     Gradient averaging happens inside the model's own backward (bucketed RCCL all-reduce over the flat gradient
-    buffer); BN running statistics stay rank-local and rank 0's are what checkpoints see, as in the reference."""
+    buffer).
+
+    Deviation from DDP, stated: torch's DistributedDataParallel (default broadcast_buffers=True) re-broadcasts rank 0's
+    buffers (BN running statistics, num_batches_tracked, queue, queue_ptr) before EVERY forward.  Here the queue / queue_ptr
+    are identical on all ranks by construction (every rank enqueues the same all-gathered keys) and BN running statistics
+    evolve rank-locally between calls of `sync_buffers()` — train-mode numerics never read them and rank 0's checkpoint is
+    the same as under DDP; `sync_buffers()` (called by the pretrain driver at every epoch end) makes the other ranks'
+    copies equal to rank 0's, which is the state DDP leaves them in."""
 
     def __init__(self, module: MoCoDiffLossTwoFc):
         super().__init__()
@@ -37,6 +44,15 @@ class DataParallelPretext(nn.Module):
                 for b in module.buffers():
                     dist.broadcast(b, src=0)
             module._state_loaded()
+            module.setup_side_group()          # collective: every rank constructs the wrapper, as with DDP
+
+    @torch.no_grad()
+    def sync_buffers(self):
+        """Broadcast rank 0's buffers (what DDP's broadcast_buffers does before each forward)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for b in self.module.buffers():
+                dist.broadcast(b, src=0)
+            self.module._ptr_host = None
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

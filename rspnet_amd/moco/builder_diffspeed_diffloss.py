@@ -128,14 +128,26 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._ptr_host: Optional[int] = None
         self._cpu_group = None
         self._last_q = None
+        self._last_k = []
         self._pending = []
+        self._q_version = None
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
 
     # ---- state ----------------------------------------------------------------------------------------------------
     def _state_loaded(self):
         self._ptr_host = None
+        self._q_version = None
         self.encoder_q.weights_changed()
         self.encoder_k.weights_changed()
+
+    def _check_q_weights(self):
+        """Re-pack encoder_q's forward weights when ANY optimizer touched them since the last step.  The fused SGD kernel
+        writes through raw pointers and invalidates the cache itself (optim.py); every torch-side update (torch.optim.SGD,
+        nesterov / dampening fallbacks, manual p.add_) bumps the parameters' autograd version counters instead."""
+        ver = sum(p._version for p in self._q_params)
+        if ver != self._q_version:
+            self._q_version = ver
+            self.encoder_q.weights_changed()
 
     def _prepare(self):
         if self._flat is None:
@@ -143,6 +155,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             self._q_params = list(self.encoder_q.parameters())
         self._flat.ensure()
         self._tie_num_batches_tracked()
+        self._check_q_weights()
 
     def _tie_num_batches_tracked(self):
         """All BN step counters of one encoder share one int64 buffer so a key/query pass bumps them with one add."""
@@ -168,43 +181,74 @@ class MoCoDiffLossTwoFc(nn.Module):
         self.encoder_k.weights_changed()
 
     def _cpu_pg(self):
-        """Host-side side channel for the 2 KB permutation (single node: loopback).  Returns None when a gloo group
-        cannot be created next to the RCCL one; the permutation then travels through the device (one small sync)."""
+        """Host-side side channel for the per-step (speed, permutations) message (single node: loopback).  The gloo group is
+        created collectively by DataParallelPretext.__init__ (setup_side_group) and agreed on by all ranks; None means the
+        message travels through the default (device) group instead, at the price of one small device sync per step."""
         if self._cpu_group is None:
             if dist.get_backend() == "gloo":
                 self._cpu_group = dist.group.WORLD
             else:
-                import os
-                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-                try:
-                    self._cpu_group = dist.new_group(backend="gloo")
-                except Exception:      # noqa: BLE001 - any rendezvous / interface problem: fall back, stay correct
-                    self._cpu_group = False
+                self._cpu_group = False          # no side group was set up (bare model under an RCCL group)
         return self._cpu_group or None
 
-    def _draw_shuffle(self, n: int) -> np.ndarray:
-        """idx_shuffle: drawn on the CPU by every rank, rank 0's wins (:372-378) — exchanged host-side."""
-        idx = torch.randperm(n)
+    def setup_side_group(self):
+        """Collective over the default group: create a gloo group next to it and keep it only if EVERY rank succeeded (a
+        rank-local fallback would have ranks issuing different collectives for the same step: deadlock)."""
+        import logging
+        import os
+        log = logging.getLogger(__name__)
+        backend = dist.get_backend()
+        if backend == "gloo":
+            self._cpu_group = dist.group.WORLD
+            return
+        if backend != "nccl":                 # e.g. the in-process "threaded" group of the tests: no sockets to build on
+            self._cpu_group = False
+            return
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        group, err = None, None
+        try:
+            group = dist.new_group(backend="gloo")
+        except Exception as e:      # noqa: BLE001 - rendezvous / interface problems differ per platform
+            err = e
+        ok = torch.tensor([0 if group is None else 1], dtype=torch.int32, device=self.queue.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            self._cpu_group = group
+            log.info("rspnet_amd: gloo side group created; shuffle permutations travel host-side (no per-step device sync)")
+        else:
+            self._cpu_group = False
+            log.warning("rspnet_amd: gloo side group unavailable on at least one rank (%s); shuffle permutations are broadcast "
+                        "through the device group: one small device sync per step", err)
+
+    def _draw_step_randomness(self, B: int):
+        """This step's (speed, idx_shuffle #1, idx_shuffle #2).  Drawn on every rank in the reference's call order
+        (random.choice :430, torch.randperm :372 twice); rank 0's values win (:375-378 broadcasts idx_shuffle; the speed must be
+        rank-shared as well, or T_real — hence every all-to-all / all-gather shape — would differ across ranks when
+        diff_speed has several entries).  One host-side broadcast carries all three."""
         rank, ws = _world()
+        speed = random.choice(self.diff_speed)
+        sh1, sh2 = torch.randperm(B * ws), torch.randperm(B * ws)
         if ws > 1:
+            msg = torch.cat([torch.tensor([speed], dtype=torch.int64), sh1.to(torch.int64), sh2.to(torch.int64)])
             group = self._cpu_pg()
             if group is not None:
-                dist.broadcast(idx, src=0, group=group)
+                dist.broadcast(msg, src=0, group=group)
             else:
-                dev_idx = idx.to(self.queue.device)
-                dist.broadcast(dev_idx, src=0)
-                idx = dev_idx.cpu()
-        return idx.numpy().astype(np.int64)
+                dev_msg = msg.to(self.queue.device)
+                dist.broadcast(dev_msg, src=0)
+                msg = dev_msg.cpu()
+            speed = int(msg[0])
+            sh1, sh2 = msg[1:1 + B * ws], msg[1 + B * ws:]
+        return speed, sh1.numpy().astype(np.int64), sh2.numpy().astype(np.int64)
 
     @torch.no_grad()
-    def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int):
-        """Key pass with shuffle-BN (:408-419).  Returns (features of my samples in my order (B,2*dim),
-        features of ALL samples in global order (B*ws, 2*dim))."""
+    def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
+        """Key pass with shuffle-BN (:408-419) under the global permutation `idx`.  Returns (features of my samples in my
+        order (B,2*dim), features of ALL samples in global order (B*ws, 2*dim))."""
         be = _ops.backend()
         rank, ws = _world()
         B = im.shape[0]
         dev = im.device
-        idx = self._draw_shuffle(B * ws)
         G = idx.reshape(ws, B)
         owner = G // B
         if ws == 1:
@@ -225,6 +269,9 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._nbt_k += 1
         a, m, _ = self.encoder_k.forward_ndhwc(x, keep=False)
         feats = torch.cat([a, m], dim=1)
+        # introspection only (tests compare with the reference's encoder_k outputs): this rank's key features in arrival
+        # order + the position each arrival has in the reference's shuffled batch G[rank]
+        self._last_k.append((feats, np.argsort(owner[rank], kind="stable") if ws > 1 else np.arange(B)))
         # where does global sample g end up?  rank r = position(g)//B; inside r's batch, clips arrive ordered by
         # source rank, then by their order in G[r]
         loc = np.empty(B * ws, dtype=np.int64)
@@ -293,18 +340,19 @@ class MoCoDiffLossTwoFc(nn.Module):
         dev = im_q.device
         B, C, T, H, W = im_q.shape
         im_q, im_k = im_q.contiguous(), im_k.contiguous()
+        self._last_k = []
         with torch.no_grad():
             self._momentum_update_key_encoder()
             # _diff_speed (:421-447)
             random_indices = torch.randperm(B, device=dev)
             n1 = int(B * self.alpha)
-            speed = random.choice(self.diff_speed)
+            speed, sh1, sh2 = self._draw_step_randomness(B)
             T_real = T // speed
             step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
             step_q[random_indices[:n1].to(dev)] = 1                      # s1 rows play q,k at normal speed
             step_kn = (1 + speed) - step_q if speed != 1 else step_q.clone()   # k_negative swaps the speeds
-            kneg_mine, kneg_all = self._forward_encoder_k(im_k, step_kn, T_real)
-            k_mine, _ = self._forward_encoder_k(im_k, step_q, T_real)
+            kneg_mine, kneg_all = self._forward_encoder_k(im_k, step_kn, T_real, sh1)
+            k_mine, _ = self._forward_encoder_k(im_k, step_q, T_real, sh2)
             dim = kneg_mine.shape[1] // 2
             k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
             kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()

@@ -83,8 +83,9 @@ def _conv_plan(lib_id, g: "ConvGeom", in_ld, out_ld):
     lib = _lib.load()
     d = g.desc(in_ld=in_ld, out_ld=out_ld)
     ref = C.byref(d)
+    names = tuple(lib.rsp_conv3d_kernel_name(ref, which).decode() for which in (0, 1, 2))
     return (d, ref, lib.rsp_conv3d_stat_tiles(ref), lib.rsp_conv3d_fwd_workspace(ref), lib.rsp_conv3d_dgrad_workspace(ref),
-            lib.rsp_conv3d_wgrad_workspace(ref), g.out_dims)
+            lib.rsp_conv3d_wgrad_workspace(ref), g.out_dims, names)
 
 
 @functools.lru_cache(maxsize=4096)
@@ -137,7 +138,7 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
-        # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, gemm_n) per MFMA launch
+        # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name) per MFMA launch
         # group, recorded on the stream the kernels run on (torch's current stream).
         self.event_log = None
 
@@ -148,13 +149,12 @@ class HipOps:
         e.record()
         return e
 
-    def _log(self, kind, flops, e0, ncols=0):
-        # ncols = GEMM N of the launch (Cout forward, Cin dgrad): > 64 runs igemm_kernel<128,128>, else the 64/32-wide tile
-        # or the 4-channel stem kernel
+    def _log(self, kind, flops, e0, kernel=""):
+        # kernel = the template instance the library dispatches for this launch (rsp_conv3d_kernel_name)
         if e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.event_log.append((kind, flops, e0, e1, ncols))
+            self.event_log.append((kind, flops, e0, e1, kernel))
 
     # one grow-only scratch buffer per device; kernels on one stream are serialised so it can be shared
     def _workspace(self, dev, nbytes: int) -> torch.Tensor:
@@ -178,7 +178,7 @@ class HipOps:
     def conv_fwd(self, g: ConvGeom, x, w_packed, bias, want_stats: bool, out: Optional[torch.Tensor] = None,
                  out_ld: Optional[int] = None, in_ld: Optional[int] = None):
         _chk(x, "x")
-        d, dref, tiles, wsb, _, _, (do, ho, wo) = _conv_plan(0, g, in_ld, out_ld)
+        d, dref, tiles, wsb, _, _, (do, ho, wo), names = _conv_plan(0, g, in_ld, out_ld)
         if out is None:
             out = torch.empty((g.N, do, ho, wo, g.Cout), dtype=torch.float32, device=x.device)
         stats = None
@@ -188,19 +188,19 @@ class HipOps:
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_fwd(dref, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
                                            _ptr(ws), wsb, _stream()), "rsp_conv3d_fwd")
-        self._log("conv_fwd", g.flops, e0, g.Cout)
+        self._log("conv_fwd", g.flops, e0, names[0])
         return out, stats
 
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):
         _chk(dy, "dy")
         _chk(w_ref, "w_ref")
-        d, dref, _, _, wsb, _, _ = _conv_plan(0, g, None, None)
+        d, dref, _, _, wsb, _, _, names = _conv_plan(0, g, None, None)
         dx = torch.empty((g.N, g.Di, g.Hi, g.Wi, g.Cin), dtype=torch.float32, device=dy.device)
         ws = self._workspace(dy.device, wsb)
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_dgrad(dref, _ptr(dy), _ptr(w_ref), _ptr(dx), _ptr(ws), wsb, _stream()),
                    "rsp_conv3d_dgrad")
-        self._log("conv_dgrad", g.flops, e0, g.Cin)
+        self._log("conv_dgrad", g.flops, e0, names[1])
         return dx
 
     def conv_wgrad(self, g: ConvGeom, x, dy, dw_out: torch.Tensor, dbias_out: Optional[torch.Tensor] = None):
@@ -208,12 +208,12 @@ class HipOps:
         _chk(x, "x")
         _chk(dy, "dy")
         _chk(dw_out, "dw_out")
-        d, dref, _, _, _, wsb, _ = _conv_plan(0, g, None, None)
+        d, dref, _, _, _, wsb, _, names = _conv_plan(0, g, None, None)
         ws = self._workspace(x.device, wsb)
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_wgrad(dref, _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
                                              _stream()), "rsp_conv3d_wgrad")
-        self._log("conv_wgrad", g.flops, e0)
+        self._log("conv_wgrad", g.flops, e0, names[2])
 
     # ---- batch norm -------------------------------------------------------------------------------------------
     def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,

@@ -62,7 +62,7 @@ class SGD(torch.optim.SGD):
         else:
             relink = False
         for p in trained:
-            off, numel = flat.offsets[[k for k in flat.names if flat._pq[k] is p][0]] if False else p._rsp_flat[1:]
+            off, numel = p._rsp_flat[1:]
             view = mom[off:off + numel].view(p.shape)
             st = self.state[p]
             buf = st.get("momentum_buffer")
@@ -89,3 +89,11 @@ class SGD(torch.optim.SGD):
         finally:
             for p, g in saved:
                 p.grad = g
+        # torch updated (some of) the flat-buffer parameters in place: their packed forward copies are stale
+        seen = set()
+        for group in self.param_groups:
+            for p in group["params"]:
+                info = getattr(p, "_rsp_flat", None)
+                if info is not None and id(info[0]) not in seen:
+                    seen.add(id(info[0]))
+                    info[0].enc_q.weights_changed()

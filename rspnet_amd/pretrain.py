@@ -113,7 +113,9 @@ class Engine:
         if not args.no_scale_lr:
             self.learning_rate = scale_learning_rate(self.learning_rate, args.world_size, self.batch_size)
         o = cfg["optimizer"]
-        self.optimizer = SGD([p for p in self.model.parameters() if p.requires_grad], lr=self.learning_rate,
+        # all parameters, frozen encoder_k included, exactly as pretrain.py:65-72 does: the checkpoint's 'optimizer' entry
+        # (param_groups[0]['params'] indices) is then interchangeable with the reference's
+        self.optimizer = SGD(self.model.parameters(), lr=self.learning_rate,
                              momentum=float(o["momentum"]), dampening=float(o["dampening"]),
                              weight_decay=float(o["weight_decay"]), nesterov=bool(o["nesterov"]))
         self.num_epochs = int(cfg["num_epochs"])          # the jsonnet value is the STRING '200' (moco-train-base.jsonnet:18)
@@ -183,6 +185,7 @@ class Engine:
             stats = self.train_epoch()
             self.scheduler.step()
             self.current_epoch += 1
+            self.model.sync_buffers()
             if self.local_rank == 0:
                 is_best = stats["loss"] < self.best_loss
                 self.best_loss = min(self.best_loss, stats["loss"])
@@ -264,7 +267,12 @@ def main_worker(local_rank: int, args, dist_url: str):
     if local_rank == 0 and args.run_dir is not None:
         Path(args.run_dir).mkdir(parents=True, exist_ok=True)
         logging.getLogger().addHandler(logging.FileHandler(Path(args.run_dir) / "experiment.log"))   # framework/logging.py:31
-    torch.manual_seed(args.seed + local_rank)                       # pretrain.py:266-267
+    import random
+    import numpy as np
+    seed = args.seed + local_rank                                   # utils/reproduction.py initialize_seed (pretrain.py:266-267)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
     torch.cuda.set_device(local_rank)
     if args.world_size > 1:
         dist.init_process_group("nccl", init_method=dist_url, rank=local_rank, world_size=args.world_size,

@@ -73,6 +73,12 @@ def run_model_step(arch, meta, inputs, rank, device, optimizer="fused"):
     q_A, q_M = model._last_q
     res = {"loss": loss, "loss_A": loss_A, "loss_M": loss_M, "logits1": out[0], "logits2": out[1], "l_pos_M": rl[0],
            "l_neg_M": rl[1], "q_A": q_A, "q_M": q_M}
+    # encoder_k outputs of this rank in the reference's shuffled order (pass #1 = k_negative clips, pass #2 = k clips)
+    dim = q_A.shape[1]
+    for tag, (feats, order) in zip(("kneg", "k"), model._last_k):
+        shuf = torch.empty_like(feats)
+        shuf[torch.from_numpy(order).to(feats.device)] = feats
+        res[f"{tag}_A_shuf"], res[f"{tag}_M_shuf"] = shuf[:, :dim], shuf[:, dim:]
     res = {k: v.detach().cpu().numpy() for k, v in res.items()}
     assert tgt.dtype == torch.long and int(tgt.abs().sum()) == 0
     assert rt.dtype == torch.long and int((rt - 1).abs().sum()) == 0

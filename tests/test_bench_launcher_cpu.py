@@ -1,0 +1,54 @@
+"""CPU: `python bench.py --gpus N` starts its own ranks (the driver's entry point for the 1/2/4/8-GPU curve).  The launcher
+path is run end to end without a GPU: the parent spawns 2 child interpreters with a tcp://127.0.0.1 rendezvous, the children
+form a gloo group and run the pretext step on the tests' checker backend at a tiny size (--selftest-cpu), rank 0 prints
+the single contract line.  What this pins: argument forwarding, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* plumbing, the MAX-over-ranks
+timing + single JSON line, and a non-zero exit when a rank fails (reference: pretrain.py:278-283,335-336)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+TINY = ["--selftest-cpu", "--arch", "c3d", "--batch", "2", "--hw", "16", "--queue", "64", "--steps", "2", "--warmup", "1"]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    return env
+
+
+def test_bench_self_launches_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + TINY, capture_output=True, text=True, timeout=600, cwd=ROOT, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "selftest-cpu"
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
+    assert "cpu_baseline" not in d                     # rank 0 at N=1 only
+
+
+def test_bench_under_external_launcher_env():
+    """WORLD_SIZE already set (python -m torch.distributed.run ...): the process is a rank, no second level of spawning."""
+    env = _env()
+    env.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1"] + TINY, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1"
+
+
+def test_bench_launcher_reports_rank_failure():
+    bad = [a if a != "16" else "1" for a in TINY]      # 1-pixel clips: every rank fails inside the model
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + bad, capture_output=True, text=True, timeout=600, cwd=ROOT, env=_env())
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_gpus_mismatch_is_an_error():
+    env = _env()
+    env.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + TINY, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -44,7 +44,7 @@ def _run_rank(rank, ws, arch, seed, lock, tls, out, dev):
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
         model.train()
         params = [p for p in wrapped.parameters() if p.requires_grad]
-        opt = SGD(params, lr=meta["lr"], momentum=meta["sgd_momentum"], dampening=0.0, weight_decay=meta["weight_decay"],
+        opt = SGD(wrapped.parameters(), lr=meta["lr"], momentum=meta["sgd_momentum"], dampening=0.0, weight_decay=meta["weight_decay"],
                   nesterov=False)
         names = {id(p): n for n, p in model.named_parameters()}
         for p in params:
@@ -62,6 +62,11 @@ def _run_rank(rank, ws, arch, seed, lock, tls, out, dev):
         q_A, q_M = model._last_q
         res = {"loss": loss, "loss_A": loss_A, "loss_M": loss_M, "logits1": o[0], "logits2": o[1], "l_pos_M": rl[0],
                "l_neg_M": rl[1], "q_A": q_A, "q_M": q_M}
+        dim = q_A.shape[1]
+        for tag, (feats, order) in zip(("kneg", "k"), model._last_k):      # this rank's encoder_k outputs, reference order
+            shuf = torch.empty_like(feats)
+            shuf[torch.from_numpy(order).to(feats.device)] = feats
+            res[f"{tag}_A_shuf"], res[f"{tag}_M_shuf"] = shuf[:, :dim], shuf[:, dim:]
         res = {k: v.detach().cpu().numpy() for k, v in res.items()}
         post = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         mom_post = {names[id(p)]: opt.state[p]["momentum_buffer"].detach().cpu().numpy() for p in params
@@ -84,7 +89,7 @@ def _run_rank(rank, ws, arch, seed, lock, tls, out, dev):
             pass
 
 
-@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "resnet18") for a, w, s in cases_for(arch, 2)][:3])
+@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "resnet18", "r2plus1d-vcop", "s3dg") for a, w, s in cases_for(arch, 2)])
 def test_two_ranks_on_one_gpu_match_the_ddp_fixture(arch, seed):
     from rspnet_amd import ops
     assert ops.backend().name == "hip"
