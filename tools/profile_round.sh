@@ -1,20 +1,26 @@
 #!/bin/bash
-# usage (on the GPU box): tools/profile_round.sh <tag>      e.g. r1c
-# Three separate rocprofv3 passes over the default bench (C3D 16x112x112, B=32): kernel trace + stats, then FETCH_SIZE and
-# WRITE_SIZE counters each in their own run (MI355X_MICROARCH.md: one --pmc pass per counter group, never with sys traces).
-# Raw outputs land in gpurun_out/; tools/summarize_profiles.py <round> <tag> turns them into profiles/<round>/.
-R=$GRAFT_REPO_ROOT; TAG=$1
+# Run ON THE GPU BOX (through gpurun): for every BASELINE backbone a bench line, a rocprofv3 kernel-trace/stats pass and the
+# three PMC passes (FETCH_SIZE / WRITE_SIZE / matrix-pipe busy), each in its own run with the program directly after `--`.
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r2a [archs...]'
+# Raw outputs land under gpurun_out/; tools/summarize_profiles.py <round> <tag> turns them into profiles/<round>/.
+set -u
+TAG="$1"; shift
+ARCHS=("$@"); [ ${#ARCHS[@]} -eq 0 ] && ARCHS=(c3d resnet18 r2plus1d-vcop s3dg)
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+OUT="$R/gpurun_out"
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_$TAG $R/gpurun_out/pmc_fetch_$TAG $R/gpurun_out/pmc_write_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/bench_under_rocprof_$TAG.json 2>/dev/null
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-cd $R; ls gpurun_out/prof_$TAG/*/ gpurun_out/pmc_fetch_$TAG/*/ gpurun_out/pmc_write_$TAG/*/ | head -20
-# keep only the small files (the kernel trace of 7 steps is a few MB; counter CSVs can be large)
-find gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG -name "*.csv" -size +30M -delete
-tail -1 gpurun_out/bench_under_rocprof_$TAG.json
-# MFMA utilisation: matrix-pipe busy cycles vs elapsed shader clocks, own pass (SQ + GRBM slots only)
-cd /tmp
-rm -rf $R/gpurun_out/pmc_mfma_$TAG
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-cd $R; find gpurun_out/pmc_mfma_$TAG -name "*.csv" -size +30M -delete; ls gpurun_out/pmc_mfma_$TAG/*/
+for a in "${ARCHS[@]}"; do
+  python3 "$R/bench.py" --arch "$a" --no-cpu-baseline > "$OUT/bench_${TAG}_$a.json" 2> "$OUT/bench_${TAG}_$a.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 10 --warmup 3 --no-cpu-baseline \
+    > "$OUT/bench_under_rocprof_${TAG}_$a.json" 2> "$OUT/prof_${TAG}_$a.err"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline \
+    > /dev/null 2> "$OUT/pmc_fetch_${TAG}_$a.err"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline \
+    > /dev/null 2> "$OUT/pmc_write_${TAG}_$a.err"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline \
+    > /dev/null 2> "$OUT/pmc_mfma_${TAG}_$a.err"
+  # keep only the small summaries of the raw traces (the per-dispatch kernel trace of 10 steps is tens of MB)
+  find "$OUT/prof_${TAG}_$a" -name '*_kernel_trace.csv' -delete
+  echo "$a done: $(cat "$OUT/bench_${TAG}_$a.json" | head -c 300)"
+done

@@ -1,7 +1,12 @@
 #!/usr/bin/env python
-"""Turn the raw rocprofv3 outputs under gpurun_out/ into the small committed summaries under profiles/<round>/ and
-profiles/traffic.json (HBM bytes per launch of the dominant kernel, read by bench.py for roofline.traffic).
-FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on gfx950; values are KiB."""
+"""Turn the raw rocprofv3 outputs of tools/profile_round.sh (gpurun_out/{prof,pmc_fetch,pmc_write,pmc_mfma}_<tag>_<arch>) into
+the small committed summaries under profiles/<round>/ and into profiles/traffic.json (HBM bytes per launch of every conv kernel
+of every backbone, read by bench.py for roofline.traffic).
+
+    python tools/summarize_profiles.py r02 r2a
+
+FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on gfx950; both counters are in KiB.
+Matrix-pipe busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)."""
 import collections
 import csv
 import glob
@@ -11,37 +16,81 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd, tag = sys.argv[1], sys.argv[2]          # e.g. r01 r1b
+rnd, tag = sys.argv[1], sys.argv[2]
 out = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
-shutil.copy(glob.glob(f"{g}/prof_{tag}/*/*_kernel_stats.csv")[0], f"{out}/kernel_stats_c3d_b32_{tag}.csv")
+BATCH = {"c3d": 32, "resnet18": 32, "r2plus1d-vcop": 32, "s3dg": 16}
+PROFILED_STEPS = 3          # --steps 2 --warmup 1 in the PMC passes
 
 
-def pmc(kind):
-    f = glob.glob(f"{g}/pmc_{kind}_{tag}/*/*_counter_collection.csv")[0]
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
-        agg[k][0] += 1
-        agg[k][1] += float(r["Counter_Value"])
-    with open(f"{out}/pmc_{kind}_size_by_kernel_{tag}.txt", "w") as o:
-        o.write(f"# rocprofv3 --pmc {kind.upper()}_SIZE -- python3 bench.py --steps 2 --warmup 1 (3 steps); raw counter sum (KiB)\n")
-        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
-            o.write(f"{k:60s} calls={n:5d} sum_KiB={v:.0f} avg_MiB_per_launch={v / n / 1024:.1f}\n")
-    return agg
+def short(name):
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
 
 
-fetch, write = pmc("fetch"), pmc("write")
-dom = [k for k in fetch if k.startswith("void igemm_kernel<128, 128")][0]
-n = fetch[dom][0]
-traffic = {"kernel": dom, "launches_profiled": n,
-           "fetch_bytes_per_launch": fetch[dom][1] * 1024 * 2 / n, "write_bytes_per_launch": write[dom][1] * 1024 / write[dom][0],
-           "note": "FETCH_SIZE x2 (gfx950 half-count for wide coalesced reads) + WRITE_SIZE, averaged over the fwd+dgrad "
-                   "launches of 3 C3D B=32 steps", "source": f"profiles/{rnd}/pmc_*_{tag}.txt"}
-traffic["hbm_bytes_per_launch"] = traffic["fetch_bytes_per_launch"] + traffic["write_bytes_per_launch"]
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1))
-rows = list(csv.DictReader(open(f"{out}/kernel_stats_c3d_b32_{tag}.csv")))
-for r in rows[:8]:
-    print(r["Name"].replace("(anonymous namespace)::", "")[:70].ljust(70), r["Calls"], f'{float(r["AverageNs"]) / 1e6:.3f} ms', r["Percentage"])
+def one(path_glob):
+    f = glob.glob(path_glob)
+    return f[0] if f else None
+
+
+def pmc_by_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.defaultdict(lambda: collections.Counter())
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[k][r["Counter_Name"]] += 1
+    return agg, calls
+
+
+tpath = os.path.join(ROOT, "profiles", "traffic.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+if "kernel" in traffic:      # round-1 single-kernel format
+    traffic = {}
+
+for arch, B in BATCH.items():
+    ks = one(f"{g}/prof_{tag}_{arch}/*/*_kernel_stats.csv")
+    if not ks:
+        continue
+    shutil.copy(ks, f"{out}/kernel_stats_{arch}_b{B}_{tag}.csv")
+    for kind in ("bench", "bench_under_rocprof"):
+        src = f"{g}/{kind}_{tag}_{arch}.json"
+        if os.path.exists(src) and os.path.getsize(src):
+            shutil.copy(src, f"{out}/{kind}_{arch}_b{B}_{tag}.json")
+    fetch_f, write_f, mfma_f = (one(f"{g}/pmc_{k}_{tag}_{arch}/*/*_counter_collection.csv") for k in ("fetch", "write", "mfma"))
+    lines = [f"# {arch} B={B}: rocprofv3 --pmc <counter> -- python3 bench.py --arch {arch} --steps 2 --warmup 1 ({PROFILED_STEPS} steps), "
+             f"one pass per counter group; FETCH x2 per MI355X_MICROARCH.md (gfx950 half-count), KiB -> bytes",
+             f"# {'kernel':58s} launches  fetch_MB/launch(x2)  write_MB/launch  hbm_MB/launch  mfma_busy"]
+    fetch = pmc_by_kernel(fetch_f) if fetch_f else ({}, {})
+    write = pmc_by_kernel(write_f) if write_f else ({}, {})
+    mfma = pmc_by_kernel(mfma_f) if mfma_f else ({}, {})
+    ent = {}
+    names = sorted(fetch[0], key=lambda k: -(fetch[0][k]["FETCH_SIZE"] + write[0].get(k, {}).get("WRITE_SIZE", 0.0)))
+    for k in names[:24]:
+        n = fetch[1][k]["FETCH_SIZE"]
+        fb = fetch[0][k]["FETCH_SIZE"] * 1024 * 2 / max(n, 1)
+        wn = write[1].get(k, {}).get("WRITE_SIZE", 0)
+        wb = write[0].get(k, {}).get("WRITE_SIZE", 0.0) * 1024 / max(wn, 1)
+        busy = ""
+        if k in mfma[0]:
+            act = mfma[0][k].get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            if act > 0:
+                busy = f"{mfma[0][k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (act * 1024.0):.3f}"
+        lines.append(f"{k:60s} {n:6d}  {fb / 1e6:12.2f}  {wb / 1e6:12.2f}  {(fb + wb) / 1e6:12.2f}  {busy}")
+        if any(s in k for s in ("igemm_kernel", "wgrad_dma_kernel", "wgrad_kernel", "stem_")):
+            ent[k] = {"launches_profiled": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                      "hbm_bytes_per_launch": fb + wb, "mfma_busy": float(busy) if busy else None,
+                      "source": f"profiles/{rnd}/pmc_by_kernel_{arch}_b{B}_{tag}.txt"}
+    with open(f"{out}/pmc_by_kernel_{arch}_b{B}_{tag}.txt", "w") as o:
+        o.write("\n".join(lines) + "\n")
+    traffic[f"{arch}_b{B}"] = ent
+    rows = list(csv.DictReader(open(ks)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"== {arch} B={B}: GPU time {tot / 1e6 / 13:.2f} ms/step over 13 profiled steps")
+    for r in rows[:10]:
+        k = short(r["Name"])
+        t = traffic[f"{arch}_b{B}"].get(k, {})
+        print(f"  {k[:56]:56s} calls {int(r['Calls']):6d}  avg {float(r['AverageNs']) / 1e6:8.4f} ms  {float(r['Percentage']):5.1f}%  "
+              f"hbm {t.get('hbm_bytes_per_launch', 0) / 1e6:8.1f} MB/launch  busy {t.get('mfma_busy')}")
+
+json.dump(traffic, open(tpath, "w"), indent=1)
