@@ -70,6 +70,32 @@ size_t rsp_conv3d_dgrad_workspace(const rsp_conv3d_desc* d);
 int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_ref, float* dx, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* dgrad over weights already re-packed into the per-stride-class layouts (rsp_conv3d_pack_jobs(which = 1) + rsp_pack_run):
+ * the workspace then only holds the K-split partials (rsp_conv3d_dgrad_workspace(d) is always enough). */
+size_t rsp_conv3d_packed_dgrad_elems(const rsp_conv3d_desc* d);
+int rsp_conv3d_dgrad_packed(const rsp_conv3d_desc* d, const float* dy, const float* w_packed, float* dx, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* Batched weight re-pack.  The weights change once per step (torch.optim.SGD step, pretrain.py:165; momentum update of the key
+ * encoder, builder_diffspeed_diffloss.py:337-343), so every convolution's packed copy is rebuilt once per step: instead of one
+ * small launch per convolution (and per dgrad stride class) the host describes the re-packs once — the weight and packed
+ * buffers do not move — uploads the array, and replays it with ONE launch per step and encoder.
+ *   rsp_conv3d_pack_jobs: fills (host memory) the jobs that re-pack w_ref (reference layout (Cout_src, Cin_src, kT, kH, kW)) into
+ *     w_packed for descriptor d; d->Cout / d->Cin may exceed the source dims, the excess is zero (channel padding, e.g. the
+ *     3 -> 4 channel stems).  which = 0: forward layout (1 job, rsp_conv3d_packed_fwd_elems floats); which = 1: all dgrad
+ *     stride-class layouts (<= sT*sH*sW jobs, rsp_conv3d_packed_dgrad_elems floats).  Returns the number of jobs or RSP_E*.
+ *   rsp_pack_run: executes n_jobs jobs stored in DEVICE memory. */
+typedef struct rsp_pack_job {
+  const void* src;
+  void* dst;
+  int64_t total;
+  int32_t kind, Cout_src, Cin_src, kT, kH, kW;
+  int32_t transpose, O, C, Kld, nTd, nTh, nTw, k0d, k0h, k0w, kstepd, ksteph, kstepw, ntaps;
+} rsp_pack_job;
+int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Cout_src, int32_t Cin_src, const float* w_ref,
+                             float* w_packed, rsp_pack_job* jobs, int32_t max_jobs);
+int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, void* stream);
+
 /* wgrad: dw (reference layout, overwritten) = sum over positions of dy ⊗ im2col(x); dbias (nullable) = sum dy. */
 size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d);
 int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
@@ -86,9 +112,11 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which);
  * ------------------------------------------------------------------------------------------------------- */
 /* Reduce stat partials -> mean (incl. conv bias), invstd; update running stats
  * (running_var with the unbiased n/(n-1) estimate), as F.batch_norm(training=True) does.
- * count = number of positions per channel.  scale_shift out: [2][C] = (gamma*invstd, beta - mean*gamma*invstd). */
+ * count = number of positions per channel.  scale_shift out: [2][C] = (gamma*invstd, beta - mean*gamma*invstd).
+ * stat_ld (>= C) = channels per partial row: the C channels may be a slice of a wider convolution's partials (several
+ * BasicConv3d that share their input run as ONE GEMM over the concatenated filters, models/s3dg.py:80-88). */
 size_t rsp_bn_finalize_workspace(int32_t tiles, int32_t C);
-int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int64_t count, const float* conv_bias,
+int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int32_t stat_ld, int64_t count, const float* conv_bias,
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, float* mean_invstd /*[2][C]*/, float* scale_shift /*[2][C]*/, void* workspace,
                     size_t workspace_bytes, void* stream);
@@ -166,15 +194,16 @@ int rsp_l2norm_bwd(const float* x, const float* dy, int32_t B, int32_t dim, floa
 /* ---------------------------------------------------------------------------------------------------------
  * Contrastive block (moco/builder_diffspeed_diffloss.py:521-538) and Loss (:263-283).
  * logits1 = [qA.kA | qA@queue]/T, logits2 = [qA.knegA | qA@queue]/T  each [B][1+K];  lposM = qM.kM/T, lnegM = qM.knegM/T
- * queue: [dim][K] (register_buffer "queue", :329-330).
+ * queue: [dim][K] (register_buffer "queue", :329-330).  qA/kA/knegA are [B][dim]; qM/kM/knegM are [B][dim_m]
+ * (dim_m == dim except for fc_type 'speednet', whose second head is 1-dimensional: moco/split_wrapper.py:124-126).
  * ------------------------------------------------------------------------------------------------------- */
 int rsp_logits_fwd(const float* qA, const float* qM, const float* kA, const float* kM, const float* knegA,
-                   const float* knegM, const float* queue, int32_t B, int32_t dim, int32_t K, float inv_T,
+                   const float* knegM, const float* queue, int32_t B, int32_t dim, int32_t dim_m, int32_t K, float inv_T,
                    float* logits1, float* logits2, float* lposM, float* lnegM, void* stream);
 size_t rsp_logits_bwd_workspace(int32_t B, int32_t dim, int32_t K);
 int rsp_logits_bwd(const float* dlogits1, const float* dlogits2, const float* dlposM, const float* dlnegM,
                    const float* kA, const float* kM, const float* knegA, const float* knegM, const float* queue,
-                   int32_t B, int32_t dim, int32_t K, float inv_T, float* dqA, float* dqM, void* workspace,
+                   int32_t B, int32_t dim, int32_t dim_m, int32_t K, float inv_T, float* dqA, float* dqM, void* workspace,
                    size_t workspace_bytes, void* stream);
 
 /* losses[3] = (A*(ce1+ce2)+M*ranking, ce1+ce2, ranking); CE targets are class 0 (labels_A), ranking target +1.
@@ -203,6 +232,20 @@ int rsp_momentum_update(float* k, const float* q, int64_t n, float m, void* stre
  * p -= lr*buf. */
 int rsp_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float wd, float gscale,
                  int first, void* stream);
+
+/* Small element-wise ops on dense fp32 vectors (y may alias a or b):
+ *   RSP_ELT_RELU_FWD     y = max(a, 0)              nn.ReLU between the two convs of ConvFc (moco/split_wrapper.py:31-34)
+ *   RSP_ELT_RELU_BWD     y = a > 0 ? b : 0          its backward (a = forward output, b = incoming gradient)
+ *   RSP_ELT_SIGMOID_FWD  y = 1 / (1 + exp(-a))      torch.sigmoid of the 'speednet' head (moco/split_wrapper.py:146-147)
+ *   RSP_ELT_SIGMOID_BWD  y = b * a * (1 - a)        its backward (a = forward output)
+ *   RSP_ELT_ADD          y = a + b                  autograd's gradient accumulation where a tensor has several consumers
+ *                                                   (residual adds models/resnet.py:72-75, inception fan-out models/s3dg.py:93-99) */
+#define RSP_ELT_RELU_FWD 0
+#define RSP_ELT_RELU_BWD 1
+#define RSP_ELT_SIGMOID_FWD 2
+#define RSP_ELT_SIGMOID_BWD 3
+#define RSP_ELT_ADD 4
+int rsp_eltwise(int32_t op, const float* a, const float* b /* nullable for the *_FWD ops */, float* y, int64_t n, void* stream);
 
 /* rows gather: out[j][:] = in[idx[j]][:]  (feature un-shuffle, :389-406). */
 int rsp_rows_gather(const float* in, const int32_t* idx, int32_t n, int32_t width, float* out, void* stream);

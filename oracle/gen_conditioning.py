@@ -1,0 +1,101 @@
+"""How well-conditioned are the fixtures' gradients?  TEST INFRASTRUCTURE ONLY.
+
+``python -m oracle.gen_conditioning [arch ...]`` runs the oracle restatement of every single-rank fixture case three times
+on the same inputs with the same code — fp32 as the reference does (oneDNN convolutions, fused batch_norm), fp64, fp32 with
+oneDNN switched off (ATen's native convolution) and fp32 with BatchNorm evaluated in its folded scale/shift form (what a fused
+conv+BN kernel computes): the same function in other summation / evaluation orders, which is all that separates any two
+correct fp32 implementations — and records, per case, the relative L2 distance of the variants' parameter gradients (max and
+median over tensors) and logits from the default run in tests/golden/conditioning.json; `grad_rel_l2_max` is the larger one.
+
+Why: in a ReLU / max-pool network the backward pass is discontinuous in the forward values.  Two correct fp32
+implementations whose forward activations differ by a relative delta (summation order; delta ~ 1e-6 for C3D, ~3e-5 for the
+deep S3D-G / Bottleneck stacks) decide a fraction ~delta of the ReLU masks / pool arg-maxes differently, and each such element
+changes its gradient contribution by O(1): the whole-gradient distance is ~sqrt(delta) (3e-3 .. 2e-2), independent of the
+fixture size (more elements: more flips, each weighing less).  kappa = |g_fp32 - g_fp64| / |g_fp64| of the ORACLE ITSELF is
+therefore the floor under any whole-step gradient comparison with the reference's fp32 numbers, and tests/golden_util.py
+derives the per-backbone whole-step gradient gate from it (the exact, unit-by-unit check of the backward composition is the
+teacher-forced replay, tests/test_teacher_forced_gpu.py, at 2e-5)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import gen_golden as G      # noqa: E402
+from oracle import restatement as S     # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def measure(tag, seed, meta=None, spec=None, fast=False):
+    """fast=True: skip the fp64 variant (gen_golden's seed screen)."""
+    if spec is None:
+        with open(os.path.join(GOLDEN, f"state_spec_{G.tag_file(tag)}.json")) as f:
+            spec = {k: (tuple(s), d) for k, (s, d) in json.load(f).items()}
+    if meta is None:
+        z = np.load(os.path.join(GOLDEN, G.case_name(tag, 1, seed) + ".npz"))
+        meta = json.loads(str(z["meta"]))
+    state, mom, clips, perms_B, sh = G.case_inputs(spec, tag, meta["B"], meta["HW"], meta["K"], 1, seed)
+
+    import contextlib
+
+    def run(dt, mkldnn=True, folded_bn=False):
+        torch.set_default_dtype(dt)
+        try:
+            with torch.backends.mkldnn.flags(enabled=mkldnn), (S.bn_scale_shift() if folded_bn else contextlib.nullcontext()):
+                return _run_once(dt)
+        finally:
+            torch.set_default_dtype(torch.float32)
+
+    def _run_once(dt):
+        if True:
+            st = {k: (torch.from_numpy(v.copy()).to(dt) if v.dtype == np.float32 else torch.from_numpy(v.copy())) for k, v in state.items()}
+            return S.moco_step(meta["arch"], [st], [torch.from_numpy(clips[0][0]).to(dt)], [torch.from_numpy(clips[0][1]).to(dt)],
+                               [torch.from_numpy(perms_B[0])], (torch.from_numpy(sh[0]), torch.from_numpy(sh[1])), meta["speed"],
+                               K=meta["K"], lr=meta["lr"], fc_type=meta.get("fc_type", "linear"), momentum_buffers=[{}])[0]
+
+    o32 = run(torch.float32)
+    out = {}
+    variants = [("native_conv", lambda: run(torch.float32, mkldnn=False)), ("folded_bn", lambda: run(torch.float32, folded_bn=True))]
+    if not fast:
+        variants.insert(0, ("fp64", lambda: run(torch.float64)))
+    for tag_v, fn in variants:
+        other = fn()
+        errs = []
+        for k, g in o32["grads"].items():
+            if g is None or float(g.norm()) < 1e-4:
+                continue
+            errs.append(float((other["grads"][k].double() - g.double()).norm() / g.double().norm()))
+        out[f"grad_rel_l2_max_{tag_v}"] = max(errs)
+        out[f"grad_rel_l2_median_{tag_v}"] = float(np.median(errs))
+        out[f"logits_rel_{tag_v}"] = float((other["logits1"].double() - o32["logits1"].double()).abs().max() / o32["logits1"].abs().max())
+    out["grad_rel_l2_max"] = max(v for k, v in out.items() if k.startswith("grad_rel_l2_max_"))
+    return out
+
+
+def main():
+    only = sys.argv[1:]
+    path = os.path.join(GOLDEN, "conditioning.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    with open(os.path.join(GOLDEN, "index.json")) as f:
+        index = json.load(f)
+    for tag, ws, seed in index:
+        if ws != 1 or (only and tag not in only):
+            continue
+        m = measure(tag, seed)
+        prev = out.get(tag)
+        out[tag] = m if prev is None else {k: max(m[k], prev[k]) for k in m}       # worst over the arch's seeds
+        print(tag, seed, m, flush=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -21,14 +21,15 @@ from oracle import restatement as S
 
 # (arch, B, T, HW, classes, seed)
 CASES = [("c3d", 4, 16, 32, 11, 4), ("resnet18", 4, 16, 64, 11, 9), ("r2plus1d-vcop", 4, 16, 32, 11, 1), ("s3dg", 4, 16, 64, 11, 8)]
-# S3D-G at 64 px ends in 1x2x2 maps behind nine overlapping max-pools: every seed holds near-ties (same situation as the
-# pretext fixtures, tests/golden_util.py GRAD_TOL_BY_ARCH); it is gated at the looser bar
-SEED_GATE = {"s3dg": 5e-2}
+# S3D-G's deep stack decides some ReLU masks / pool arg-maxes by rounding on every seed (same situation as its pretext
+# fixtures: tests/golden_util.py, oracle/gen_conditioning.py); its screen is looser
+SEED_GATE = {"s3dg": 1e-2}
 
 
 def product_grad_error(arch, ncls, state, x, target, grads):
-    """Worst gradient-summary error of the product's host logic on the torch checker backend: used only to reject seeds whose
-    tiny late layers hold a ReLU / max-pool decision inside the fp32 rounding band ("Gradient tolerance")."""
+    """Worst relative L2 gradient distance (estimated from 16 random projections, oracle/portable.py) of the product's host
+    logic on the torch checker backend: used only to reject seeds whose tiny late layers hold a ReLU / max-pool decision
+    inside the fp32 rounding band ("Gradient tolerance")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_ops import CpuOps
     from golden_util import summary_err
@@ -42,8 +43,8 @@ def product_grad_error(arch, ncls, state, x, target, grads):
         model.train()
         loss = torch.nn.CrossEntropyLoss()(model(torch.from_numpy(x)), torch.from_numpy(target))
         loss.backward()
-        return max(summary_err(n, p.grad.numpy(), P.summarise(n, grads[n])) for n, p in model.named_parameters()
-                   if grads[n] is not None)
+        return max(P.proj_rel_err(n, p.grad.numpy(), P.projections(n, grads[n])) for n, p in model.named_parameters()
+                   if grads[n] is not None and float(np.abs(grads[n]).max()) > 0)
     finally:
         ops.set_backend(prev)
 
@@ -83,6 +84,8 @@ def main():
                "target": target, "logits_eval": le, "logits": lt, "loss": np.float64(loss)}
         for k, g in grads.items():
             out["gradsum." + k] = np.zeros(0) if g is None else P.summarise(k, g)
+            if g is not None:
+                out["gradproj." + k] = P.projections(k, g)
         for k, v in post.items():
             if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
                 out["post." + k] = P.summarise(k, v) if v.ndim else np.asarray(v)

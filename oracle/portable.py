@@ -67,6 +67,26 @@ def summarise(name: str, arr: np.ndarray, count: int = 16) -> np.ndarray:
     return np.concatenate([[np.sqrt((flat * flat).sum()), flat.sum()], flat[idx]])
 
 
+def projections(name: str, arr: np.ndarray, count: int = 16) -> np.ndarray:
+    """`count` fixed pseudo-random +-1 projections of a tensor, <x, u_j> / sqrt(numel), float64.  With golden projections
+    g_j and measured ones m_j, sqrt(sum (m_j-g_j)^2 / sum g_j^2) estimates the relative L2 distance |m-g|/|g| of the full
+    tensors (Johnson-Lindenstrauss) — unlike the plain element sum, whose error can exceed the L2 error by sqrt(numel) when
+    the difference has a coherent component."""
+    flat = np.asarray(arr, dtype=np.float64).reshape(-1)
+    n = flat.size
+    out = np.empty(count, dtype=np.float64)
+    for j in range(count):
+        sign = np.where(uniform01(f"proj{j}:" + name, 11, n) < 0.5, -1.0, 1.0)
+        out[j] = float(flat @ sign) / np.sqrt(n)
+    return out
+
+
+def proj_rel_err(name: str, mine: np.ndarray, golden_proj: np.ndarray) -> float:
+    m = projections(name, mine, len(golden_proj))
+    den = float(np.sqrt((golden_proj ** 2).sum()))
+    return float(np.sqrt(((m - golden_proj) ** 2).sum()) / max(den, 1e-12))
+
+
 def fill_state(spec: Dict[str, Tuple[Tuple[int, ...], str]], seed: int) -> Dict[str, np.ndarray]:
     """Fill a state dict described by {key: (shape, dtype)} with well-conditioned portable values.
 

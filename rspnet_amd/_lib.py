@@ -33,6 +33,13 @@ class PoolDesc(C.Structure):
         "in_ld", "out_ld", "res_ld")]
 
 
+class PackJob(C.Structure):
+    """rsp_pack_job (112 bytes)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("total", C.c_int64)] + [(n, C.c_int32) for n in (
+        "kind", "Cout_src", "Cin_src", "kT", "kH", "kW", "transpose", "O", "C", "Kld", "nTd", "nTh", "nTw", "k0d", "k0h", "k0w",
+        "kstepd", "ksteph", "kstepw", "ntaps")]
+
+
 class AugmentClipDesc(C.Structure):
     """rsp_augment_clip_desc (88 bytes)"""
     _fields_ = [("src", C.c_void_p), ("frame_pitch", C.c_int64), ("row_pitch", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
@@ -60,11 +67,15 @@ SIGNATURES = {
     "rsp_conv3d_fwd": (C.c_int, [_PD, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_conv3d_dgrad_workspace": (_sz, [_PD]),
     "rsp_conv3d_dgrad": (C.c_int, [_PD, _p, _p, _p, _p, _sz, _p]),
+    "rsp_conv3d_packed_dgrad_elems": (_sz, [_PD]),
+    "rsp_conv3d_dgrad_packed": (C.c_int, [_PD, _p, _p, _p, _p, _sz, _p]),
+    "rsp_conv3d_pack_jobs": (_i32, [_PD, _i32, _i32, _i32, _p, _p, _p, _i32]),
+    "rsp_pack_run": (C.c_int, [_p, _i32, _p]),
     "rsp_conv3d_wgrad_workspace": (_sz, [_PD]),
     "rsp_conv3d_wgrad": (C.c_int, [_PD, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_conv3d_kernel_name": (C.c_char_p, [_PD, C.c_int]),
     "rsp_bn_finalize_workspace": (_sz, [_i32, _i32]),
-    "rsp_bn_finalize": (C.c_int, [_p, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_bn_finalize": (C.c_int, [_p, _i32, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_bn_stat_tiles": (_i32, [_i64]),
     "rsp_bn_stats": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "rsp_bn_act_pool_fwd": (C.c_int, [_PP, _p, _p, _p, C.c_int, _p, _p]),
@@ -86,15 +97,16 @@ SIGNATURES = {
     "rsp_linear_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_int, _p, _p, _p, _p, _sz, _p]),
     "rsp_l2norm_fwd": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "rsp_l2norm_bwd": (C.c_int, [_p, _p, _i32, _i32, _p, _p]),
-    "rsp_logits_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p]),
+    "rsp_logits_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p]),
     "rsp_logits_bwd_workspace": (_sz, [_i32, _i32, _i32]),
-    "rsp_logits_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
+    "rsp_logits_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
     "rsp_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "rsp_queue_enqueue": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
     "rsp_clip_gather": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _p]),
     "rsp_momentum_update": (C.c_int, [_p, _p, _i64, _f, _p]),
     "rsp_sgd_step": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _f, C.c_int, _p]),
     "rsp_rows_gather": (C.c_int, [_p, _p, _i32, _i32, _p, _p]),
+    "rsp_eltwise": (C.c_int, [_i32, _p, _p, _p, _i64, _p]),
     "rsp_augment_workspace": (_sz, [_i32, _i32, _i32]),
     "rsp_augment_batch": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _i64,
                                     _p, _sz, _p]),

@@ -13,7 +13,7 @@ namespace {
 // statistics
 // ------------------------------------------------------------------------------------------------------------------
 // stage 1: [tiles][C][2] float partials -> [S][C][2] double partials
-__global__ __launch_bounds__(256) void bn_finalize_stage1(const float* __restrict__ part, int tiles, int C, int S,
+__global__ __launch_bounds__(256) void bn_finalize_stage1(const float* __restrict__ part, int tiles, int C, int ld, int S,
                                                           double* __restrict__ out) {
   __shared__ double red[4][64][2];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void bn_finalize_stage1(const float* __restric
   double s = 0.0, ss = 0.0;
   if (c < C)
     for (int t = t0 + rl; t < t1; t += 4) {
-      const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * C + c) * 2);
+      const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * ld + c) * 2);
       s += (double)v.x;
       ss += (double)v.y;
     }
@@ -48,6 +48,55 @@ __global__ void bn_finalize_stage2(const double* __restrict__ part, int S, int C
   for (int i = 0; i < S; ++i) {
     s += part[((long long)i * C + c) * 2 + 0];
     ss += part[((long long)i * C + c) * 2 + 1];
+  }
+  const double n = (double)count;
+  const double mean0 = s / n;                   // mean of the bias-free conv output
+  double var = ss / n - mean0 * mean0;          // biased
+  var = var > 0.0 ? var : 0.0;
+  const double mean = mean0 + (conv_bias ? (double)conv_bias[c] : 0.0);
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_invstd[c] = (float)mean;
+  mean_invstd[C + c] = invstd;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = b - (float)mean * sc;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// Single-launch variant for up to a few thousand tiles: one workgroup of 1024 threads per 64 channels — 16 tile-lanes per channel
+// reduce the [tiles][C][2] partials in fp64 (fixed order: lane-strided, then a 16-way LDS tree read in index order), then the
+// first 64 threads finalize their channel exactly as bn_finalize_stage2 does.  Replaces two ~6 us launches per BatchNorm by one
+// (S3D-G runs 231 BatchNorm forwards per step).
+__global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __restrict__ part, int tiles, int C, int ld, long long count,
+                                                               const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+  __shared__ double red[16][64][2];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0.0, ss = 0.0;
+  if (c < C)
+    for (int t = rl; t < tiles; t += 16) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * ld + c) * 2);
+      s += (double)v.x;
+      ss += (double)v.y;
+    }
+  red[rl][cl][0] = s;
+  red[rl][cl][1] = ss;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  s = 0.0;
+  ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s += red[i][cl][0];
+    ss += red[i][cl][1];
   }
   const double n = (double)count;
   const double mean0 = s / n;                   // mean of the bias-free conv output
@@ -500,20 +549,25 @@ size_t rsp_bn_finalize_workspace(int32_t tiles, int32_t C) {
   return (size_t)S * C * 2 * sizeof(double);
 }
 
-int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int64_t count, const float* conv_bias,
+int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int32_t stat_ld, int64_t count, const float* conv_bias,
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, float* mean_invstd, float* scale_shift, void* workspace,
                     size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(stat_partials && mean_invstd && scale_shift && workspace, "rsp_bn_finalize: null pointer");
-  RSP_REQUIRE(tiles > 0 && C > 0 && count > 0, "rsp_bn_finalize: bad size");
+  RSP_REQUIRE(tiles > 0 && C > 0 && count > 0 && stat_ld >= C, "rsp_bn_finalize: bad size");
   const int S = tiles >= 4096 ? 64 : (tiles >= 64 ? 16 : 1);
   if (workspace_bytes < (size_t)S * C * 2 * sizeof(double)) {
     rsp_set_error("rsp_bn_finalize: workspace too small");
     return RSP_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (tiles <= 2048) {
+    hipLaunchKernelGGL(bn_finalize_one_kernel, dim3(rsp_cdiv(C, 64)), dim3(1024), 0, s, stat_partials, tiles, C, stat_ld, (long long)count,
+                       conv_bias, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
+    return rsp_check_launch("bn_finalize_one_kernel");
+  }
   double* part = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(bn_finalize_stage1, dim3(rsp_cdiv(C, 64), S), dim3(256), 0, s, stat_partials, tiles, C, S, part);
+  hipLaunchKernelGGL(bn_finalize_stage1, dim3(rsp_cdiv(C, 64), S), dim3(256), 0, s, stat_partials, tiles, C, stat_ld, S, part);
   int rc = rsp_check_launch("bn_finalize_stage1");
   if (rc != RSP_OK) return rc;
   hipLaunchKernelGGL(bn_finalize_stage2, dim3(rsp_cdiv(C, 128)), dim3(128), 0, s, part, S, C, (long long)count, conv_bias,

@@ -38,6 +38,7 @@ struct IgemmParams {
   int oDm, oHm, oWm;            // output memory dims
   int oSd, oSh, oSw, oOd, oOh, oOw;  // memory coord = g*oS + oO
   int out_ld, Cout;
+  int stat_ld;                  // channels per stat-partial row (= Cout of the whole convolution; this launch may cover a column segment)
   int Di, Hi, Wi, in_ld, Cin;   // input tensor
   int sD, sH, sW;               // in coord = g*s + off(tap)
   int nTd, nTh, nTw;            // taps per dim (tap index = (a_d*nTh + a_h)*nTw + a_w)
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
           s += red[((sb * WPB + w) * BN + c) * 2 + 0];
           ss += red[((sb * WPB + w) * BN + c) * 2 + 1];
         }
-        float* o = p.stat + ((long long)(m_tile * SB + sb) * p.Cout + n0 + c) * 2;
+        float* o = p.stat + ((long long)(m_tile * SB + sb) * p.stat_ld + n0 + c) * 2;
         o[0] = s;
         o[1] = ss;
       }
@@ -437,7 +438,7 @@ struct ReduceParams {
   const float* __restrict__ bias;
   float* __restrict__ y;
   float* __restrict__ stat;
-  int M, Cout, splitk;
+  int M, Cout, splitk, stat_ld;
   int row0;   // first row covered by the partials ([splitk][M - row0][Cout]); a multiple of 128
   int Gd, Gh, Gw, oDm, oHm, oWm, oSd, oSh, oSw, oOd, oOh, oOw, out_ld;
 };
@@ -480,8 +481,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
         a += red[w][threadIdx.x][0];
         b += red[w][threadIdx.x][1];
       }
-      p.stat[((long long)m_tile * p.Cout + c) * 2 + 0] = a;
-      p.stat[((long long)m_tile * p.Cout + c) * 2 + 1] = b;
+      p.stat[((long long)m_tile * p.stat_ld + c) * 2 + 0] = a;
+      p.stat[((long long)m_tile * p.stat_ld + c) * 2 + 1] = b;
     }
   }
 }
@@ -513,14 +514,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const ReducePara
                 p.out_ld;
     }
   }
-  for (int z = 0; z < p.splitk; ++z) {
+  // K-slices are summed four at a time, ((z0 + z1) + (z2 + z3)) onto the running sum: 32 independent 16-byte loads in flight per
+  // thread instead of 8 (the small late layers run S = 8..16 slices on a few dozen workgroups, where each dependent round of
+  // loads is an exposed L2 round trip: 27 us -> ~10 us per reduce on R3D-18's layer 3/4 shapes); the order is fixed.
+  const float* pbase[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (addr[i] >= 0) {
-        const int r = m_tile * 128 + rl + 16 * i;
-        v[i] += *reinterpret_cast<const floatx4*>(p.partial + z * slab + (long long)(r - p.row0) * p.Cout + c);
-      }
-    }
+  for (int i = 0; i < 8; ++i) pbase[i] = p.partial + (long long)(m_tile * 128 + rl + 16 * i - p.row0) * p.Cout + c;
+  int z = 0;
+  for (; z + 4 <= p.splitk; z += 4) {
+    floatx4 t[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        t[u][i] = addr[i] >= 0 ? *reinterpret_cast<const floatx4*>(pbase[i] + (z + u) * slab) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += (t[0][i] + t[1][i]) + (t[2][i] + t[3][i]);
+  }
+  for (; z < p.splitk; ++z) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (addr[i] >= 0) v[i] += *reinterpret_cast<const floatx4*>(pbase[i] + z * slab);
   }
   floatx4 bv = floatx4{0.f, 0.f, 0.f, 0.f};
   if (p.bias && cok) bv = *reinterpret_cast<const floatx4*>(p.bias + c);
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const ReducePara
       float a = 0.f;
 #pragma unroll
       for (int w = 0; w < 16; ++w) a += red[which][w][cc >> 2][cc & 3];
-      if (c0 + cc < p.Cout) p.stat[((long long)m_tile * p.Cout + c0 + cc) * 2 + which] = a;
+      if (c0 + cc < p.Cout) p.stat[((long long)m_tile * p.stat_ld + c0 + cc) * 2 + which] = a;
     }
   }
 }
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const ReducePara
 struct PackParams {
   const float* __restrict__ w;
   float* __restrict__ out;
-  int Cout, Cin, kT, kH, kW;
+  int Cout, Cin, kT, kH, kW;   // dims of the SOURCE tensor (reference layout); O / C below may be larger: zero padding
   int transpose;  // 0: o=co,c=ci (forward)   1: o=ci,c=co (dgrad)
   int O, C, Kld;
   int nTd, nTh, nTw;     // taps enumerated per dim
@@ -573,9 +587,40 @@ __global__ void pack_weight_kernel(const PackParams p) {
       const int ah = q % p.nTh, ad = q / p.nTh;
       const int kt = p.k0d + ad * p.kstepd, kh = p.k0h + ah * p.ksteph, kw = p.k0w + aw * p.kstepw;
       const int co = p.transpose ? c : o, ci = p.transpose ? o : c;
-      v = p.w[((((long long)co * p.Cin + ci) * p.kT + kt) * p.kH + kh) * p.kW + kw];
+      if (co < p.Cout && ci < p.Cin) v = p.w[((((long long)co * p.Cin + ci) * p.kT + kt) * p.kH + kh) * p.kW + kw];
     }
     p.out[i] = v;
+  }
+}
+
+// Many re-packs in one launch (blockIdx.y = job): a step re-packs every convolution weight of an encoder once (forward
+// layout, and for the query encoder the dgrad layouts) — as single launches that was 80-270 four-microsecond kernels per step.
+__global__ void pack_batch_kernel(const rsp_pack_job* __restrict__ jobs) {
+  const rsp_pack_job j = jobs[blockIdx.y];
+  const float* __restrict__ w = reinterpret_cast<const float*>(j.src);
+  float* __restrict__ out = reinterpret_cast<float*>(j.dst);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < j.total; i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (j.kind == 1) {   // stem layout [tap][64][4] (conv_stem.hip)
+      const int ci = (int)(i & 3), n = (int)((i >> 2) & 63), tap = (int)(i >> 8);
+      if (tap < j.ntaps && n < j.Cout_src && ci < j.Cin_src) {
+        const int kw = tap % j.kW, r = tap / j.kW;
+        const int kh = r % j.kH, kt = r / j.kH;
+        v = w[((((long long)n * j.Cin_src + ci) * j.kT + kt) * j.kH + kh) * j.kW + kw];
+      }
+    } else {
+      const int o = (int)(i / j.Kld);
+      const int k = (int)(i - (long long)o * j.Kld);
+      if (k < j.ntaps * j.C) {
+        const int tap = k / j.C, c = k - tap * j.C;
+        const int aw = tap % j.nTw, q = tap / j.nTw;
+        const int ah = q % j.nTh, ad = q / j.nTh;
+        const int kt = j.k0d + ad * j.kstepd, kh = j.k0h + ah * j.ksteph, kw = j.k0w + aw * j.kstepw;
+        const int co = j.transpose ? c : o, ci = j.transpose ? o : c;
+        if (co < j.Cout_src && ci < j.Cin_src) v = w[((((long long)co * j.Cin_src + ci) * j.kT + kt) * j.kH + kh) * j.kW + kw];
+      }
+    }
+    out[i] = v;
   }
 }
 
@@ -680,6 +725,7 @@ void fill_reduce(ReduceParams& r, const IgemmParams& p) {
   r.stat = p.stat;
   r.M = p.M;
   r.Cout = p.Cout;
+  r.stat_ld = p.stat_ld;
   r.splitk = p.splitk;
   r.row0 = p.tail_row0;
   r.Gd = p.Gd; r.Gh = p.Gh; r.Gw = p.Gw;
@@ -697,7 +743,7 @@ size_t split_partial_bytes(const SplitPlan& sp, long long M, int n_tiles, int Co
   return (size_t)sp.splitk * (size_t)(M - row0) * Cout * sizeof(float);
 }
 
-int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
+int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
   static const float* zero_page = nullptr;
   if (!zero_page) {
     void* z = nullptr;
@@ -758,7 +804,61 @@ int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipSt
   return rc;
 }
 
+// Column segments of one GEMM.  The N tiles are 128 wide (64 / 32 for narrow outputs); a channel count such as 144, 160 or 288
+// would run its last 128-wide tile almost empty (144 -> 2 tiles, 56 % of the MFMA work useful).  When the part beyond the
+// last multiple of 128 fits a 64- or 32-wide tile it is launched on its own with that tile shape (144 = 128 + 16 -> 90 %):
+// same kernel, operands addressed through offset base pointers; the stat-partial rows keep the full convolution's pitch.
+struct Segments {
+  int n;
+  int c0[2], width[2];
+};
+
+Segments plan_segments(int Cout) {
+  Segments g;
+  const int full = Cout / 128 * 128, r = Cout - full;
+#ifdef RSP_TUNE
+  if (getenv("RSP_NO_SEGMENTS")) return {1, {0, 0}, {Cout, 0}};
+#endif
+  if (full == 0 || r == 0 || r > 64) {
+    g.n = 1; g.c0[0] = 0; g.width[0] = Cout; g.c0[1] = 0; g.width[1] = 0;
+  } else {
+    g.n = 2; g.c0[0] = 0; g.width[0] = full; g.c0[1] = full; g.width[1] = r;
+  }
+  return g;
+}
+
+int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
+  const Segments g = plan_segments(p.Cout);
+  p.stat_ld = p.Cout;
+  if (g.n == 1) return run_igemm_segment(p, vec4, workspace, ws_bytes, s);
+  for (int i = 0; i < g.n; ++i) {
+    IgemmParams q = p;
+    const int c0 = g.c0[i];
+    q.Cout = g.width[i];
+    q.w = p.w + (long long)c0 * p.Kld;
+    q.w_bytes = (unsigned)((unsigned long long)q.Cout * p.Kld * 4ull);
+    q.bias = p.bias ? p.bias + c0 : nullptr;
+    q.y = p.y + c0;
+    q.stat = p.stat ? p.stat + 2ll * c0 : nullptr;
+    const int rc = run_igemm_segment(q, vec4, workspace, ws_bytes, s);   // same stream: the workspace is free again when it starts
+    if (rc != RSP_OK) return rc;
+  }
+  return RSP_OK;
+}
+
+size_t igemm_partial_bytes_segment(long long M, int Cout, int K);
+
 size_t igemm_partial_bytes(long long M, int Cout, int K) {
+  const Segments g = plan_segments(Cout);
+  size_t best = 0;
+  for (int i = 0; i < g.n; ++i) {
+    const size_t b = igemm_partial_bytes_segment(M, g.width[i], K);
+    best = b > best ? b : best;
+  }
+  return best;
+}
+
+size_t igemm_partial_bytes_segment(long long M, int Cout, int K) {
 #ifdef RSP_TUNE
   if (getenv("RSP_SPLIT")) return (size_t)16 * M * Cout * sizeof(float);   // room for any forced split
 #endif
@@ -880,8 +980,9 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   const int cin = which == 0 ? d->Cin : d->Cout, ld = which == 0 ? d->in_ld : d->out_ld, cols = which == 0 ? d->Cout : d->Cin;
   const bool vec4 = cin % 4 == 0 && ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 && d->kW <= 8;
   const int bn = tile_bn(cols);
-  if (vec4) return bn == 128 ? "igemm_kernel<128,128,2,2,4>" : (bn == 64 ? "igemm_kernel<128,64,2,2,4>" : "igemm_kernel<128,32,4,1,4>");
-  return bn == 128 ? "igemm_kernel<128,128,2,2,1>" : (bn == 64 ? "igemm_kernel<128,64,2,2,1>" : "igemm_kernel<128,32,4,1,1>");
+  // spelled as rocprofv3 prints the demangled instance (minus namespace and argument list)
+  if (vec4) return bn == 128 ? "igemm_kernel<128, 128, 2, 2, 4, 2>" : (bn == 64 ? "igemm_kernel<128, 64, 2, 2, 4, 2>" : "igemm_kernel<128, 32, 4, 1, 4, 2>");
+  return bn == 128 ? "igemm_kernel<128, 128, 2, 2, 1, 2>" : (bn == 64 ? "igemm_kernel<128, 64, 2, 2, 1, 2>" : "igemm_kernel<128, 32, 4, 1, 1, 2>");
 }
 
 // ---- dgrad ----------------------------------------------------------------------------------------------------
@@ -900,23 +1001,21 @@ size_t rsp_conv3d_dgrad_workspace(const rsp_conv3d_desc* d) {
   return dgrad_wpack_bytes(d) + part;
 }
 
-int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_ref, float* dx, void* workspace,
-                     size_t workspace_bytes, void* stream) {
-  RSP_REQUIRE(desc_ok(d), "rsp_conv3d_dgrad: bad descriptor");
-  RSP_REQUIRE(dy && w_ref && dx && workspace, "rsp_conv3d_dgrad: null pointer");
-  RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_dgrad: workspace must be 16-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  const int nclass = d->sT * d->sH * d->sW;
-  unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
-  const size_t wp_bytes = dgrad_wpack_bytes(d);
-  if (workspace_bytes < wp_bytes) {
-    rsp_set_error("rsp_conv3d_dgrad: workspace too small");
-    return RSP_EWORKSPACE;
-  }
-  float* wpk = reinterpret_cast<float*>(wsp);
-  void* part = wsp + wp_bytes;
-  const size_t part_bytes = workspace_bytes - wp_bytes;
+// Fill the re-pack description of one dgrad stride-parity class (source dims = the descriptor's: no padding).
+static void dgrad_pack_params(const rsp_conv3d_desc* d, const DgradClass& g, const float* w_ref, float* out, PackParams& pk) {
+  pk.w = w_ref; pk.out = out;
+  pk.Cout = d->Cout; pk.Cin = d->Cin; pk.kT = d->kT; pk.kH = d->kH; pk.kW = d->kW;
+  pk.transpose = 1; pk.O = d->Cin; pk.C = d->Cout;
+  pk.Kld = (int)rsp_align_up((size_t)g.nt * g.nh * g.nw * d->Cout, 4);
+  pk.nTd = g.nt; pk.nTh = g.nh; pk.nTw = g.nw;
+  pk.k0d = g.k0t; pk.k0h = g.k0h; pk.k0w = g.k0w;
+  pk.kstepd = d->sT; pk.ksteph = d->sH; pk.kstepw = d->sW;
+}
 
+// The GEMM launches of dgrad over already packed per-class weights (class c's block follows class c-1's, O x Kld floats each).
+static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk, float* dx, void* part, size_t part_bytes,
+                     hipStream_t s) {
+  const int nclass = d->sT * d->sH * d->sW;
   bool any_empty = false;
   for (int c = 0; c < nclass; ++c) {
     const DgradClass g = dgrad_class(d, c);
@@ -931,31 +1030,14 @@ int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_r
       (void)hipMemset2DAsync(dx, (size_t)d->in_ld * 4, 0, (size_t)d->Cin * 4, rows, s);
     }
   }
-
   size_t woff = 0;
   for (int c = 0; c < nclass; ++c) {
     const DgradClass g = dgrad_class(d, c);
     if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
-
-    PackParams pk;
-    pk.w = w_ref; pk.out = wpk + woff;
-    pk.Cout = d->Cout; pk.Cin = d->Cin; pk.kT = d->kT; pk.kH = d->kH; pk.kW = d->kW;
-    pk.transpose = 1; pk.O = d->Cin; pk.C = d->Cout;
-    pk.Kld = (int)rsp_align_up((size_t)g.nt * g.nh * g.nw * d->Cout, 4);
-    pk.nTd = g.nt; pk.nTh = g.nh; pk.nTw = g.nw;
-    pk.k0d = g.k0t; pk.k0h = g.k0h; pk.k0w = g.k0w;
-    pk.kstepd = d->sT; pk.ksteph = d->sH; pk.kstepw = d->sW;
-    {
-      const long long total = (long long)pk.O * pk.Kld;
-      const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-      hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, pk);
-      int rc = rsp_check_launch("pack_weight_kernel(dgrad)");
-      if (rc != RSP_OK) return rc;
-    }
-
+    const int Kld = (int)rsp_align_up((size_t)g.nt * g.nh * g.nw * d->Cout, 4);
     IgemmParams p;
     memset(&p, 0, sizeof p);
-    p.x = dy; p.w = pk.out; p.bias = nullptr; p.y = dx; p.stat = nullptr;
+    p.x = dy; p.w = wpk + woff; p.bias = nullptr; p.y = dx; p.stat = nullptr;
     p.M = d->N * g.Gd * g.Gh * g.Gw;
     p.Gd = g.Gd; p.Gh = g.Gh; p.Gw = g.Gw;
     p.oDm = d->Di; p.oHm = d->Hi; p.oWm = d->Wi;
@@ -971,18 +1053,121 @@ int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_r
     p.off0w = (g.rw + d->pW - g.k0w) / d->sW;
     p.offstep = -1;
     p.K = g.nt * g.nh * g.nw * d->Cout;
-    p.Kld = pk.Kld;
+    p.Kld = Kld;
     const unsigned long long xb = (unsigned long long)d->N * d->Do * d->Ho * d->Wo * d->out_ld * 4ull;
-    const unsigned long long wb = (unsigned long long)pk.O * pk.Kld * 4ull;
+    const unsigned long long wb = (unsigned long long)d->Cin * Kld * 4ull;
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
-    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && xb < (1ull << 32) && wb < (1ull << 32) &&
-                      g.nt <= 8 && g.nh <= 8 && g.nw <= 8;
+    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && rsp_aligned16(p.w) && xb < (1ull << 32) &&
+                      wb < (1ull << 32) && g.nt <= 8 && g.nh <= 8 && g.nw <= 8;
     int rc = run_igemm(p, vec4, part, part_bytes, s);
+    if (rc != RSP_OK) return rc;
+    woff += (size_t)d->Cin * Kld;
+  }
+  return RSP_OK;
+}
+
+int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_ref, float* dx, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(desc_ok(d), "rsp_conv3d_dgrad: bad descriptor");
+  RSP_REQUIRE(dy && w_ref && dx && workspace, "rsp_conv3d_dgrad: null pointer");
+  RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_dgrad: workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nclass = d->sT * d->sH * d->sW;
+  unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
+  const size_t wp_bytes = dgrad_wpack_bytes(d);
+  if (workspace_bytes < wp_bytes) {
+    rsp_set_error("rsp_conv3d_dgrad: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  float* wpk = reinterpret_cast<float*>(wsp);
+  size_t woff = 0;
+  for (int c = 0; c < nclass; ++c) {
+    const DgradClass g = dgrad_class(d, c);
+    if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+    PackParams pk;
+    dgrad_pack_params(d, g, w_ref, wpk + woff, pk);
+    const long long total = (long long)pk.O * pk.Kld;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, pk);
+    int rc = rsp_check_launch("pack_weight_kernel(dgrad)");
     if (rc != RSP_OK) return rc;
     woff += (size_t)pk.O * pk.Kld;
   }
-  return RSP_OK;
+  return dgrad_run(d, dy, wpk, dx, wsp + wp_bytes, workspace_bytes - wp_bytes, s);
+}
+
+size_t rsp_conv3d_packed_dgrad_elems(const rsp_conv3d_desc* d) {
+  if (!desc_ok(d)) return 0;
+  return dgrad_wpack_bytes(d) / sizeof(float);
+}
+
+int rsp_conv3d_dgrad_packed(const rsp_conv3d_desc* d, const float* dy, const float* w_packed, float* dx, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(desc_ok(d), "rsp_conv3d_dgrad_packed: bad descriptor");
+  RSP_REQUIRE(dy && w_packed && dx, "rsp_conv3d_dgrad_packed: null pointer");
+  RSP_REQUIRE(rsp_aligned16(w_packed) && (!workspace || rsp_aligned16(workspace)),
+              "rsp_conv3d_dgrad_packed: packed weight / workspace must be 16-byte aligned");
+  return dgrad_run(d, dy, w_packed, dx, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- batched re-pack -------------------------------------------------------------------------------------------------
+int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Cout_src, int32_t Cin_src, const float* w_ref,
+                             float* w_packed, rsp_pack_job* jobs, int32_t max_jobs) {
+  if (!desc_ok(d) || !w_ref || !w_packed || !jobs || Cout_src <= 0 || Cin_src <= 0 || Cout_src > d->Cout || Cin_src > d->Cin) {
+    rsp_set_error("rsp_conv3d_pack_jobs: bad argument");
+    return RSP_EINVAL;
+  }
+  auto fill = [&](rsp_pack_job& j, const PackParams& pk) {
+    memset(&j, 0, sizeof j);
+    j.src = pk.w; j.dst = pk.out; j.kind = 0;
+    j.Cout_src = Cout_src; j.Cin_src = Cin_src; j.kT = d->kT; j.kH = d->kH; j.kW = d->kW;
+    j.transpose = pk.transpose; j.O = pk.O; j.C = pk.C; j.Kld = pk.Kld;
+    j.nTd = pk.nTd; j.nTh = pk.nTh; j.nTw = pk.nTw; j.k0d = pk.k0d; j.k0h = pk.k0h; j.k0w = pk.k0w;
+    j.kstepd = pk.kstepd; j.ksteph = pk.ksteph; j.kstepw = pk.kstepw;
+    j.ntaps = pk.nTd * pk.nTh * pk.nTw;
+    j.total = (long long)pk.O * pk.Kld;
+  };
+  if (which == 0) {
+    if (max_jobs < 1) return RSP_EINVAL;
+    if (rsp_stem_applicable(d)) {
+      rsp_pack_job& j = jobs[0];
+      memset(&j, 0, sizeof j);
+      j.src = w_ref; j.dst = w_packed; j.kind = 1;
+      j.Cout_src = Cout_src; j.Cin_src = Cin_src; j.kT = d->kT; j.kH = d->kH; j.kW = d->kW;
+      j.ntaps = d->kT * d->kH * d->kW;
+      j.total = (long long)rsp_stem_packed_elems(d);
+      return 1;
+    }
+    PackParams pk;
+    pk.w = w_ref; pk.out = w_packed;
+    pk.transpose = 0; pk.O = d->Cout; pk.C = d->Cin;
+    pk.Kld = (int)rsp_align_up((size_t)d->kT * d->kH * d->kW * d->Cin, 4);
+    pk.nTd = d->kT; pk.nTh = d->kH; pk.nTw = d->kW;
+    pk.k0d = pk.k0h = pk.k0w = 0;
+    pk.kstepd = pk.ksteph = pk.kstepw = 1;
+    fill(jobs[0], pk);
+    return 1;
+  }
+  int n = 0;
+  size_t woff = 0;
+  const int nclass = d->sT * d->sH * d->sW;
+  for (int c = 0; c < nclass; ++c) {
+    const DgradClass g = dgrad_class(d, c);
+    if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+    if (n >= max_jobs) return RSP_EINVAL;
+    PackParams pk;
+    dgrad_pack_params(d, g, w_ref, w_packed + woff, pk);
+    fill(jobs[n++], pk);
+    woff += (size_t)pk.O * pk.Kld;
+  }
+  return n;
+}
+
+int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, void* stream) {
+  RSP_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535, "rsp_pack_run: bad argument");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(48, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
+  return rsp_check_launch("pack_batch_kernel");
 }
 
 }  // extern "C"

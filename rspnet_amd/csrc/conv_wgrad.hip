@@ -628,18 +628,46 @@ const char* rsp_wgrad_kernel_name(const rsp_conv3d_desc* d) {
   const WPlan w = wplan(d);
   const bool dma = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && d->Cin % 4 == 0 && d->in_ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 &&
                    d->kW <= 8;
-  if (dma) return w.bm == 128 ? (w.bn == 128 ? "wgrad_dma_kernel<128,128>" : "wgrad_dma_kernel<128,64>")
-                              : (w.bn == 128 ? "wgrad_dma_kernel<64,128>" : "wgrad_dma_kernel<64,64>");
-  return w.bm == 128 ? (w.bn == 128 ? "wgrad_kernel<128,128>" : "wgrad_kernel<128,64>")
-                     : (w.bn == 128 ? "wgrad_kernel<64,128>" : "wgrad_kernel<64,64>");
+  if (dma) return w.bm == 128 ? (w.bn == 128 ? "wgrad_dma_kernel<128, 128, 2, 2>" : "wgrad_dma_kernel<128, 64, 2, 2>")
+                              : (w.bn == 128 ? "wgrad_dma_kernel<64, 128, 2, 2>" : "wgrad_dma_kernel<64, 64, 2, 2>");
+  return w.bm == 128 ? (w.bn == 128 ? "wgrad_kernel<128, 128, 2, 2, *>" : "wgrad_kernel<128, 64, 2, 2, *>")
+                     : (w.bn == 128 ? "wgrad_kernel<64, 128, 2, 2, *>" : "wgrad_kernel<64, 64, 2, 2, *>");
 }
+
+namespace {
+
+// Output-channel segments (same idea as the forward kernel's column segments, conv_igemm.hip): the Cout tiles are 128 wide
+// when Cout > 64, so e.g. Cout = 144 would run a second tile that is 1/8 full.  The part beyond the last multiple of 128 is
+// run as its own problem on the 64-wide tile when it fits one (144 = 128 + 16: 75 % useful instead of 56 %).
+int wgrad_split_at(const rsp_conv3d_desc* d) {
+#ifdef RSP_TUNE
+  if (getenv("RSP_NO_SEGMENTS")) return 0;
+#endif
+  const int full = d->Cout / 128 * 128, r = d->Cout - full;
+  return (full > 0 && r > 0 && r <= 64) ? full : 0;
+}
+
+size_t wgrad_ws_one(const rsp_conv3d_desc* d) {
+  const WPlan w = wplan(d);
+  return w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes;
+}
+
+int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+}  // namespace
 
 extern "C" {
 
 size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d) {
   if (!wdesc_ok(d)) return 0;
-  const WPlan w = wplan(d);
-  return w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes;
+  const int at = wgrad_split_at(d);
+  if (!at) return wgrad_ws_one(d);
+  rsp_conv3d_desc a = *d, b = *d;
+  a.Cout = at;
+  b.Cout = d->Cout - at;
+  const size_t wa = wgrad_ws_one(&a), wb = wgrad_ws_one(&b);
+  return wa > wb ? wa : wb;
 }
 
 int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
@@ -647,6 +675,24 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   RSP_REQUIRE(wdesc_ok(d), "rsp_conv3d_wgrad: bad descriptor");
   RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad: null pointer");
   RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_wgrad: workspace must be 16-byte aligned");
+  const int at = wgrad_split_at(d);
+  if (!at) return wgrad_one(d, x, dy, dw_ref, dbias, workspace, workspace_bytes, stream);
+  // two problems over disjoint output-channel ranges; dy keeps its row pitch (out_ld), dw / dbias are contiguous per channel
+  rsp_conv3d_desc a = *d, b = *d;
+  a.Cout = at;
+  b.Cout = d->Cout - at;
+  const long long per_co = (long long)d->Cin * d->kT * d->kH * d->kW;
+  int rc = wgrad_one(&a, x, dy, dw_ref, dbias, workspace, workspace_bytes, stream);
+  if (rc != RSP_OK) return rc;
+  return wgrad_one(&b, x, dy + at, dw_ref + at * per_co, dbias ? dbias + at : nullptr, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
+              size_t workspace_bytes, void* stream) {
   const WPlan w = wplan(d);
   if (workspace_bytes < w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes) {
     rsp_set_error("rsp_conv3d_wgrad: workspace too small");
@@ -731,4 +777,5 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   return rc;
 }
 
-}  // extern "C"
+}  // namespace
+

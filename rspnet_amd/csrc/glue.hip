@@ -79,6 +79,33 @@ __global__ void rows_gather_kernel(const float* __restrict__ in, const int* __re
   }
 }
 
+// Small element-wise pieces of the 'conv' / 'speednet' projection heads (moco/split_wrapper.py:18-39,146-149) and the
+// gradient accumulation at fan-out points of the layer graph (residual / inception branches share an input).
+// op: 0 relu fwd (y = max(a,0)), 1 relu bwd (y = a > 0 ? b : 0), 2 sigmoid fwd, 3 sigmoid bwd (y = b*a*(1-a), a = sigmoid out),
+//     4 accumulate (y = a + b)
+template <int OP>
+__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                      long long n) {
+  auto f = [](float u, float v) -> float {
+    if (OP == 0) return fmaxf(u, 0.f);
+    if (OP == 1) return u > 0.f ? v : 0.f;
+    if (OP == 2) return 1.f / (1.f + expf(-u));
+    if (OP == 3) return v * u * (1.f - u);
+    return u + v;
+  };
+  const bool vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(y) | (b ? reinterpret_cast<uintptr_t>(b) : 0)) & 15) == 0;
+  const long long n4 = vec ? n >> 2 : 0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += 256ll * gridDim.x) {
+    const floatx4 u = reinterpret_cast<const floatx4*>(a)[i];
+    const floatx4 v = b ? reinterpret_cast<const floatx4*>(b)[i] : floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f(u[e], v[e]);
+    reinterpret_cast<floatx4*>(y)[i] = o;
+  }
+  for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) y[i] = f(a[i], b ? b[i] : 0.f);
+}
+
 int grid_for(long long total) {
   long long b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -113,6 +140,22 @@ int rsp_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, floa
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long long)n, lr, mu,
                      wd, gscale, first);
   return rsp_check_launch("sgd_kernel");
+}
+
+int rsp_eltwise(int32_t op, const float* a, const float* b, float* y, int64_t n, void* stream) {
+  RSP_REQUIRE(a && y && n > 0, "rsp_eltwise: bad argument");
+  RSP_REQUIRE(op >= 0 && op <= 4, "rsp_eltwise: unknown op");
+  RSP_REQUIRE(b || op == 0 || op == 2, "rsp_eltwise: this op needs a second operand");
+  const dim3 g(grid_for(n / 4 + 1)), t(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (op) {
+    case 0: hipLaunchKernelGGL(eltwise_kernel<0>, g, t, 0, s, a, b, y, (long long)n); break;
+    case 1: hipLaunchKernelGGL(eltwise_kernel<1>, g, t, 0, s, a, b, y, (long long)n); break;
+    case 2: hipLaunchKernelGGL(eltwise_kernel<2>, g, t, 0, s, a, b, y, (long long)n); break;
+    case 3: hipLaunchKernelGGL(eltwise_kernel<3>, g, t, 0, s, a, b, y, (long long)n); break;
+    default: hipLaunchKernelGGL(eltwise_kernel<4>, g, t, 0, s, a, b, y, (long long)n); break;
+  }
+  return rsp_check_launch("eltwise_kernel");
 }
 
 int rsp_rows_gather(const float* in, const int32_t* idx, int32_t n, int32_t width, float* out, void* stream) {

@@ -9,77 +9,54 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------------------------------------
-// one block per sample: pooled = mean_p feat[b,p,:]; raw_h = W_h pooled + b_h; out_h = raw_h / max(|raw_h|, 1e-12)
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ feat, int B, int P, int C, int ld,
+// raw[h][b][o] = b_h[o] + sum_c W_h[o][c] * pooled[b][c]: workgroup = (sample, 32 output rows of the stacked [W1; W2]), one
+// wave per 8 rows, every weight load of a wave independent (8 rows x C/64 columns in flight).  (Round 1 ran the whole head
+// in one workgroup per sample: ~64 dependent L2 round trips on only B CUs, 205-414 us measured.)
+// Summation order per output: lane-strided partial sums over c, then the wave butterfly.
+__global__ __launch_bounds__(256) void head_raw_kernel(const float* __restrict__ pooled, int B, int C,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
-                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       int dim, float* __restrict__ out1, float* __restrict__ out2,
-                                                       float* __restrict__ pooled, float* __restrict__ raw) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // [C] pooled, [2*dim] raw
-  float* sp = sm;
-  float* sr = sm + C;
-  const int b = blockIdx.x, t = threadIdx.x;
-  const float invP = 1.f / (float)P;
-  const int lane = t & 63, wave = t >> 6;
-  // mean over positions: wave w takes positions w, w+4, ... (independent loads in flight), fixed-order combine
-  float* part = sm + C + 2 * dim;   // [4][C]
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, int dim,
+                                                       float* __restrict__ raw) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o0 = blockIdx.y * 32 + wave * 8;
+  const float* x = pooled + (long long)b * C;
+  const float* rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int o = min(o0 + r, 2 * dim - 1);
+    rows[r] = (o >= dim ? w2 + (long long)(o - dim) * C : w1 + (long long)o * C);
+  }
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll 4
   for (int c = lane; c < C; c += 64) {
-    float s0 = 0.f, s1 = 0.f;
-    const float* f = feat + (long long)b * P * ld + c;
-    int p = wave;
-    for (; p + 4 < P; p += 8) {
-      s0 += f[(long long)p * ld];
-      s1 += f[(long long)(p + 4) * ld];
-    }
-    if (p < P) s0 += f[(long long)p * ld];
-    part[wave * C + c] = s0 + s1;
+    const float xv = x[c];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = fmaf(rows[r][c], xv, acc[r]);
   }
-  __syncthreads();
-  for (int c = t; c < C; c += 256) {
-    const float s = ((part[c] + part[C + c]) + (part[2 * C + c] + part[3 * C + c])) * invP;
-    sp[c] = s;
-    pooled[(long long)b * C + c] = s;
-  }
-  __syncthreads();
-  // 2*dim dot products of length C against the pooled vector.  Each wave takes 8 weight rows at a time so that 8 x C/64
-  // independent loads are in flight per wave (one row at a time is a chain of ~dim/2 exposed global-load latencies: 0.2 ms
-  // for 256 x 512, measured), summation order per row unchanged.
-  for (int o0 = wave * 8; o0 < 2 * dim; o0 += 32) {
-    float acc[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float x = sp[c];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int o = o0 + r;
-        if (o < 2 * dim) {
-          const int hsel = o >= dim;
-          acc[r] = fmaf((hsel ? w2 : w1)[(long long)(o - hsel * dim) * C + c], x, acc[r]);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int o = o0 + r;
-      const float s = rsp_wave_sum(acc[r]);
-      if (lane == 0 && o < 2 * dim) {
-        const int hsel = o >= dim, oo = o - hsel * dim;
-        const float v = s + (hsel ? b2 : b1)[oo];
-        sr[o] = v;
-        raw[((long long)hsel * B + b) * dim + oo] = v;
-      }
+  for (int r = 0; r < 8; ++r) {
+    const int o = o0 + r;
+    const float sum = rsp_wave_sum(acc[r]);
+    if (lane == 0 && o < 2 * dim) {
+      const int hsel = o >= dim, oo = o - hsel * dim;
+      raw[((long long)hsel * B + b) * dim + oo] = sum + (hsel ? b2 : b1)[oo];
     }
   }
-  __syncthreads();
-  if (wave < 2) {
-    float ss = 0.f;
-    for (int o = lane; o < dim; o += 64) ss = fmaf(sr[wave * dim + o], sr[wave * dim + o], ss);
-    ss = rsp_wave_sum(ss);
-    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-    float* out = wave ? out2 : out1;
-    for (int o = lane; o < dim; o += 64) out[(long long)b * dim + o] = sr[wave * dim + o] / nrm;
-  }
+}
+
+// out_h[b][:] = raw[h][b][:] / max(|raw[h][b][:]|, 1e-12); one wave per (sample, head)
+__global__ __launch_bounds__(64) void head_norm_kernel(const float* __restrict__ raw, int B, int dim, float* __restrict__ out1,
+                                                       float* __restrict__ out2) {
+  const int b = blockIdx.x, hsel = blockIdx.y, lane = threadIdx.x;
+  const float* r = raw + ((long long)hsel * B + b) * dim;
+  float ss = 0.f;
+  for (int o = lane; o < dim; o += 64) ss = fmaf(r[o], r[o], ss);
+  ss = rsp_wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  float* out = (hsel ? out2 : out1) + (long long)b * dim;
+  for (int o = lane; o < dim; o += 64) out[o] = r[o] / nrm;
 }
 
 // draw[h][b][:] = (dout - y*(y.dout)) / n   with y = raw/n, n = max(|raw|, eps)
@@ -191,10 +168,11 @@ __global__ __launch_bounds__(256) void logits_neg_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void logits_pos_kernel(const float* __restrict__ qA, const float* __restrict__ qM,
                                                          const float* __restrict__ kA, const float* __restrict__ kM,
                                                          const float* __restrict__ knegA, const float* __restrict__ knegM,
-                                                         int dim, int K1, float inv_T, float* __restrict__ logits1,
+                                                         int dimA, int dimM, int K1, float inv_T, float* __restrict__ logits1,
                                                          float* __restrict__ logits2, float* __restrict__ lposM,
                                                          float* __restrict__ lnegM) {
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = wave < 2 ? dimA : dimM;
   const float* q = (wave < 2 ? qA : qM) + (long long)b * dim;
   const float* k = (wave == 0 ? kA : wave == 1 ? knegA : wave == 2 ? kM : knegM) + (long long)b * dim;
   float s = 0.f;
@@ -257,9 +235,13 @@ __global__ void logits_bwd_final_kernel(const float* __restrict__ partial, int n
                                         const float* __restrict__ g2, const float* __restrict__ gp,
                                         const float* __restrict__ gn, const float* __restrict__ kA,
                                         const float* __restrict__ kM, const float* __restrict__ knegA,
-                                        const float* __restrict__ knegM, int B, int dim, int K1, float inv_T,
+                                        const float* __restrict__ knegM, int B, int dim, int dimM, int K1, float inv_T,
                                         float* __restrict__ dqA, float* __restrict__ dqM) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * dimM) {
+    const int b = i / dimM;
+    dqM[i] = (gp[b] * kM[i] + gn[b] * knegM[i]) * inv_T;
+  }
   if (i >= B * dim) return;
   const int b = i / dim;
   float s = 0.f;
@@ -267,7 +249,6 @@ __global__ void logits_bwd_final_kernel(const float* __restrict__ partial, int n
   s = fmaf(g1[(long long)b * K1], kA[i], s);
   s = fmaf(g2[(long long)b * K1], knegA[i], s);
   dqA[i] = s * inv_T;
-  dqM[i] = (gp[b] * kM[i] + gn[b] * knegM[i]) * inv_T;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -438,21 +419,18 @@ int rsp_head_fwd(const float* feat, int32_t B, int32_t P, int32_t C, int32_t fea
                  const float* b1, const float* w2, const float* b2, int32_t dim, float* out1, float* out2,
                  float* pooled, float* raw, void* stream) {
   RSP_REQUIRE(feat && w1 && b1 && w2 && b2 && out1 && out2 && pooled && raw, "rsp_head_fwd: null pointer");
-  RSP_REQUIRE(B > 0 && P > 0 && C > 0 && dim > 0 && feat_ld >= C && (5 * C + 2 * dim) * 4 <= 64 * 1024,
+  RSP_REQUIRE(B > 0 && P > 0 && C > 0 && dim > 0 && feat_ld >= C,
               "rsp_head_fwd: bad size");
-  if (P > 8) {
-    // pool with B x C/64 workgroups first (one workgroup per sample would serialise ~P*C/256 dependent loads), then run
-    // the head on the pooled vector (P = 1)
-    hipLaunchKernelGGL(smean_kernel, dim3(B, rsp_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, feat, P, C, feat_ld, pooled);
-    int rc = rsp_check_launch("smean_kernel");
-    if (rc != RSP_OK) return rc;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)(5 * C + 2 * dim) * 4, (hipStream_t)stream, pooled, B, 1, C,
-                       C, w1, b1, w2, b2, dim, out1, out2, pooled, raw);
-    return rsp_check_launch("head_fwd_kernel");
-  }
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)(5 * C + 2 * dim) * 4, (hipStream_t)stream, feat, B, P, C,
-                     feat_ld, w1, b1, w2, b2, dim, out1, out2, pooled, raw);
-  return rsp_check_launch("head_fwd_kernel");
+  hipStream_t s = (hipStream_t)stream;
+  // pool with B x C/64 workgroups, then the stacked 2*dim x C mat-vec on B x 2*dim/32 workgroups, then the two l2-norms
+  hipLaunchKernelGGL(smean_kernel, dim3(B, rsp_cdiv(C, 64)), dim3(256), 0, s, feat, P, C, feat_ld, pooled);
+  int rc = rsp_check_launch("smean_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(head_raw_kernel, dim3(B, rsp_cdiv(2 * dim, 32)), dim3(256), 0, s, pooled, B, C, w1, b1, w2, b2, dim, raw);
+  rc = rsp_check_launch("head_raw_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(head_norm_kernel, dim3(B, 2), dim3(64), 0, s, raw, B, dim, out1, out2);
+  return rsp_check_launch("head_norm_kernel");
 }
 
 size_t rsp_head_bwd_workspace(int32_t B, int32_t dim) { return (size_t)2 * B * dim * sizeof(float); }
@@ -484,17 +462,17 @@ int rsp_head_bwd(const float* dout1, const float* dout2, const float* pooled, co
 }
 
 int rsp_logits_fwd(const float* qA, const float* qM, const float* kA, const float* kM, const float* knegA,
-                   const float* knegM, const float* queue, int32_t B, int32_t dim, int32_t K, float inv_T,
+                   const float* knegM, const float* queue, int32_t B, int32_t dim, int32_t dim_m, int32_t K, float inv_T,
                    float* logits1, float* logits2, float* lposM, float* lnegM, void* stream) {
   RSP_REQUIRE(qA && qM && kA && kM && knegA && knegM && queue && logits1 && logits2 && lposM && lnegM,
               "rsp_logits_fwd: null pointer");
-  RSP_REQUIRE(B > 0 && dim > 0 && dim % 2 == 0 && K > 0, "rsp_logits_fwd: bad size (dim must be even)");
+  RSP_REQUIRE(B > 0 && dim > 0 && dim % 2 == 0 && dim_m > 0 && K > 0, "rsp_logits_fwd: bad size (dim must be even)");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(logits_neg_kernel, dim3(rsp_cdiv(K, 128)), dim3(256), 0, s, qA, queue, B, dim, K, inv_T, logits1,
                      logits2);
   int rc = rsp_check_launch("logits_neg_kernel");
   if (rc != RSP_OK) return rc;
-  hipLaunchKernelGGL(logits_pos_kernel, dim3(B), dim3(256), 0, s, qA, qM, kA, kM, knegA, knegM, dim, K + 1, inv_T, logits1,
+  hipLaunchKernelGGL(logits_pos_kernel, dim3(B), dim3(256), 0, s, qA, qM, kA, kM, knegA, knegM, dim, dim_m, K + 1, inv_T, logits1,
                      logits2, lposM, lnegM);
   return rsp_check_launch("logits_pos_kernel");
 }
@@ -505,11 +483,11 @@ size_t rsp_logits_bwd_workspace(int32_t B, int32_t dim, int32_t K) {
 
 int rsp_logits_bwd(const float* dlogits1, const float* dlogits2, const float* dlposM, const float* dlnegM,
                    const float* kA, const float* kM, const float* knegA, const float* knegM, const float* queue,
-                   int32_t B, int32_t dim, int32_t K, float inv_T, float* dqA, float* dqM, void* workspace,
+                   int32_t B, int32_t dim, int32_t dim_m, int32_t K, float inv_T, float* dqA, float* dqM, void* workspace,
                    size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(dlogits1 && dlogits2 && dlposM && dlnegM && kA && kM && knegA && knegM && queue && dqA && dqM && workspace,
               "rsp_logits_bwd: null pointer");
-  RSP_REQUIRE(B > 0 && dim > 0 && K > 0, "rsp_logits_bwd: bad size");
+  RSP_REQUIRE(B > 0 && dim > 0 && dim_m > 0 && dim_m <= dim && K > 0, "rsp_logits_bwd: bad size");
   if (workspace_bytes < rsp_logits_bwd_workspace(B, dim, K)) {
     rsp_set_error("rsp_logits_bwd: workspace too small");
     return RSP_EWORKSPACE;
@@ -530,7 +508,7 @@ int rsp_logits_bwd(const float* dlogits1, const float* dlogits2, const float* dl
   int rc = rsp_check_launch("logits_bwd_neg_kernel");
   if (rc != RSP_OK) return rc;
   hipLaunchKernelGGL(logits_bwd_final_kernel, dim3(rsp_cdiv((long long)B * dim, 256)), dim3(256), 0, s, partial, nslices,
-                     dlogits1, dlogits2, dlposM, dlnegM, kA, kM, knegA, knegM, B, dim, K + 1, inv_T, dqA, dqM);
+                     dlogits1, dlogits2, dlposM, dlnegM, kA, kM, knegA, knegM, B, dim, dim_m, K + 1, inv_T, dqA, dqM);
   return rsp_check_launch("logits_bwd_final_kernel");
 }
 

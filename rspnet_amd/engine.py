@@ -4,6 +4,7 @@ A backbone (rspnet_amd/models/*) is an ``nn.Module`` tree that only *holds* para
 state-dict names; its ``plan()`` lists fused units over numbered tensor slots:
 
   ConvBN   conv3d → BatchNorm3d(train) [→ + residual] [→ ReLU] [→ disjoint MaxPool3d]     (all four backbones)
+  ConvBias conv3d + bias [→ ReLU], no BatchNorm                                            ('conv' projection head)
   Pool     stand-alone MaxPool3d with overlapping windows                                  (ResNet stem, S3D-G)
   Gate     S3D-G self-gating  x * sigmoid(W·mean(x) + b)
   Concat   channel concat of branch outputs (S3D-G inception)
@@ -43,6 +44,41 @@ class ConvBN:
     #   mid-channel counts (83, 230, 921 ...) are not multiples of 4; padded, this conv's output and the next conv's input are
     #   16-byte rows and both take the LDS-DMA kernels instead of the scalar gather.  Pad channels carry zero weights and
     #   gamma = beta = 0, so they are exactly 0 after BN+ReLU and contribute nothing downstream; their gradients are dropped.
+
+
+@dataclass
+class ConvBNGroup:
+    """ConvBN units that read the SAME tensor with the same geometry (S3D-G's inception siblings branch0 / branch1.0 /
+    branch2.0, models/s3dg.py:80-88): when their filters sit back to back in memory (rspnet_amd/flat.py `adjacent`) they run
+    as ONE convolution over the concatenated filters — one GEMM instead of three in forward, one dgrad whose K runs over all
+    members (the fan-out sum of their input gradients comes out of the GEMM, no adds) and one wgrad in backward.  BatchNorm
+    stays per member (channel slices of the shared conv output / statistics).  With any other parameter layout (fine-tune
+    path, stand-alone use) the members simply run one by one."""
+    members: List[ConvBN]
+
+    def _cat_node(self):
+        """What PackedWeights keys on: an object whose .conv.weight is the concatenated filter tensor."""
+        holder = getattr(self, "_holder", None)
+        if holder is None:
+            holder = self._holder = _CatHolder(self._cat)
+        return holder
+
+
+class _CatHolder:
+    def __init__(self, conv):
+        self.conv = conv
+
+
+@dataclass
+class ConvBias:
+    """nn.Conv3d(bias=True) [+ ReLU] without BatchNorm: the two convs of ConvFc (moco/split_wrapper.py:18-39)."""
+    conv: nn.Module
+    src: int
+    dst: int
+    k: Triple
+    s: Triple = (1, 1, 1)
+    p: Triple = (0, 0, 0)
+    relu: bool = False
 
 
 @dataclass
@@ -86,43 +122,77 @@ class _Saved:
 class ForwardCtx:
     saved: Dict[int, _Saved] = field(default_factory=dict)
     feat_shape: Optional[Tuple[int, ...]] = None
+    packed: Optional["PackedWeights"] = None       # the encoder's weight cache (dgrad layouts are fetched from it in backward)
 
 
 class PackedWeights:
-    """Forward-packed conv weights of one encoder, rebuilt when the owner says the weights changed."""
+    """Packed copies of one encoder's convolution weights: the forward layout of every conv and, for convs whose input needs
+    a gradient, the dgrad layouts.  The weights change once per step, so all copies are rebuilt together by ONE batched launch
+    (ops.PackSet) the first time one of them is needed after `invalidate()`; channel padding (3 -> 4 channel stems, R(2+1)D's
+    odd mid-channel counts) is applied by the re-pack itself.  A conv seen for the first time is packed on its own and joins
+    the batch at the next rebuild."""
 
     def __init__(self):
-        self._cache: Dict[int, torch.Tensor] = {}
+        self._entries = []        # (geometry, which, conv module)
+        self._index = {}          # (id(conv), which, geometry) -> (set number, position)
+        self._sets = []
+        self._ptrs = []
+        self._dirty = True
 
     def invalidate(self):
-        self._cache.clear()
+        self._dirty = True
 
-    def get(self, node: ConvBN, cg: ConvGeom):
-        key = id(node.conv)
-        w = self._cache.get(key)
-        if w is None:
-            w = _ops.backend().conv_pack_fwd(cg, pad_weight(node.conv.weight.data, cg.Cout, cg.Cin))
-            self._cache[key] = w
-        return w
+    def _refresh(self):
+        be = _ops.backend()
+        ptrs = [c.weight.data_ptr() for _, _, c in self._entries]
+        if len(self._sets) > 1 or ptrs != self._ptrs:      # new members since the last rebuild, or the parameters moved
+            self._sets = [be.pack_set([(g, which, c.weight.data) for g, which, c in self._entries])] if self._entries else []
+            self._index = {(id(c), which, g): (0, i) for i, (g, which, c) in enumerate(self._entries)}
+            self._ptrs = ptrs
+        for ps in self._sets:
+            ps.run()
+        self._dirty = False
+
+    def _lookup(self, conv, cg: ConvGeom, which: int):
+        if self._dirty:
+            self._refresh()
+        key = (id(conv), which, cg)
+        at = self._index.get(key)
+        if at is None:
+            ps = _ops.backend().pack_set([(cg, which, conv.weight.data)])
+            ps.run()
+            self._sets.append(ps)
+            self._entries.append((cg, which, conv))
+            self._ptrs.append(conv.weight.data_ptr())
+            at = self._index[key] = (len(self._sets) - 1, 0)
+        return self._sets[at[0]].packed[at[1]]
+
+    def get(self, node, cg: ConvGeom):
+        return self._lookup(node.conv, cg, 0)
+
+    def get_dgrad(self, node, cg: ConvGeom):
+        return self._lookup(node.conv, cg, 1)
 
 
-def pad_in_channels(w: torch.Tensor, cin: int) -> torch.Tensor:
-    """(Cout,Cin,k..) weight zero-padded to `cin` input channels — the 3-channel stems run on clips padded to 4
-    channels so their im2col gathers are 16-byte loads (INPUT_CHANNEL_PAD)."""
-    if w.shape[1] == cin:
-        return w
-    out = torch.zeros((w.shape[0], cin) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
-    out[:, :w.shape[1]] = w
-    return out
+class _CatConv:
+    """Stands in for a conv module where the engine / PackedWeights expect `.weight`: the concatenated filters of a group."""
+    weight: torch.Tensor = None
 
 
-def pad_weight(w: torch.Tensor, cout: int, cin: int) -> torch.Tensor:
-    """(Cout,Cin,k..) weight zero-padded to (cout, cin, k..)."""
-    if w.shape[0] == cout:
-        return pad_in_channels(w, cin)
-    out = torch.zeros((cout, cin) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
-    out[:w.shape[0], :w.shape[1]] = w
-    return out
+def _adjacent_cat(ts):
+    """If the tensors sit back to back in one storage (flat parameter / gradient buffers, rspnet_amd/flat.py), the single
+    tensor that covers them — dim 0 concatenated — else None."""
+    t0 = ts[0]
+    if not all(t.is_contiguous() and t.shape[1:] == t0.shape[1:] and t.dtype == t0.dtype for t in ts):
+        return None
+    end = t0.data_ptr() + t0.numel() * t0.element_size()
+    for t in ts[1:]:
+        if t.data_ptr() != end or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr():
+            return None
+        end += t.numel() * t.element_size()
+    shape = (sum(t.shape[0] for t in ts),) + tuple(t0.shape[1:])
+    stride = tuple(t0.stride())
+    return torch.as_strided(t0, shape, stride, t0.storage_offset())
 
 
 def _pad_vec(v: torch.Tensor, n: int, fill: float = 0.0) -> torch.Tensor:
@@ -164,47 +234,95 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
     be = _ops.backend()
     assert training or not keep, "eval-mode forward keeps nothing for backward"
     slots: Dict[int, torch.Tensor] = {plan.input_slot: x}
-    ctx = ForwardCtx() if keep else None
+    ctx = ForwardCtx(packed=packed) if keep else None
+    def bn_apply(node, y, ss, cg_cout, N, do, ho, wo, xin):
+        pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
+        pg = PoolGeom(N, do, ho, wo, cg_cout, pk, ps, (0, 0, 0))
+        res = slots[node.residual] if node.residual is not None else None
+        if node.into is not None:
+            pdo, pho, pwo = pg.out_dims
+            out = _view(_slice_of(slots, node.into, (N, pdo, pho, pwo), xin.device), node.into, cg_cout)
+            be.bn_act_pool_fwd(pg, y, ss, res, node.relu, out=out)
+        else:
+            slots[node.dst] = be.bn_act_pool_fwd(pg, y, ss, res, node.relu)
+        return pg, res
+
+    def convbn(node, key):
+        xin = slots[node.src]
+        N, D, H, W, Cin = xin.shape
+        w = node.conv.weight
+        Cout = w.shape[0]
+        Cp = node.cout_pad if node.cout_pad > Cout else Cout
+        cg = ConvGeom(N, D, H, W, Cin, Cp, node.k, node.s, node.p, Cin_alg=w.shape[1])
+        bias = getattr(node.conv, "bias", None)
+        bn = node.bn
+        bias_d = None if bias is None else (bias.data if Cp == Cout else _pad_vec(bias.data, Cp))
+        if training:
+            y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_d, True)
+            if Cp == Cout:
+                mi, ss = be.bn_finalize(stats, cg.rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps),
+                                        float(bn.momentum), bn.running_mean, bn.running_var)
+            else:
+                rm, rv = _pad_vec(bn.running_mean, Cp), _pad_vec(bn.running_var, Cp, 1.0)
+                mi, ss = be.bn_finalize(stats, cg.rows, bias_d, _pad_vec(bn.weight.data, Cp), _pad_vec(bn.bias.data, Cp),
+                                        float(bn.eps), float(bn.momentum), rm, rv)
+                bn.running_mean.copy_(rm[:Cout])
+                bn.running_var.copy_(rv[:Cout])
+        else:
+            y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), None, False)     # bias folded into the shift
+            ss = _eval_scale_shift(bn, bias)
+            mi = None
+            if Cp != Cout:
+                ss = torch.cat([ss, torch.zeros((2, Cp - Cout), dtype=ss.dtype, device=ss.device)], dim=1).contiguous()
+        do, ho, wo = cg.out_dims
+        pg, res = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin)
+        if keep:
+            ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, res)
+
+    def convbn_group(node, ni):
+        """One GEMM over the members' concatenated filters (see ConvBNGroup); falls back to member-by-member execution."""
+        ms = node.members
+        wcat = _adjacent_cat([m.conv.weight.data for m in ms]) if training else None
+        if wcat is None:
+            for j, m in enumerate(ms):
+                convbn(m, (ni, j))
+            return
+        xin = slots[ms[0].src]
+        N, D, H, W, Cin = xin.shape
+        if getattr(node, "_cat", None) is None:
+            node._cat = _CatConv()
+        node._cat.weight = wcat
+        cg = ConvGeom(N, D, H, W, Cin, wcat.shape[0], ms[0].k, ms[0].s, ms[0].p)
+        y, stats = be.conv_fwd(cg, xin, packed.get(node._cat_node(), cg), None, True)
+        do, ho, wo = cg.out_dims
+        off, per = 0, []
+        for m in ms:
+            C = m.conv.weight.shape[0]
+            bn = m.bn
+            mi, ss = be.bn_finalize(stats[:, off:off + C], cg.rows, None, bn.weight.data, bn.bias.data, float(bn.eps),
+                                    float(bn.momentum), bn.running_mean, bn.running_var)
+            pg, _ = bn_apply(m, y[..., off:off + C], ss, C, N, do, ho, wo, xin)
+            per.append((off, C, mi, ss, pg))
+            off += C
+        if keep:
+            ctx.saved[ni] = ("group", xin, y, cg, per)
+
     for ni, node in enumerate(plan.nodes):
         if isinstance(node, ConvBN):
+            convbn(node, ni)
+        elif isinstance(node, ConvBNGroup):
+            convbn_group(node, ni)
+        elif isinstance(node, ConvBias):
             xin = slots[node.src]
             N, D, H, W, Cin = xin.shape
             w = node.conv.weight
-            Cout = w.shape[0]
-            Cp = node.cout_pad if node.cout_pad > Cout else Cout
-            cg = ConvGeom(N, D, H, W, Cin, Cp, node.k, node.s, node.p, Cin_alg=w.shape[1])
-            bias = getattr(node.conv, "bias", None)
-            bn = node.bn
-            bias_d = None if bias is None else (bias.data if Cp == Cout else _pad_vec(bias.data, Cp))
-            if training:
-                y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_d, True)
-                if Cp == Cout:
-                    mi, ss = be.bn_finalize(stats, cg.rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps),
-                                            float(bn.momentum), bn.running_mean, bn.running_var)
-                else:
-                    rm, rv = _pad_vec(bn.running_mean, Cp), _pad_vec(bn.running_var, Cp, 1.0)
-                    mi, ss = be.bn_finalize(stats, cg.rows, bias_d, _pad_vec(bn.weight.data, Cp), _pad_vec(bn.bias.data, Cp),
-                                            float(bn.eps), float(bn.momentum), rm, rv)
-                    bn.running_mean.copy_(rm[:Cout])
-                    bn.running_var.copy_(rv[:Cout])
-            else:
-                y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), None, False)     # bias folded into the shift
-                ss = _eval_scale_shift(bn, bias)
-                mi = None
-                if Cp != Cout:
-                    ss = torch.cat([ss, torch.zeros((2, Cp - Cout), dtype=ss.dtype, device=ss.device)], dim=1).contiguous()
-            do, ho, wo = cg.out_dims
-            pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
-            pg = PoolGeom(N, do, ho, wo, cg.Cout, pk, ps, (0, 0, 0))
-            res = slots[node.residual] if node.residual is not None else None
-            if node.into is not None:
-                pdo, pho, pwo = pg.out_dims
-                out = _view(_slice_of(slots, node.into, (N, pdo, pho, pwo), xin.device), node.into, cg.Cout)
-                be.bn_act_pool_fwd(pg, y, ss, res, node.relu, out=out)
-            else:
-                slots[node.dst] = be.bn_act_pool_fwd(pg, y, ss, res, node.relu)
+            cg = ConvGeom(N, D, H, W, Cin, w.shape[0], node.k, node.s, node.p)
+            y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), node.conv.bias.data, False)
+            if node.relu:
+                y = be.eltwise("relu_fwd", y, out=y)
+            slots[node.dst] = y
             if keep:
-                ctx.saved[ni] = _Saved(xin, y, mi, ss, cg, pg, res)
+                ctx.saved[ni] = (xin, y, cg)
         elif isinstance(node, Pool):
             xin = slots[node.src]
             N, D, H, W, Cc = xin.shape
@@ -229,63 +347,113 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
     return out, ctx
 
 
-def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, after_param_grads=None):
+def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, after_param_grads=None,
+                 want_input_grad: bool = False, packed: Optional[PackedWeights] = None):
     """Backward through the plan.  `grad_of(param)` returns the (pre-allocated, flat-buffer) gradient view to
     fill for a parameter, or None to skip it.  `after_param_grads(node_index)` is called once a node's parameter
-    gradients are complete (used to launch bucketed all-reduces overlapped with the rest of backward)."""
+    gradients are complete (used to launch bucketed all-reduces overlapped with the rest of backward).
+    want_input_grad: also propagate to the plan's input slot and return that gradient (projection-head sub-plans, whose
+    input is the backbone feature; the backbone's own input is the clip and needs none)."""
     be = _ops.backend()
+    packed = packed if packed is not None else ctx.packed
     dslots: Dict[int, torch.Tensor] = {plan.output_slot: dfeat}
 
     def add_grad(slot, g):
+        # gradient accumulation at fan-out points; g is always the fresh output of the op that produced it, so the sum is
+        # written over it (no allocation, nothing else aliases it)
         if g is None:
             return
         if slot in dslots:
-            dslots[slot] = dslots[slot] + g
+            dslots[slot] = be.eltwise("add", dslots[slot].contiguous(), g, out=g)
         else:
             dslots[slot] = g
+
+    def convbn_bwd(node, key, ni):
+        sv = ctx.saved.pop(key)
+        if node.into is not None:
+            dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout)
+        else:
+            dout = dslots.pop(node.dst)
+        bn = node.bn
+        Cout, Cp = node.conv.weight.shape[0], sv.cg.Cout
+        if Cp == Cout:
+            dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
+                                          node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
+        else:
+            dgam = torch.empty(Cp, dtype=torch.float32, device=dout.device)
+            dbet = torch.empty(Cp, dtype=torch.float32, device=dout.device)
+            dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, _pad_vec(bn.weight.data, Cp), sv.mi, sv.ss, node.relu,
+                                          node.residual is not None, dgam, dbet)
+            for g, src in ((grad_of(bn.weight), dgam), (grad_of(bn.bias), dbet)):
+                if g is not None:
+                    g.copy_(src[:Cout])
+        if node.residual is not None:
+            add_grad(node.residual, dres)
+        bias = getattr(node.conv, "bias", None)
+        if bias is not None:
+            gb = grad_of(bias)
+            if gb is not None:
+                # A conv bias in front of train-mode BatchNorm has an identically-zero gradient (BN subtracts the
+                # batch mean); the reference's autograd produces ~1e-8 rounding noise there.
+                gb.zero_()
+        gw = grad_of(node.conv.weight)
+        if gw is not None and (gw.shape[1] != sv.cg.Cin or gw.shape[0] != Cp):   # channel-padded: drop the pad gradients
+            gpad = torch.empty((Cp, sv.cg.Cin) + tuple(gw.shape[2:]), dtype=gw.dtype, device=gw.device)
+            be.conv_wgrad(sv.cg, sv.x, dy, gpad)
+            gw.copy_(gpad[:gw.shape[0], :gw.shape[1]])
+        else:
+            be.conv_wgrad(sv.cg, sv.x, dy, gw)
+        if after_param_grads is not None:
+            after_param_grads(ni)
+        if node.src != plan.input_slot or want_input_grad:
+            add_grad(node.src, be.conv_dgrad_packed(sv.cg, dy, packed.get_dgrad(node, sv.cg)))
+
+    def convbn_group_bwd(node, ni):
+        sv = ctx.saved.pop(ni, None)
+        ms = node.members
+        if sv is None:                                   # forward ran the members one by one
+            for j in range(len(ms) - 1, -1, -1):
+                convbn_bwd(ms[j], (ni, j), ni)
+            return
+        _, xin, y, cg, per = sv
+        dy_cat = torch.empty_like(y)
+        for m, (off, C, mi, ss, pg) in zip(ms, per):
+            dout = _view(dslots[m.into[0]], m.into, C) if m.into is not None else dslots.pop(m.dst)
+            be.bn_act_pool_bwd(pg, y[..., off:off + C], None, dout, m.bn.weight.data, mi, ss, m.relu, False,
+                               grad_of(m.bn.weight), grad_of(m.bn.bias), dy_out=dy_cat[..., off:off + C])
+        gws = [grad_of(m.conv.weight) for m in ms]
+        gcat = _adjacent_cat(gws) if all(g is not None for g in gws) else None
+        if gcat is not None:
+            be.conv_wgrad(cg, xin, dy_cat, gcat)
+        else:
+            tmp = torch.empty_like(node._cat.weight)
+            be.conv_wgrad(cg, xin, dy_cat, tmp)
+            off = 0
+            for m, g in zip(ms, gws):
+                if g is not None:
+                    g.copy_(tmp[off:off + g.shape[0]])
+                off += m.conv.weight.shape[0]
+        if after_param_grads is not None:
+            after_param_grads(ni)
+        if ms[0].src != plan.input_slot or want_input_grad:
+            add_grad(ms[0].src, be.conv_dgrad_packed(cg, dy_cat, packed.get_dgrad(node._cat_node(), cg)))
 
     for ni in range(len(plan.nodes) - 1, -1, -1):
         node = plan.nodes[ni]
         if isinstance(node, ConvBN):
-            sv = ctx.saved.pop(ni)
-            if node.into is not None:
-                dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout)
-            else:
-                dout = dslots.pop(node.dst)
-            bn = node.bn
-            Cout, Cp = node.conv.weight.shape[0], sv.cg.Cout
-            if Cp == Cout:
-                dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
-                                              node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
-            else:
-                dgam = torch.empty(Cp, dtype=torch.float32, device=dout.device)
-                dbet = torch.empty(Cp, dtype=torch.float32, device=dout.device)
-                dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, _pad_vec(bn.weight.data, Cp), sv.mi, sv.ss, node.relu,
-                                              node.residual is not None, dgam, dbet)
-                for g, src in ((grad_of(bn.weight), dgam), (grad_of(bn.bias), dbet)):
-                    if g is not None:
-                        g.copy_(src[:Cout])
-            if node.residual is not None:
-                add_grad(node.residual, dres)
-            bias = getattr(node.conv, "bias", None)
-            if bias is not None:
-                gb = grad_of(bias)
-                if gb is not None:
-                    # A conv bias in front of train-mode BatchNorm has an identically-zero gradient (BN subtracts the
-                    # batch mean); the reference's autograd produces ~1e-8 rounding noise there.
-                    gb.zero_()
-            gw = grad_of(node.conv.weight)
-            if gw is not None and (gw.shape[1] != sv.cg.Cin or gw.shape[0] != Cp):   # channel-padded: drop the pad gradients
-                gpad = torch.empty((Cp, sv.cg.Cin) + tuple(gw.shape[2:]), dtype=gw.dtype, device=gw.device)
-                be.conv_wgrad(sv.cg, sv.x, dy, gpad)
-                gw.copy_(gpad[:gw.shape[0], :gw.shape[1]])
-            else:
-                be.conv_wgrad(sv.cg, sv.x, dy, gw)
+            convbn_bwd(node, ni, ni)
+        elif isinstance(node, ConvBNGroup):
+            convbn_group_bwd(node, ni)
+        elif isinstance(node, ConvBias):
+            xin, y, cg = ctx.saved.pop(ni)
+            dout = dslots.pop(node.dst)
+            dz = be.eltwise("relu_bwd", y, dout.contiguous()) if node.relu else dout.contiguous()
+            be.conv_wgrad(cg, xin, dz, grad_of(node.conv.weight), grad_of(node.conv.bias))
             if after_param_grads is not None:
                 after_param_grads(ni)
-            if node.src != plan.input_slot:
-                add_grad(node.src, be.conv_dgrad(sv.cg, dy, pad_weight(node.conv.weight.data, Cp, sv.cg.Cin)))
-            del dy, dout, sv
+            if node.src != plan.input_slot or want_input_grad:
+                add_grad(node.src, be.conv_dgrad_packed(cg, dz, packed.get_dgrad(node, cg)))
+            del dz, dout
         elif isinstance(node, Pool):
             pg, idx = ctx.saved.pop(ni)
             add_grad(node.src, be.maxpool_bwd(pg, dslots.pop(node.dst), idx))
@@ -299,3 +467,4 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 after_param_grads(ni)
         else:
             raise NotImplementedError(f"plan node {type(node).__name__}")
+    return dslots.get(plan.input_slot) if want_input_grad else None

@@ -19,9 +19,28 @@ ALIGN = 4  # floats: every view starts on a 16-byte boundary
 
 
 class FlatEncoderPair:
-    def __init__(self, enc_q: nn.Module, enc_k: nn.Module, untrained_prefixes: Tuple[str, ...]):
+    def __init__(self, enc_q: nn.Module, enc_k: nn.Module, untrained_prefixes: Tuple[str, ...],
+                 adjacent: Tuple[Tuple[str, ...], ...] = ()):
+        """adjacent: groups of parameter names that must sit back to back (in the given order, no padding between them) so
+        that the group is ONE contiguous tensor — the filters of convolutions that run as a single GEMM (S3D-G's inception
+        siblings).  Every member's numel must be a multiple of ALIGN."""
         self.enc_q, self.enc_k = enc_q, enc_k
         names = [n for n, _ in enc_q.named_parameters()]
+        follower = {}
+        for grp in adjacent:
+            for a, b in zip(grp[:-1], grp[1:]):
+                follower[a] = b
+        placed_later = set(follower.values())
+        ordered = []
+        for n in names:
+            if n in placed_later:
+                continue
+            ordered.append(n)
+            while ordered[-1] in follower:
+                ordered.append(follower[ordered[-1]])
+        assert sorted(ordered) == sorted(names)
+        names = ordered
+        self.adjacent = tuple(tuple(g) for g in adjacent)
         trained = [n for n in names if not n.startswith(untrained_prefixes)]
         untrained = [n for n in names if n.startswith(untrained_prefixes)]
         self.names: List[str] = trained + untrained
@@ -75,6 +94,18 @@ class FlatEncoderPair:
 
     def grad_of(self, p: nn.Parameter):
         return self.grad_views.get(id(p))
+
+    def group_view(self, which: str, names, shape):
+        """One tensor over the adjacent parameters `names`: which = 'q' / 'k' weights or 'g' gradients."""
+        off0, _ = self.offsets[names[0]]
+        total, off = 0, off0
+        for n in names:
+            o, numel = self.offsets[n]
+            assert o == off and numel % ALIGN == 0, f"{n} is not adjacent to its group (flat layout)"
+            off += numel
+            total += numel
+        flat = {"q": self.q_flat, "k": self.k_flat, "g": self.g_flat}[which]
+        return flat[off0:off0 + total].view(shape)
 
     def attach_grads(self):
         """Make .grad of every trained parameter the view into the flat gradient buffer."""

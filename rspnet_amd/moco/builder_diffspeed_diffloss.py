@@ -151,7 +151,8 @@ class MoCoDiffLossTwoFc(nn.Module):
 
     def _prepare(self):
         if self._flat is None:
-            self._flat = FlatEncoderPair(self.encoder_q, self.encoder_k, self.encoder_q.untrained_prefixes())
+            self._flat = FlatEncoderPair(self.encoder_q, self.encoder_k, self.encoder_q.untrained_prefixes(),
+                                         adjacent=self.encoder_q.adjacent_parameters())
             self._q_params = list(self.encoder_q.parameters())
         self._flat.ensure()
         self._tie_num_batches_tracked()
@@ -243,8 +244,8 @@ class MoCoDiffLossTwoFc(nn.Module):
 
     @torch.no_grad()
     def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
-        """Key pass with shuffle-BN (:408-419) under the global permutation `idx`.  Returns (features of my samples in my
-        order (B,2*dim), features of ALL samples in global order (B*ws, 2*dim))."""
+        """Key pass with shuffle-BN (:408-419) under the global permutation `idx`.  Returns (features [A | M] of my samples in
+        my order, features of ALL samples in global order (B*ws rows), width of the A part)."""
         be = _ops.backend()
         rank, ws = _world()
         B = im.shape[0]
@@ -285,7 +286,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             gathered = feats
         loc_t = torch.from_numpy(loc.astype(np.int32)).to(dev, non_blocking=True)
         all_feats = be.rows_gather(gathered, loc_t)
-        return all_feats[rank * B:(rank + 1) * B], all_feats
+        return all_feats[rank * B:(rank + 1) * B], all_feats, a.shape[1]
 
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys_all: Tensor):
@@ -351,9 +352,8 @@ class MoCoDiffLossTwoFc(nn.Module):
             step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
             step_q[random_indices[:n1].to(dev)] = 1                      # s1 rows play q,k at normal speed
             step_kn = (1 + speed) - step_q if speed != 1 else step_q.clone()   # k_negative swaps the speeds
-            kneg_mine, kneg_all = self._forward_encoder_k(im_k, step_kn, T_real, sh1)
-            k_mine, _ = self._forward_encoder_k(im_k, step_q, T_real, sh2)
-            dim = kneg_mine.shape[1] // 2
+            kneg_mine, kneg_all, dim = self._forward_encoder_k(im_k, step_kn, T_real, sh1)
+            k_mine, _, _ = self._forward_encoder_k(im_k, step_q, T_real, sh2)
             k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
             kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
             src = torch.arange(B, dtype=torch.int32, device=dev)

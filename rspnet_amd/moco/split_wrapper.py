@@ -1,8 +1,11 @@
 """MultiTaskWrapper: backbone + two projection heads (A-VID, RSP), L2-normalised outputs.
 
-Mirror of /root/reference/moco/split_wrapper.py:66-190 for the pretext configuration (finetune=False, groups=1,
-fc_type 'linear' / 'mlp').  Heads keep the reference's Sequential(pool, Flatten, Linear) container so the state-dict keys
-are ``fc1.2.weight`` etc.; the pool+linear+normalize arithmetic is one HIP kernel (rsp_head_fwd).
+Mirror of /root/reference/moco/split_wrapper.py:66-190 for the pretext configuration (finetune=False, groups=1) with every
+`fc_type` the reference accepts: 'linear' (the shipped configs), 'mlp', 'conv' (ConvFc :18-39), 'convbn' (ConvBnFc :42-63) and
+'speednet' (second head = Linear(feat,1) + sigmoid, :125-126,146-147).  Heads keep the reference's containers so the
+state-dict keys are ``fc1.2.weight`` / ``fc1.conv1.weight`` / ``fc1.bn.running_mean`` ....  For 'linear' the
+pool+linear+normalize arithmetic is one HIP kernel (rsp_head_fwd); the other types are composed from the generic pieces
+(engine sub-plan for the head's convolutions, spatial mean, linear, l2-norm / sigmoid).
 
 finetune=True (split_wrapper.py:104-106,131-135, built by models/__init__.py:125-143) is the downstream
 classifier: backbone -> AdaptiveAvgPool3d(1) -> Linear(feat, num_classes).  Its forward is a regular autograd node
@@ -15,12 +18,47 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops as _ops
-from ..engine import INPUT_CHANNEL_PAD, PackedWeights, run_backward, run_forward
+from ..engine import INPUT_CHANNEL_PAD, ConvBN, ConvBias, PackedWeights, Plan, run_backward, run_forward
+
+FC_TYPES = ("linear", "mlp", "conv", "convbn", "speednet")
 
 
 class Flatten(nn.Module):
     def forward(self, x: Tensor):
         return x.flatten(1)
+
+
+class ConvFc(nn.Module):
+    """conv -> relu -> conv -> global average -> linear (parameter holder; split_wrapper.py:18-39)."""
+
+    def __init__(self, feat_dim: int, moco_dim: int, kernel_size, padding):
+        super().__init__()
+        self.conv1 = nn.Conv3d(feat_dim, feat_dim, kernel_size, padding=padding)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv3d(feat_dim, feat_dim, kernel_size, padding=padding)
+        self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.linear = nn.Linear(feat_dim, moco_dim)
+        self.kernel_size, self.padding = tuple(kernel_size), tuple(padding)
+
+    def plan(self) -> Plan:
+        return Plan([ConvBias(self.conv1, 0, 1, self.kernel_size, (1, 1, 1), self.padding, relu=True),
+                     ConvBias(self.conv2, 1, 2, self.kernel_size, (1, 1, 1), self.padding, relu=False)], 0, 2)
+
+
+class ConvBnFc(nn.Module):
+    """conv -> bn -> relu -> global average -> linear (parameter holder; split_wrapper.py:42-63)."""
+
+    def __init__(self, feat_dim: int, moco_dim: int, kernel_size, padding):
+        super().__init__()
+        self.conv1 = nn.Conv3d(feat_dim, feat_dim, kernel_size, padding=padding)
+        self.bn = nn.BatchNorm3d(feat_dim)
+        self.relu = nn.ReLU(inplace=True)
+        self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.linear = nn.Linear(feat_dim, moco_dim)
+        self.kernel_size, self.padding = tuple(kernel_size), tuple(padding)
+
+    def plan(self) -> Plan:
+        return Plan([ConvBN(self.conv1, self.bn, 0, 1, self.kernel_size, (1, 1, 1), self.padding, relu=True)], 0, 1)
 
 
 class MultiTaskWrapper(nn.Module):
@@ -29,9 +67,9 @@ class MultiTaskWrapper(nn.Module):
         super().__init__()
         if groups != 1:
             raise NotImplementedError("groups != 1 is not used by any shipped pretext config")
-        if fc_type not in ("linear", "mlp"):
-            raise NotImplementedError(f"fc_type '{fc_type}': the pretext configs use 'linear' (moco-train-base.jsonnet:35) "
-                                      "or 'mlp'; conv/convbn/speednet heads are not used by any shipped config")
+        if not finetune and fc_type not in FC_TYPES:
+            # the reference silently builds no heads for an unknown type and fails in forward (split_wrapper.py:107-126,138)
+            raise ValueError(f"unknown fc_type '{fc_type}' (expected one of {FC_TYPES})")
         self.finetune = finetune
         self.moco_dim = num_classes
         self.num_classes = num_classes
@@ -45,9 +83,17 @@ class MultiTaskWrapper(nn.Module):
             self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1))
             self.fc = nn.Linear(feat_dim, num_classes)
         else:
-            make = self._get_linear_fc if fc_type == "linear" else self._get_mlp_fc
-            self.fc1 = make(feat_dim, self.moco_dim)
-            self.fc2 = make(feat_dim, self.moco_dim)
+            if fc_type in ("linear", "mlp"):
+                make = self._get_linear_fc if fc_type == "linear" else self._get_mlp_fc
+                self.fc1 = make(feat_dim, self.moco_dim)
+                self.fc2 = make(feat_dim, self.moco_dim)
+            elif fc_type in ("conv", "convbn"):
+                cls = ConvFc if fc_type == "conv" else ConvBnFc
+                self.fc1 = cls(feat_dim, self.moco_dim, (3, 3, 3), (1, 1, 1))
+                self.fc2 = cls(feat_dim, self.moco_dim, (3, 3, 3), (1, 1, 1))
+            else:   # speednet: the second head is a 1-d speed-up probability (split_wrapper.py:124-126)
+                self.fc1 = self._get_linear_fc(feat_dim, self.moco_dim)
+                self.fc2 = self._get_linear_fc(feat_dim, 1)
 
         self._plan = None
         self._packed = PackedWeights()
@@ -80,6 +126,11 @@ class MultiTaskWrapper(nn.Module):
     def untrained_prefixes(self):
         return tuple("encoder." + n + "." for n in getattr(self.encoder, "classifier_names", ()))
 
+    def adjacent_parameters(self):
+        """Parameter groups the flat buffers should keep contiguous (engine.ConvBNGroup)."""
+        fn = getattr(self.encoder, "adjacent_parameters", None)
+        return tuple(tuple("encoder." + n for n in g) for g in fn()) if fn is not None else ()
+
     # ---- execution ---------------------------------------------------------------------------------------------
     def plan(self):
         if self._plan is None:
@@ -94,42 +145,64 @@ class MultiTaskWrapper(nn.Module):
         be = _ops.backend()
         feat, ctx = run_forward(self.plan(), x, self._packed, keep)
         self.feat = feat
-        if self.fc_type == "mlp":
-            pooled = be.spatial_mean_fwd(feat)
-            outs, saved = [], []
-            for fc in (self.fc1, self.fc2):
+        if self.fc_type == "linear":
+            l1, l2 = self.fc1[2], self.fc2[2]
+            x1, x2, pooled, raw = be.head_fwd(feat, l1.weight.data, l1.bias.data, l2.weight.data, l2.bias.data)
+            if keep:
+                ctx.head = (pooled, raw)
+            return x1, x2, ctx
+        # generic composition: [head convolutions] -> spatial mean -> linear [-> relu -> linear] -> l2-norm | sigmoid
+        pooled_feat = be.spatial_mean_fwd(feat) if self.fc_type in ("mlp", "speednet") else None
+        outs, saved = [], []
+        for hi, fc in enumerate((self.fc1, self.fc2)):
+            hctx = hid = None
+            if self.fc_type in ("conv", "convbn"):
+                h, hctx = run_forward(fc.plan(), feat, self._packed, keep)
+                pooled = be.spatial_mean_fwd(h)
+                raw = be.linear_fwd(pooled, fc.linear.weight.data, fc.linear.bias.data, False)
+                hshape = tuple(h.shape)
+            elif self.fc_type == "mlp":
+                pooled, hshape = pooled_feat, None
                 hid = be.linear_fwd(pooled, fc[2].weight.data, fc[2].bias.data, True)
                 raw = be.linear_fwd(hid, fc[4].weight.data, fc[4].bias.data, False)
-                outs.append(be.l2norm_fwd(raw))
-                saved.append((hid, raw))
-            if keep:
-                ctx.head = (pooled, saved)
-            return outs[0], outs[1], ctx
-        l1, l2 = self.fc1[2], self.fc2[2]
-        x1, x2, pooled, raw = be.head_fwd(feat, l1.weight.data, l1.bias.data, l2.weight.data, l2.bias.data)
+            else:
+                pooled, hshape = pooled_feat, None
+                raw = be.linear_fwd(pooled, fc[2].weight.data, fc[2].bias.data, False)
+            sig = self.fc_type == "speednet" and hi == 1
+            out = be.eltwise("sigmoid_fwd", raw) if sig else be.l2norm_fwd(raw)
+            outs.append(out)
+            saved.append((hctx, hshape, pooled, hid, raw, out))
         if keep:
-            ctx.head = (pooled, raw)
-        return x1, x2, ctx
+            ctx.head = saved
+        return outs[0], outs[1], ctx
 
     def backward_ndhwc(self, ctx, d1: Tensor, d2: Tensor, grad_of, after_param_grads=None):
         be = _ops.backend()
-        if self.fc_type == "mlp":
-            pooled, saved = ctx.head
-            dpooled = None
-            for fc, (hid, raw), d in ((self.fc1, saved[0], d1), (self.fc2, saved[1], d2)):
-                draw = be.l2norm_bwd(raw, d.contiguous())
-                dhid = be.linear_bwd(hid, raw, draw, fc[4].weight.data, False, grad_of(fc[4].weight), grad_of(fc[4].bias))
-                dp = be.linear_bwd(pooled, hid, dhid, fc[2].weight.data, True, grad_of(fc[2].weight), grad_of(fc[2].bias))
-                dpooled = dp if dpooled is None else dpooled + dp
-            dfeat = be.spatial_mean_bwd(dpooled, ctx.feat_shape)
-            if after_param_grads is not None:
-                after_param_grads(-1)
-            run_backward(self.plan(), ctx, dfeat, grad_of, after_param_grads)
-            return
-        l1, l2 = self.fc1[2], self.fc2[2]
-        pooled, raw = ctx.head
-        dfeat = be.head_bwd(d1.contiguous(), d2.contiguous(), pooled, raw, l1.weight.data, l2.weight.data, ctx.feat_shape,
-                            grad_of(l1.weight), grad_of(l1.bias), grad_of(l2.weight), grad_of(l2.bias))
+        if self.fc_type == "linear":
+            l1, l2 = self.fc1[2], self.fc2[2]
+            pooled, raw = ctx.head
+            dfeat = be.head_bwd(d1.contiguous(), d2.contiguous(), pooled, raw, l1.weight.data, l2.weight.data, ctx.feat_shape,
+                                grad_of(l1.weight), grad_of(l1.bias), grad_of(l2.weight), grad_of(l2.bias))
+        else:
+            dfeat = dpooled_feat = None
+            for hi, (fc, (hctx, hshape, pooled, hid, raw, out), d) in enumerate(zip((self.fc1, self.fc2), ctx.head, (d1, d2))):
+                sig = self.fc_type == "speednet" and hi == 1
+                draw = be.eltwise("sigmoid_bwd", out, d.contiguous()) if sig else be.l2norm_bwd(raw, d.contiguous())
+                if self.fc_type in ("conv", "convbn"):
+                    lin = fc.linear
+                    dp = be.linear_bwd(pooled, raw, draw, lin.weight.data, False, grad_of(lin.weight), grad_of(lin.bias))
+                    dh = be.spatial_mean_bwd(dp, hshape)
+                    g = run_backward(fc.plan(), hctx, dh, grad_of, None, want_input_grad=True)
+                    dfeat = g if dfeat is None else be.eltwise("add", dfeat, g, out=g)
+                    continue
+                if self.fc_type == "mlp":
+                    dhid = be.linear_bwd(hid, raw, draw, fc[4].weight.data, False, grad_of(fc[4].weight), grad_of(fc[4].bias))
+                    dp = be.linear_bwd(pooled, hid, dhid, fc[2].weight.data, True, grad_of(fc[2].weight), grad_of(fc[2].bias))
+                else:
+                    dp = be.linear_bwd(pooled, raw, draw, fc[2].weight.data, False, grad_of(fc[2].weight), grad_of(fc[2].bias))
+                dpooled_feat = dp if dpooled_feat is None else be.eltwise("add", dpooled_feat, dp, out=dp)
+            if dfeat is None:
+                dfeat = be.spatial_mean_bwd(dpooled_feat, ctx.feat_shape)
         if after_param_grads is not None:
             after_param_grads(-1)
         run_backward(self.plan(), ctx, dfeat, grad_of, after_param_grads)

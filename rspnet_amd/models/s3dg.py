@@ -10,7 +10,7 @@ from collections import OrderedDict
 
 from torch import nn
 
-from ..engine import ConvBN, Gate, Plan, Pool
+from ..engine import ConvBN, ConvBNGroup, Gate, Plan, Pool
 
 
 class BasicConv3d(nn.Module):
@@ -107,11 +107,23 @@ class S3D_G(nn.Module):
                 total = sum(m.widths)
                 cat = new()
                 offs = [0, m.widths[0], m.widths[0] + m.widths[1], m.widths[0] + m.widths[1] + m.widths[2]]
+                # the three pointwise convs that read the block input run as one GEMM when their filters are adjacent
+                first = len(nodes)
                 basic(m.branch0, cur, into=(cat, offs[0], total))
-                sep(m.branch1[1], basic(m.branch1[0], cur), into=(cat, offs[1], total))
-                sep(m.branch2[1], basic(m.branch2[0], cur), into=(cat, offs[2], total))
+                b1 = basic(m.branch1[0], cur)
+                b2 = basic(m.branch2[0], cur)
+                nodes[first:] = [ConvBNGroup(nodes[first:])]
+                sep(m.branch1[1], b1, into=(cat, offs[1], total))
+                sep(m.branch2[1], b2, into=(cat, offs[2], total))
                 pooled = new()
                 nodes.append(Pool(cur, pooled, (3, 3, 3), (1, 1, 1), (1, 1, 1)))
                 basic(m.branch3[1], pooled, into=(cat, offs[3], total))
                 cur = cat
         return Plan(nodes, input_slot=0, output_slot=cur)
+
+    def adjacent_parameters(self):
+        """Parameter groups (names relative to this module) the flat layout should place back to back: the filters of each
+        inception block's three pointwise convolutions on the block input (models/s3dg.py:80-88)."""
+        return tuple((f"feature.{name}.branch0.conv3d.weight", f"feature.{name}.branch1.0.conv3d.weight",
+                      f"feature.{name}.branch2.0.conv3d.weight")
+                     for name, m in self.feature.named_children() if isinstance(m, sep_inc))

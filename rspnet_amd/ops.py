@@ -156,14 +156,17 @@ class HipOps:
             e1.record()
             self.event_log.append((kind, flops, e0, e1, kernel))
 
-    # one grow-only scratch buffer per device; kernels on one stream are serialised so it can be shared
+    # one grow-only scratch buffer per (device, stream): kernels on one stream are serialised, so they can share it; work issued
+    # on different streams (independent branches of a layer graph) must not
     def _workspace(self, dev, nbytes: int) -> torch.Tensor:
-        buf = self._ws.get(dev)
+        stream = torch.cuda.current_stream(dev)
+        key = (dev, stream.cuda_stream)
+        buf = self._ws.get(key)
         if buf is None or buf.numel() < nbytes:
             if buf is not None:
-                buf.record_stream(torch.cuda.current_stream(dev))
+                buf.record_stream(stream)
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
-            self._ws[dev] = buf
+            self._ws[key] = buf
         return buf
 
     # ---- conv -------------------------------------------------------------------------------------------------
@@ -203,6 +206,24 @@ class HipOps:
         self._log("conv_dgrad", g.flops, e0, names[1])
         return dx
 
+    def conv_dgrad_packed(self, g: ConvGeom, dy, w_packed):
+        """dgrad over weights re-packed by a PackSet (which=1 entry)."""
+        _chk(dy, "dy")
+        d, dref, _, _, wsb, _, _, names = _conv_plan(0, g, None, None)
+        dx = torch.empty((g.N, g.Di, g.Hi, g.Wi, g.Cin), dtype=torch.float32, device=dy.device)
+        ws = self._workspace(dy.device, wsb)
+        e0 = self._ev()
+        _lib.check(self.lib.rsp_conv3d_dgrad_packed(dref, _ptr(dy), _ptr(_chk(w_packed, "w_packed")), _ptr(dx), _ptr(ws), wsb,
+                                                    _stream()), "rsp_conv3d_dgrad_packed")
+        self._log("conv_dgrad", g.flops, e0, names[1])
+        return dx
+
+    def pack_set(self, entries):
+        """entries: list of (ConvGeom, which, w_ref) with which = 0 (forward layout) / 1 (dgrad layouts) and w_ref the LIVE
+        reference-layout weight tensor (it may have fewer channels than the geometry: zero padding).  Allocates the packed
+        buffers and the device job table once; PackSet.run() re-packs all of them with one launch."""
+        return PackSet(self, entries)
+
     def conv_wgrad(self, g: ConvGeom, x, dy, dw_out: torch.Tensor, dbias_out: Optional[torch.Tensor] = None):
         """dw_out (Cout,Cin,kT,kH,kW) and dbias_out are written in place (they are views of the flat grad buffer)."""
         _chk(x, "x")
@@ -218,32 +239,46 @@ class HipOps:
     # ---- batch norm -------------------------------------------------------------------------------------------
     def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,
                     running_var):
-        _chk(stats, "stats")
         tiles, Cc, _ = stats.shape
+        if stats.is_contiguous():
+            _chk(stats, "stats")
+            stat_ld = Cc
+        else:      # channel slice of a wider convolution's partials
+            if not stats.is_cuda or stats.dtype != torch.float32 or stats.stride(2) != 1 or stats.stride(1) != 2 or stats.stride(0) % 2:
+                raise _lib.RspError("stats: expected [tiles][C][2] float32 partials or a channel slice of them")
+            stat_ld = stats.stride(0) // 2
         mi = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
         ss = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
         wsb = (64 if tiles >= 4096 else (16 if tiles >= 64 else 1)) * Cc * 16   # == rsp_bn_finalize_workspace(tiles, Cc)
         ws = self._workspace(stats.device, wsb)
-        _lib.check(self.lib.rsp_bn_finalize(_ptr(stats), tiles, Cc, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta), eps,
+        _lib.check(self.lib.rsp_bn_finalize(_ptr(stats), tiles, Cc, stat_ld, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta), eps,
                                             momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi), _ptr(ss), _ptr(ws),
                                             wsb, _stream()), "rsp_bn_finalize")
         return mi, ss
 
     def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu: bool, out=None):
-        _chk(y, "y")
+        in_ld = _rows_ld(y, "y")             # y may be a channel slice of a wider conv output
         if out is None:
             do, ho, wo = pg.out_dims
             out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
-        d, dref, _, _ = _pool_plan(0, pg, None, _rows_ld(out, "out"), None if residual is None else _rows_ld(residual, "residual"))
+        d, dref, _, _ = _pool_plan(0, pg, in_ld, _rows_ld(out, "out"), None if residual is None else _rows_ld(residual, "residual"))
         _lib.check(self.lib.rsp_bn_act_pool_fwd(dref, _ptr(y), _ptr(scale_shift), _ptr(residual), int(relu), _ptr(out),
                                                 _stream()), "rsp_bn_act_pool_fwd")
         return out
 
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu: bool,
-                        want_dres: bool, dgamma_out, dbeta_out):
-        _chk(y, "y")
-        d, dref, wsb, _ = _pool_plan(0, pg, None, _rows_ld(dout, "dout"), None if residual is None else _rows_ld(residual, "residual"))
-        dy = torch.empty_like(y)
+                        want_dres: bool, dgamma_out, dbeta_out, dy_out=None):
+        """dy_out: where to write dy (same channel pitch as y — a slice of a wider gradient tensor when y is a slice)."""
+        in_ld = _rows_ld(y, "y")
+        d, dref, wsb, _ = _pool_plan(0, pg, in_ld, _rows_ld(dout, "dout"), None if residual is None else _rows_ld(residual, "residual"))
+        if dy_out is not None:
+            if _rows_ld(dy_out, "dy_out") != in_ld or dy_out.shape != y.shape:
+                raise _lib.RspError("dy_out: expected the shape and channel pitch of y")
+            dy = dy_out
+        else:
+            if not y.is_contiguous():
+                raise _lib.RspError("y is a channel slice: pass dy_out with the same pitch")
+            dy = torch.empty_like(y)
         dres = torch.empty_like(y) if want_dres else None
         ws = self._workspace(y.device, wsb)
         _lib.check(self.lib.rsp_bn_act_pool_bwd(dref, _ptr(y), _ptr(residual), _ptr(dout), _ptr(gamma),
@@ -375,7 +410,7 @@ class HipOps:
         lp = torch.empty((B, 1), dtype=torch.float32, device=dev)
         ln = torch.empty((B, 1), dtype=torch.float32, device=dev)
         _lib.check(self.lib.rsp_logits_fwd(_ptr(qA), _ptr(qM), _ptr(kA), _ptr(kM), _ptr(knegA), _ptr(knegM), _ptr(queue), B,
-                                           dim, K, inv_T, _ptr(l1), _ptr(l2), _ptr(lp), _ptr(ln), _stream()),
+                                           dim, qM.shape[1], K, inv_T, _ptr(l1), _ptr(l2), _ptr(lp), _ptr(ln), _stream()),
                    "rsp_logits_fwd")
         return l1, l2, lp, ln
 
@@ -384,12 +419,12 @@ class HipOps:
         K = queue.shape[1]
         dev = kA.device
         dqA = torch.empty((B, dim), dtype=torch.float32, device=dev)
-        dqM = torch.empty((B, dim), dtype=torch.float32, device=dev)
+        dqM = torch.empty((B, kM.shape[1]), dtype=torch.float32, device=dev)
         wsb = self.lib.rsp_logits_bwd_workspace(B, dim, K)
         ws = self._workspace(dev, wsb)
         _lib.check(self.lib.rsp_logits_bwd(_ptr(_chk(dl1, "dl1")), _ptr(_chk(dl2, "dl2")), _ptr(_chk(dlp, "dlp")),
                                            _ptr(_chk(dln, "dln")), _ptr(kA), _ptr(kM), _ptr(knegA), _ptr(knegM), _ptr(queue),
-                                           B, dim, K, inv_T, _ptr(dqA), _ptr(dqM), _ptr(ws), wsb, _stream()),
+                                           B, dim, kM.shape[1], K, inv_T, _ptr(dqA), _ptr(dqM), _ptr(ws), wsb, _stream()),
                    "rsp_logits_bwd")
         return dqA, dqM
 
@@ -443,6 +478,19 @@ class HipOps:
         _lib.check(self.lib.rsp_rows_gather(_ptr(x), _ptr(idx), n, width, _ptr(out), _stream()), "rsp_rows_gather")
         return out
 
+    def eltwise(self, op: str, a, b=None, out=None):
+        """op in relu_fwd / relu_bwd / sigmoid_fwd / sigmoid_bwd / add; dense tensors, `out` may alias an input."""
+        code = {"relu_fwd": 0, "relu_bwd": 1, "sigmoid_fwd": 2, "sigmoid_bwd": 3, "add": 4}[op]
+        _chk(a, "a")
+        if b is not None:
+            _chk(b, "b")
+            if b.shape != a.shape:
+                raise _lib.RspError(f"eltwise {op}: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        if out is None:
+            out = torch.empty_like(a)
+        _lib.check(self.lib.rsp_eltwise(code, _ptr(a), _ptr(b), _ptr(_chk(out, "out")), a.numel(), _stream()), "rsp_eltwise")
+        return out
+
     # ---- clip augmentation (SURVEY.md §8f-2) ---------------------------------------------------------------------------
     def augment_batch(self, descs, n_clips, T, size, mean, std, out, blur9=None):
         """descs: uint8 device tensor holding n_clips rsp_augment_clip_desc records; out: (n_clips, 3, T, size, size) f32."""
@@ -457,6 +505,37 @@ class HipOps:
         _lib.check(self.lib.rsp_augment_batch(_ptr(descs), n_clips, T, size, m3, s3, b9, _ptr(out), 3 * T * size * size, _ptr(ws),
                                               ws.numel(), _stream()), "rsp_augment_batch")
         return out
+
+
+class PackSet:
+    """Persistent packed copies of a set of convolution weights + the device-resident job table that rebuilds them."""
+
+    def __init__(self, be: "HipOps", entries):
+        self.be = be
+        self.packed = []
+        jobs = []
+        dev = None
+        for g, which, w_ref in entries:
+            _chk(w_ref, "w_ref")
+            dev = w_ref.device
+            d = g.desc()
+            n = (be.lib.rsp_conv3d_packed_dgrad_elems if which else be.lib.rsp_conv3d_packed_fwd_elems)(C.byref(d))
+            out = torch.empty(n, dtype=torch.float32, device=dev)
+            buf = (_lib.PackJob * 64)()
+            cnt = be.lib.rsp_conv3d_pack_jobs(C.byref(d), which, w_ref.shape[0], w_ref.shape[1], _ptr(w_ref), _ptr(out), buf, 64)
+            if cnt < 0:
+                _lib.check(cnt, "rsp_conv3d_pack_jobs")
+            jobs.extend(bytes(buf)[i * C.sizeof(_lib.PackJob):(i + 1) * C.sizeof(_lib.PackJob)] for i in range(cnt))
+            self.packed.append(out)
+        self.n_jobs = len(jobs)
+        self.sources = [e[2] for e in entries]            # keep the weights (and their storage) alive
+        if self.n_jobs:
+            host = torch.frombuffer(bytearray(b"".join(jobs)), dtype=torch.uint8)
+            self.table = host.to(dev)
+
+    def run(self):
+        if self.n_jobs:
+            _lib.check(self.be.lib.rsp_pack_run(_ptr(self.table), self.n_jobs, _stream()), "rsp_pack_run")
 
 
 _backend = None

@@ -115,7 +115,7 @@ class CpuOps:
 
     @torch.enable_grad()
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu, want_dres,
-                        dgamma_out, dbeta_out):
+                        dgamma_out, dbeta_out, dy_out=None):
         z = self._act(pg, y, scale_shift, residual, relu).detach().requires_grad_(True)
         a = F.relu(z) if relu else z
         if pg.k != (1, 1, 1) or pg.s != (1, 1, 1):
@@ -131,6 +131,9 @@ class CpuOps:
             dgamma_out.copy_(s2.float())
         if dbeta_out is not None:
             dbeta_out.copy_(s1.float())
+        if dy_out is not None:
+            dy_out.copy_(dy)
+            return dy_out, (dz.contiguous() if want_dres else None)
         return dy.contiguous(), (dz.contiguous() if want_dres else None)
 
     def head_fwd(self, feat, w1, b1, w2, b2):
@@ -232,3 +235,39 @@ class CpuOps:
 
     def rows_gather(self, x, idx):
         return x[idx.long()].contiguous()
+
+    def eltwise(self, op, a, b=None, out=None):
+        if op == "relu_fwd":
+            r = F.relu(a)
+        elif op == "relu_bwd":
+            r = torch.where(a > 0, b, torch.zeros_like(b))
+        elif op == "sigmoid_fwd":
+            r = torch.sigmoid(a)
+        elif op == "sigmoid_bwd":
+            r = b * a * (1 - a)
+        else:
+            r = a + b
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def conv_dgrad_packed(self, g, dy, w_packed):
+        return self.conv_dgrad(g, dy, w_packed)
+
+    def pack_set(self, entries):
+        return _CpuPackSet(entries)
+
+
+class _CpuPackSet:
+    """Checker twin of rspnet_amd.ops.PackSet: the "packed" copy is the zero-padded reference-layout weight."""
+
+    def __init__(self, entries):
+        self.entries = entries
+        self.packed = [torch.zeros((g.Cout, g.Cin) + tuple(w.shape[2:]), dtype=w.dtype) for g, which, w in entries]
+        self.run()
+
+    def run(self):
+        for (g, which, w), out in zip(self.entries, self.packed):
+            out.zero_()
+            out[:w.shape[0], :w.shape[1]] = w.detach()

@@ -60,7 +60,12 @@ def check_case(arch, device, fwd_tol):
             assert p.grad is None, n
         else:
             assert p.grad is not None, n
-            worst = max(worst, summary_err(n, p.grad.detach().cpu().numpy(), g))
+            mine = p.grad.detach().cpu().numpy()
+            if "gradproj." + n in z.files and g[0] >= 1e-4:
+                l2 = float(np.sqrt((mine.astype(np.float64) ** 2).sum()))
+                worst = max(worst, P.proj_rel_err(n, mine, z["gradproj." + n]), abs(l2 - g[0]) / g[0])
+            else:
+                worst = max(worst, summary_err(n, mine, g))
     assert worst <= grad_tol(arch), worst
     post = model.state_dict()
     for name in z.files:

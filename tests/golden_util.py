@@ -20,23 +20,24 @@ def cases_for(arch, ws=None):
 
 
 
-# Gradient / post-SGD tolerance.  Forward quantities (loss, logits, features, queue, BN statistics) are compared at
-# 1e-3 or tighter (they agree to ~1e-6).  Weight gradients of these TINY fixtures are a different matter: a single
-# ReLU-mask or max-pool arg-max decision on a value that sits within fp32 rounding of zero / of its neighbour is made
-# differently by any two correct implementations (MKL-DNN vs cuDNN vs ours), and at B=4, 32 px one re-routed element
-# moves a conv weight gradient by ~1/sqrt(#positions) ~ 1e-3..1e-2 (measured: tests found such elements in 2 of 3
-# two-rank fixtures).  oracle/gen_golden.py filters the worst cases (small late layers); the rest is absorbed here.
-# Kernel-level gradient exactness is pinned separately at 2e-5 in tests/test_kernels_gpu.py on identical inputs.
+# Gradient / post-SGD tolerance of the WHOLE-STEP comparison.  Forward quantities (loss, logits, features, queue, BN
+# statistics) are compared at 1e-3 or tighter (they agree to ~1e-6).  Whole-step weight gradients have a floor that no
+# implementation can go under: the backward pass of a ReLU / max-pool network is discontinuous in the forward values, so two
+# correct fp32 implementations whose activations differ by a relative delta decide ~delta of the masks / arg-maxes
+# differently, each flip changing its gradient contribution by O(1) -> a whole-gradient distance ~sqrt(delta), independent
+# of the fixture size.  tests/golden/conditioning.json (oracle/gen_conditioning.py) holds that floor per fixture family,
+# measured as the oracle restatement in fp32 vs fp64 on the fixture's own inputs: ~3e-6 for the knife-edge-guarded C3D /
+# R3D / R(2+1)D fixtures (no flip at all), 1e-2 for S3D-G, 3e-2 for the Bottleneck ResNet-50 (deep stacks, forward
+# delta ~3e-5).  The gate is 2e-2 or 3x the measured floor, whichever is larger.  The exact check of the backward
+# composition, unit by unit at 2e-5, is the teacher-forced replay (tests/test_teacher_forced_gpu.py).
 GRAD_TOL = 2e-2
-# S3D-G: 77 BN+ReLU layers, most with only 16..256 elements per channel at fixture size — mask knife-edges are the rule,
-# not the exception (per-layer check: single-channel differences that then propagate; layers untouched by one agree to
-# ~1e-4).  Its fixtures pin the forward path and the structure of the gradients, not their last digits.
-GRAD_TOL_BY_ARCH = {"s3dg": 0.3, "resnet50": 0.3}     # resnet50: unguarded fixture (2048-channel layers, 32 elements each)
+with open(os.path.join(GOLDEN, "conditioning.json")) as _f:
+    CONDITIONING = json.load(_f)
 FWD_TOL_BY_ARCH = {"s3dg": 1e-3}
 
 
 def grad_tol(arch):
-    return GRAD_TOL_BY_ARCH.get(arch, GRAD_TOL)
+    return max(GRAD_TOL, 3.0 * CONDITIONING.get(arch, {}).get("grad_rel_l2_max", 0.0))
 
 
 def fwd_tol(arch, default):
@@ -78,6 +79,42 @@ def summary_err(key, mine, golden_summary, null_norm=1e-4):
     return rel_err(s, golden_summary)
 
 
+def tensor_err(z, rank, kind, key, mine, null_norm=1e-4):
+    """Relative L2 distance estimate between a tensor and the golden one of family `kind` ('grad', 'mom', 'post'): from the
+    fixture's 16 random projections (oracle/portable.py:projections) together with the norm; fixtures (or tensors) without
+    projections fall back to the (l2, sum, samples) summary."""
+    pk = f"r{rank}.{kind}proj.{key}"
+    gs = z[f"r{rank}.{kind}sum.{key}"]
+    if pk not in z.files:
+        return summary_err(key, mine, gs, null_norm)
+    mine = np.asarray(mine)
+    l2 = float(np.sqrt((mine.astype(np.float64) ** 2).sum()))
+    if gs[0] < null_norm:                      # mathematically-zero tensor (e.g. grad of a conv bias in front of train-mode BN)
+        assert l2 < 100 * null_norm, key
+        return 0.0
+    return max(P.proj_rel_err(key, mine, z[pk]), abs(l2 - gs[0]) / gs[0])
+
+
+def grad_err(z, rank, key, mine, null_norm=1e-4):
+    return tensor_err(z, rank, "grad", key, mine, null_norm)
+
+
+def worst_grad_err(z, rank, grads):
+    """max over parameters of grad_err; asserts that exactly the reference's parameters received a gradient."""
+    worst = ("", 0.0)
+    pre = f"r{rank}.gradsum."
+    for name in z.files:
+        if name.startswith(pre):
+            key = name[len(pre):]
+            if z[name].size == 0:
+                assert grads[key] is None, key          # never gets a grad in the reference either
+                continue
+            e = grad_err(z, rank, key, grads[key])
+            if e > worst[1]:
+                worst = (key, e)
+    return worst
+
+
 def run_restatement(arch, meta, inputs):
     state, mom, clips, perms_B, sh = inputs
     ws = meta["ws"]
@@ -114,7 +151,10 @@ def compare_to_golden(z, rank, out, post_state, mom_post, tol, tol_grad=None, ch
                 assert int(np.asarray(post_state[key])) == int(z[name]), key
             if name.startswith(pre + "postsum."):
                 key = name[len(pre + "postsum."):]
-                e = rel_err(P.summarise(key, np.asarray(post_state[key])), z[name])
+                if pre + "postproj." + key in z.files:
+                    e = tensor_err(z, rank, "post", key, post_state[key])
+                else:
+                    e = rel_err(P.summarise(key, np.asarray(post_state[key])), z[name])
                 if e > worst[1]:
                     worst = (key, e)
         errs["post_state"] = worst[1]
@@ -126,7 +166,7 @@ def compare_to_golden(z, rank, out, post_state, mom_post, tol, tol_grad=None, ch
                 key = name[len(pre + "momsum."):]
                 if z[pre + "gradsum." + key].size == 0:
                     continue                     # never gets a grad: torch.optim.SGD skips it entirely
-                e = summary_err(key, mom_post[key], z[name])
+                e = tensor_err(z, rank, "mom", key, mom_post[key])
                 if e > worst[1]:
                     worst = (key, e)
         errs["momentum_post"] = worst[1]

@@ -74,7 +74,7 @@ def run_model_step(arch, meta, inputs, rank, device, optimizer="fused"):
     res = {"loss": loss, "loss_A": loss_A, "loss_M": loss_M, "logits1": out[0], "logits2": out[1], "l_pos_M": rl[0],
            "l_neg_M": rl[1], "q_A": q_A, "q_M": q_M}
     # encoder_k outputs of this rank in the reference's shuffled order (pass #1 = k_negative clips, pass #2 = k clips)
-    dim = q_A.shape[1]
+    dim = q_A.shape[1]                       # width of the A head (the M head is 1-d for fc_type 'speednet')
     for tag, (feats, order) in zip(("kneg", "k"), model._last_k):
         shuf = torch.empty_like(feats)
         shuf[torch.from_numpy(order).to(feats.device)] = feats

@@ -55,6 +55,7 @@ class Call:
     kwargs: Dict[str, Any]
     changed: Dict[Any, Snap]              # arg position / kw name -> value after the call (in-place outputs)
     results: Any                          # Snap / tuple of (Snap | None | value)
+    aliases: Dict[str, int] = field(default_factory=dict)   # kw name -> position of the positional arg it is the same tensor as
 
 
 def _pool_unsafe(z_ncdhw, pg, relu):
@@ -112,6 +113,8 @@ class Recorder:
             args = self._neutralise(name, args, kwargs)
             pre_a = [_snap(a) if _is_t(a) else a for a in args]
             pre_k = {k: (_snap(v) if _is_t(v) else v) for k, v in kwargs.items()}
+            aliases = {k: i for k, v in kwargs.items() if _is_t(v) for i, a in enumerate(args)
+                       if _is_t(a) and a.data_ptr() == v.data_ptr() and a.shape == v.shape}
             out = fn(*args, **kwargs)
             changed = {}
             for i, a in enumerate(args):
@@ -124,7 +127,7 @@ class Recorder:
                 res = tuple(_snap(o) if _is_t(o) else o for o in out)
             else:
                 res = _snap(out) if _is_t(out) else out
-            self.calls.append(Call(name, pre_a, pre_k, changed, res))
+            self.calls.append(Call(name, pre_a, pre_k, changed, res, aliases))
             return out
         return wrapped
 
@@ -137,7 +140,7 @@ def _err(got: torch.Tensor, exp: torch.Tensor) -> float:
     return float((got - exp).abs().max() / max(float(exp.abs().max()), 1e-6))
 
 
-def replay(calls: List[Call], backend, dev, tol=2e-5, skip=("conv_pack_fwd",)):
+def replay(calls: List[Call], backend, dev, tol=2e-5, skip=("conv_pack_fwd", "pack_set")):
     """Run every recorded call on `backend` with the recorded inputs; returns {op name: worst rel err}; asserts <= tol."""
     worst: Dict[str, float] = {}
     where: Dict[str, int] = {}
@@ -153,9 +156,16 @@ def replay(calls: List[Call], backend, dev, tol=2e-5, skip=("conv_pack_fwd",)):
             continue
         args = [_materialise(a, dev) if isinstance(a, Snap) else a for a in c.args]
         kwargs = {k: (_materialise(v, dev) if isinstance(v, Snap) else v) for k, v in c.kwargs.items()}
+        for k, i in c.aliases.items():
+            kwargs[k] = args[i]
         if c.name == "conv_fwd":
             # the checker's "packed" weight is the reference layout; the device backend packs it its own way
             args[2] = backend.conv_pack_fwd(args[0], args[2].contiguous())
+        if c.name == "conv_dgrad_packed":
+            # checker "packed" = zero-padded reference layout: re-pack it through the backend's own batched path
+            ps = backend.pack_set([(args[0], 1, args[2].contiguous())])
+            ps.run()
+            args[2] = ps.packed[0]
         if c.name == "bn_finalize":
             args[0] = args[0].float().contiguous()          # checker keeps its single stat tile in fp64
         out = getattr(backend, c.name)(*args, **kwargs)

@@ -19,7 +19,7 @@ def _worker(rank, ws, arch, seed, port, tmp):
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
     from cpu_ops import CpuOps
-    from golden_util import build_inputs, compare_to_golden, load_case, summary_err, fwd_tol, grad_tol
+    from golden_util import build_inputs, compare_to_golden, load_case, worst_grad_err, fwd_tol, grad_tol
     from model_util import run_model_step
     from rspnet_amd import ops
     torch.set_num_threads(4)
@@ -31,13 +31,8 @@ def _worker(rank, ws, arch, seed, port, tmp):
     spec, inputs = build_inputs(arch, meta)
     res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, torch.device("cpu"), "fused")
     errs = compare_to_golden(z, rank, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=grad_tol(arch))
-    worst = 0.0
-    for name in z.files:
-        if name.startswith(f"r{rank}.gradsum."):
-            key = name[len(f"r{rank}.gradsum."):]
-            if z[name].size:
-                worst = max(worst, summary_err(key, grads[key], z[name]))
-    assert worst <= grad_tol(arch), worst
+    wkey, worst = worst_grad_err(z, rank, grads)
+    assert worst <= grad_tol(arch), (wkey, worst)
     np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([worst]))
     dist.barrier()
     dist.destroy_process_group()
@@ -46,7 +41,7 @@ def _worker(rank, ws, arch, seed, port, tmp):
 from golden_util import cases_for
 
 
-@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "resnet18", "r2plus1d-vcop", "s3dg") for a, w, s in cases_for(arch, 2)])
+@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "c3d:linear:4", "resnet18", "r2plus1d-vcop", "s3dg") for a, w, s in cases_for(arch, 2)])
 def test_two_rank_step_matches_golden(arch, seed):
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:

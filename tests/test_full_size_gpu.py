@@ -109,14 +109,19 @@ def test_batchnorm_normalises_at_full_size(hip):
     assert torch.equal(pooled, ref)
 
 
-def test_full_size_step_bookkeeping_and_determinism():
+# BASELINE.json configs 1-4: (arch, clips per GPU, H = W)
+WORKLOADS = [("c3d", 32, 112), ("resnet18", 32, 112), ("r2plus1d-vcop", 32, 112), ("s3dg", 16, 224)]
+
+
+@pytest.mark.parametrize("arch,B,HW", WORKLOADS, ids=[w[0] for w in WORKLOADS])
+def test_full_size_step_bookkeeping_and_determinism(arch, B, HW):
     from rspnet_amd.moco import Loss, ModelFactory
     from rspnet_amd.optim import SGD
     K, T_, m_, lr, wd = 16384, 0.07, 0.999, 0.05, 1e-4
-    cfg = {"model": {"arch": "c3d"}, "moco": {"dim": 128, "k": K, "m": m_, "t": T_, "fc_type": "linear", "diff_speed": [2]}}
+    cfg = {"model": {"arch": arch}, "moco": {"dim": 128, "k": K, "m": m_, "t": T_, "fc_type": "linear", "diff_speed": [2]}}
     gen = torch.Generator(device=DEV).manual_seed(11)
-    im_q = torch.randn(B, 3, 32, 112, 112, device=DEV, generator=gen)
-    im_k = im_q + 0.1 * torch.randn(B, 3, 32, 112, 112, device=DEV, generator=gen)
+    im_q = torch.randn(B, 3, 32, HW, HW, device=DEV, generator=gen)
+    im_k = im_q + 0.1 * torch.randn(B, 3, 32, HW, HW, device=DEV, generator=gen)
 
     def one_step():
         import random
@@ -125,8 +130,7 @@ def test_full_size_step_bookkeeping_and_determinism():
         wrapped = ModelFactory(cfg).build_moco_diffloss(device=DEV)
         model = wrapped.module
         model.train()
-        params = [p for p in wrapped.parameters() if p.requires_grad]
-        opt = SGD(params, lr=lr, momentum=0.9, dampening=0.0, weight_decay=wd, nesterov=False)
+        opt = SGD(wrapped.parameters(), lr=lr, momentum=0.9, dampening=0.0, weight_decay=wd, nesterov=False)
         q0 = {n: p.detach().clone() for n, p in model.encoder_q.named_parameters()}
         k0 = {n: p.detach().clone() for n, p in model.encoder_k.named_parameters()}
         queue0 = model.queue.clone()
@@ -163,3 +167,28 @@ def test_full_size_step_bookkeeping_and_determinism():
     assert torch.equal(out[0], out2[0]) and torch.equal(out[1], out2[1]) and torch.equal(losses[0], losses2[0])
     for (n, p), (_, p2) in zip(model.encoder_q.named_parameters(), model2.encoder_q.named_parameters()):
         assert torch.equal(p, p2), n
+    # every BatchNorm of both encoders saw finite statistics; the key encoder ran twice, the query encoder once
+    for n, b in model.named_buffers():
+        if n.endswith(("running_mean", "running_var")):
+            assert torch.isfinite(b).all(), n
+        elif n.endswith("num_batches_tracked"):
+            assert int(b) == (2 if n.startswith("encoder_k.") else 1), n
+
+
+def test_offsets_beyond_32_bits_are_refused_or_handled(hip):
+    """The LDS-DMA kernels address with 32-bit byte offsets.  S3D-G's largest activation at B=16, 224^2 (stem output
+    16x8x112x112x64 fp32 = 411 MB) is far below 4 GiB, and the library routes anything larger to the 64-bit scalar-gather kernel
+    instead of wrapping around: a conv whose input exceeds 4 GiB must still be right."""
+    N, D, H, W, Cin, Cout = 1, 33, 1024, 1024, 32, 8          # 33 * 2^20 * 32 * 4 B = 4.4 GB input
+    g = ConvGeom(N, D, H, W, Cin, Cout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    x = torch.zeros((N, D, H, W, Cin), device=DEV)
+    x[0, D - 1, H - 1, W - 1, :] = 1.0                          # the very last position, beyond the 32-bit range
+    x[0, 0, 0, 0, :] = 2.0
+    w = torch.arange(Cout * Cin, device=DEV, dtype=torch.float32).view(Cout, Cin, 1, 1, 1) * 1e-3
+    y, _ = hip.conv_fwd(g, x, hip.conv_pack_fwd(g, w), None, False)
+    want_last = w.view(Cout, Cin).sum(1)
+    assert float((y[0, D - 1, H - 1, W - 1] - want_last).abs().max()) <= 1e-5
+    assert float((y[0, 0, 0, 0] - 2 * want_last).abs().max()) <= 1e-5
+    assert float(y[0, D - 1, H - 1, W - 2].abs().max()) == 0.0
+    del x, y
+    torch.cuda.empty_cache()

@@ -51,6 +51,12 @@ CONV_CASES = [
     (1, 1, 5, 5, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # tiny: M=25 < one tile
     (1, 4, 130, 128, 32, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # 520 tiles = one whole round of 512 + a K-split tail of 8
     (1, 4, 70, 80, 32, 320, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # 175 x 3 tiles: whole rounds end mid-way (510), 3 column tiles
+    # column / output-channel segments: the part of Cout (Cin for dgrad) beyond the last multiple of 128 runs on a narrower tile
+    (2, 4, 12, 12, 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # R(2+1)D conv2 spatial: 144 = 128 + 16 (32-wide tile)
+    (2, 4, 12, 12, 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),      # its temporal partner: dgrad N = 144
+    (2, 4, 10, 10, 128, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 288 = 256 + 32
+    (1, 4, 14, 14, 96, 160, (3, 1, 1), (1, 1, 1), (1, 0, 0)),      # S3D-G: 160 = 128 + 32, Cin = 96
+    (1, 2, 7, 7, 256, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # 576 = 512 + 64, small M (K-split tail tiles in both segments)
     # 4-channel (zero-padded RGB) stems: direct LDS-halo kernel (conv_stem.hip)
     (2, 4, 12, 12, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # C3D conv1: all 3 time-slices resident, 14-tap chunks
     (2, 5, 18, 20, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),        # R3D stem: ring of 3 time-slices, stride 2 de-interleave

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from golden_util import ALL_CASES, build_inputs, compare_to_golden, load_case, run_restatement, summary_err
+from golden_util import ALL_CASES, build_inputs, compare_to_golden, load_case, run_restatement, worst_grad_err
 from oracle import portable as P
 
 
@@ -18,16 +18,9 @@ def test_restatement_matches_golden(arch, ws, seed):
                if k not in ("grads", "momentum_post")}
         errs = compare_to_golden(z, r, out, post, mom_post, tol=2e-5, tol_grad=2e-4)
         # gradient summaries
-        worst = 0.0
-        for name in z.files:
-            if name.startswith(f"r{r}.gradsum."):
-                key = name[len(f"r{r}.gradsum."):]
-                g = outs[r]["grads"][key]
-                if z[name].size == 0:
-                    assert g is None, key          # encoder.linear / encoder.fc never get a grad
-                else:
-                    worst = max(worst, summary_err(key, g.numpy(), z[name]))
-        assert worst <= 2e-4, worst
+        grads = {k: (None if g is None else g.numpy()) for k, g in outs[r]["grads"].items()}
+        wkey, worst = worst_grad_err(z, r, grads)
+        assert worst <= 2e-4, (wkey, worst)
 
 
 def test_portable_generator_is_stable():

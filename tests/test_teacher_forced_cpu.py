@@ -24,7 +24,7 @@ def test_recorded_step_replays_exactly(arch):
         ops.set_backend(prev)
     compare_to_golden(z, 0, res, post, None, tol=fwd_tol(a, 2e-4), check=("fwd",))
     names = {c.name for c in rec.calls}
-    assert {"conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act_pool_bwd", "sgd_step", "logits_bwd"} <= names
+    assert {"conv_fwd", "conv_dgrad_packed", "conv_wgrad", "bn_act_pool_bwd", "sgd_step", "logits_bwd"} <= names
     total = sum(c.args[3].data.numel() for c in rec.calls if c.name == "bn_act_pool_bwd")
     assert rec.neutralised <= 1e-3 * total, (rec.neutralised, total)
     worst, _ = replay(rec.calls, CpuOps(), torch.device("cpu"), tol=1e-6)

@@ -16,7 +16,7 @@ from teacher_forced import Recorder, replay
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
-ARCHS = ["c3d", "c3d:mlp", "resnet18", "resnet34", "resnet50", "r2plus1d-vcop", "s3dg"]
+ARCHS = ["c3d", "c3d:mlp", "c3d:conv", "c3d:convbn", "c3d:speednet", "c3d:linear:4", "resnet18", "resnet34", "resnet50", "r2plus1d-vcop", "s3dg"]
 
 
 @pytest.mark.parametrize("arch", [a for a in ARCHS if cases_for(a, 1)])
@@ -34,7 +34,7 @@ def test_every_op_of_a_step_teacher_forced(arch):
     assert be.name == "hip"
     worst, where = replay(rec.calls, be, torch.device("cuda", 0), tol=TOL)
     torch.cuda.synchronize()
-    for must in ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_finalize", "bn_act_pool_fwd", "bn_act_pool_bwd", "logits_fwd",
+    for must in ("conv_fwd", "conv_dgrad_packed", "conv_wgrad", "bn_finalize", "bn_act_pool_fwd", "bn_act_pool_bwd", "logits_fwd",
                  "logits_bwd", "loss_fwd_bwd", "sgd_step", "momentum_update", "clip_gather", "queue_enqueue"):
         assert must in worst, must
     if arch == "s3dg":

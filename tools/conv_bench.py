@@ -15,6 +15,8 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--what", default="fwd,dgrad,wgrad")
 ap.add_argument("--stems", action="store_true", help="the four backbone stems (Cin padded to 4) instead of the C3D stack")
 ap.add_argument("--r3d", action="store_true", help="R3D-18 residual-stage conv shapes")
+ap.add_argument("--r21d", action="store_true", help="R(2+1)D factored conv shapes (mid channels zero-padded to a multiple of 4)")
+ap.add_argument("--s3dg", action="store_true", help="S3D-G conv shapes (B=16 by default for this list)")
 ap.add_argument("--no-stem-kernel", action="store_true", help="ablation build only: route stems through the implicit-GEMM kernel")
 args = ap.parse_args()
 if args.tune is not None:
@@ -50,8 +52,31 @@ STEMS = [("c3d-stem", 16, 112, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)), ("r3d-st
          ("r21d-stem", 16, 112, 4, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)), ("s3dg-stem", 16, 224, 4, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3))]
 R3D = [("r3d-l1", 8, 28, 64, 64), ("r3d-l2", 4, 14, 128, 128), ("r3d-l3", 2, 7, 256, 256), ("r3d-l4", 1, 4, 512, 512),
        ("r3d-l2s2", 8, 28, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)), ("r3d-l4s2", 2, 7, 256, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1))]
+S_ = lambda k: ((1, k, k), (1, 1, 1), (0, k // 2, k // 2))
+T_ = lambda k, st=1: ((k, 1, 1), (st, 1, 1), (k // 2, 0, 0))
+R21D = [("c1.sp", 16, 112, 4, 84, (1, 7, 7), (1, 2, 2), (0, 3, 3)), ("c1.tm", 16, 56, 84, 64, *T_(3)),
+        ("c2.sp", 16, 56, 64, 144, *S_(3)), ("c2.tm", 16, 56, 144, 64, *T_(3)),
+        ("c3a.sp", 16, 56, 64, 232, (1, 3, 3), (1, 2, 2), (0, 1, 1)), ("c3a.tm", 16, 28, 232, 128, *T_(3, 2)),
+        ("c3b.sp", 8, 28, 128, 288, *S_(3)), ("c3b.tm", 8, 28, 288, 128, *T_(3)),
+        ("c4a.sp", 8, 28, 128, 460, (1, 3, 3), (1, 2, 2), (0, 1, 1)), ("c4a.tm", 8, 14, 460, 256, *T_(3, 2)),
+        ("c4b.sp", 4, 14, 256, 576, *S_(3)), ("c4b.tm", 4, 14, 576, 256, *T_(3)),
+        ("c5a.sp", 4, 14, 256, 924, (1, 3, 3), (1, 2, 2), (0, 1, 1)), ("c5a.tm", 4, 7, 924, 512, *T_(3, 2)),
+        ("c5b.sp", 2, 7, 512, 1152, *S_(3)), ("c5b.tm", 2, 7, 1152, 512, *T_(3))]
+P_ = ((1, 1, 1), (1, 1, 1), (0, 0, 0))
+S3DG = [("stem.tm", 8, 112, 64, 64, *T_(7)), ("basic", 8, 56, 64, 64, *P_), ("sc2.sp", 8, 56, 64, 192, *S_(3)), ("sc2.tm", 8, 56, 192, 192, *T_(3)),
+        ("3b.b0", 8, 28, 192, 64, *P_), ("3b.b1", 8, 28, 192, 96, *P_), ("3b.b1s", 8, 28, 96, 128, *S_(3)), ("3b.b1t", 8, 28, 128, 128, *T_(3)),
+        ("3c.b1", 8, 28, 256, 128, *P_), ("3c.b1s", 8, 28, 128, 192, *S_(3)), ("3c.b1t", 8, 28, 192, 192, *T_(3)),
+        ("4b.b0", 4, 14, 480, 192, *P_), ("4b.b1s", 4, 14, 96, 208, *S_(3)), ("4b.b1t", 4, 14, 208, 208, *T_(3)), ("4b.b2", 4, 14, 480, 16, *P_),
+        ("4f.b0", 4, 14, 528, 256, *P_), ("4f.b1s", 4, 14, 160, 320, *S_(3)), ("4f.b1t", 4, 14, 320, 320, *T_(3)),
+        ("5c.b0", 2, 7, 832, 384, *P_), ("5c.b1s", 2, 7, 192, 384, *S_(3)), ("5c.b1t", 2, 7, 384, 384, *T_(3))]
 if args.stems:
     LAYERS = STEMS
+if args.r21d:
+    LAYERS = R21D
+if args.s3dg:
+    LAYERS = S3DG
+    if B == 32:
+        B = 16
 if args.r3d:
     LAYERS = R3D
 tot = {}
