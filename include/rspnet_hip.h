@@ -84,17 +84,18 @@ int rsp_conv3d_dgrad_packed(const rsp_conv3d_desc* d, const float* dy, const flo
  *     w_packed for descriptor d; d->Cout / d->Cin may exceed the source dims, the excess is zero (channel padding, e.g. the
  *     3 -> 4 channel stems).  which = 0: forward layout (1 job, rsp_conv3d_packed_fwd_elems floats); which = 1: all dgrad
  *     stride-class layouts (<= sT*sH*sW jobs, rsp_conv3d_packed_dgrad_elems floats).  Returns the number of jobs or RSP_E*.
- *   rsp_pack_run: executes n_jobs jobs stored in DEVICE memory. */
+ *   rsp_pack_run: executes n_jobs jobs stored in DEVICE memory; max_blocks = the largest `blocks` field among them (grid.x). */
 typedef struct rsp_pack_job {
   const void* src;
   void* dst;
   int64_t total;
   int32_t kind, Cout_src, Cin_src, kT, kH, kW;
   int32_t transpose, O, C, Kld, nTd, nTh, nTw, k0d, k0h, k0w, kstepd, ksteph, kstepw, ntaps;
+  int32_t blocks, reserved;   /* workgroups this job needs (one per packed row) */
 } rsp_pack_job;
 int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Cout_src, int32_t Cin_src, const float* w_ref,
                              float* w_packed, rsp_pack_job* jobs, int32_t max_jobs);
-int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, void* stream);
+int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, int32_t max_blocks, void* stream);
 
 /* wgrad: dw (reference layout, overwritten) = sum over positions of dy ⊗ im2col(x); dbias (nullable) = sum dy. */
 size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d);

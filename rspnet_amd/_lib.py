@@ -37,7 +37,7 @@ class PackJob(C.Structure):
     """rsp_pack_job (112 bytes)"""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("total", C.c_int64)] + [(n, C.c_int32) for n in (
         "kind", "Cout_src", "Cin_src", "kT", "kH", "kW", "transpose", "O", "C", "Kld", "nTd", "nTh", "nTw", "k0d", "k0h", "k0w",
-        "kstepd", "ksteph", "kstepw", "ntaps")]
+        "kstepd", "ksteph", "kstepw", "ntaps", "blocks", "reserved")]
 
 
 class AugmentClipDesc(C.Structure):
@@ -70,7 +70,7 @@ SIGNATURES = {
     "rsp_conv3d_packed_dgrad_elems": (_sz, [_PD]),
     "rsp_conv3d_dgrad_packed": (C.c_int, [_PD, _p, _p, _p, _p, _sz, _p]),
     "rsp_conv3d_pack_jobs": (_i32, [_PD, _i32, _i32, _i32, _p, _p, _p, _i32]),
-    "rsp_pack_run": (C.c_int, [_p, _i32, _p]),
+    "rsp_pack_run": (C.c_int, [_p, _i32, _i32, _p]),
     "rsp_conv3d_wgrad_workspace": (_sz, [_PD]),
     "rsp_conv3d_wgrad": (C.c_int, [_PD, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_conv3d_kernel_name": (C.c_char_p, [_PD, C.c_int]),

@@ -595,33 +595,62 @@ __global__ void pack_weight_kernel(const PackParams p) {
 
 // Many re-packs in one launch (blockIdx.y = job): a step re-packs every convolution weight of an encoder once (forward
 // layout, and for the query encoder the dgrad layouts) — as single launches that was 80-270 four-microsecond kernels per step.
-__global__ void pack_batch_kernel(const rsp_pack_job* __restrict__ jobs) {
+// blockIdx.x = packed row o (stem layout: a 4096-element slice); grid.x is sized for the job with the most rows, blocks past a
+// job's end exit at once.  One workgroup walks its row tap by tap (tap decode is scalar), threads over the channel index: no
+// per-element division (the single-conv kernel above spends ~150 integer instructions per element on index arithmetic).
+__global__ __launch_bounds__(256) void pack_batch_kernel(const rsp_pack_job* __restrict__ jobs) {
   const rsp_pack_job j = jobs[blockIdx.y];
   const float* __restrict__ w = reinterpret_cast<const float*>(j.src);
   float* __restrict__ out = reinterpret_cast<float*>(j.dst);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < j.total; i += (long long)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    if (j.kind == 1) {   // stem layout [tap][64][4] (conv_stem.hip)
+  if (j.kind == 1) {   // stem layout [tap][64][4] (conv_stem.hip)
+    const long long i0 = (long long)blockIdx.x * 4096;
+    const long long i1 = i0 + 4096 < j.total ? i0 + 4096 : j.total;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
       const int ci = (int)(i & 3), n = (int)((i >> 2) & 63), tap = (int)(i >> 8);
+      float v = 0.f;
       if (tap < j.ntaps && n < j.Cout_src && ci < j.Cin_src) {
         const int kw = tap % j.kW, r = tap / j.kW;
         const int kh = r % j.kH, kt = r / j.kH;
         v = w[((((long long)n * j.Cin_src + ci) * j.kT + kt) * j.kH + kh) * j.kW + kw];
       }
-    } else {
-      const int o = (int)(i / j.Kld);
-      const int k = (int)(i - (long long)o * j.Kld);
-      if (k < j.ntaps * j.C) {
-        const int tap = k / j.C, c = k - tap * j.C;
-        const int aw = tap % j.nTw, q = tap / j.nTw;
-        const int ah = q % j.nTh, ad = q / j.nTh;
-        const int kt = j.k0d + ad * j.kstepd, kh = j.k0h + ah * j.ksteph, kw = j.k0w + aw * j.kstepw;
-        const int co = j.transpose ? c : o, ci = j.transpose ? o : c;
-        if (co < j.Cout_src && ci < j.Cin_src) v = w[((((long long)co * j.Cin_src + ci) * j.kT + kt) * j.kH + kh) * j.kW + kw];
-      }
+      out[i] = v;
     }
-    out[i] = v;
+    return;
   }
+  const int o = blockIdx.x;
+  if (o >= j.O) return;
+  // Whole filters (all T taps of one (co, ci) pair are T contiguous floats of the source) are staged through LDS, so every
+  // source line is read once, by neighbouring lanes, and the packed row is written in order: tile[c][t] -> row[tap*C + c].
+  __shared__ float tile[4096 + 64];
+  __shared__ int tsrc_of[MAX_TAPS];
+  float* __restrict__ row = out + (long long)o * j.Kld;
+  for (int tap = threadIdx.x; tap < j.ntaps; tap += 256) {
+    const int aw = tap % j.nTw, q = tap / j.nTw;
+    const int ah = q % j.nTh, ad = q / j.nTh;
+    tsrc_of[tap] = ((j.k0d + ad * j.kstepd) * j.kH + (j.k0h + ah * j.ksteph)) * j.kW + (j.k0w + aw * j.kstepw);
+  }
+  const int T = j.kT * j.kH * j.kW;
+  const int CH = T >= 4096 ? 1 : (4096 / T > 128 ? 128 : 4096 / T);
+  const bool o_in = o < (j.transpose ? j.Cin_src : j.Cout_src);
+  const int c_in = j.transpose ? j.Cout_src : j.Cin_src;
+  // filter of channel pair (o, c): forward o = co, c = ci -> consecutive c are consecutive filters; dgrad o = ci, c = co
+  const long long fbase = j.transpose ? (long long)o * T : (long long)o * j.Cin_src * T;
+  const long long fstride = j.transpose ? (long long)j.Cin_src * T : (long long)T;
+  for (int c0 = 0; c0 < j.C; c0 += CH) {
+    const int nc = min(CH, j.C - c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc * T; e += 256) {
+      const int cl = e / T, t = e - cl * T;
+      const int c = c0 + cl;
+      tile[e] = (o_in && c < c_in) ? w[fbase + c * fstride + t] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < j.ntaps * nc; e += 256) {
+      const int tap = e / nc, cl = e - tap * nc;
+      row[tap * j.C + c0 + cl] = tile[cl * T + tsrc_of[tap]];
+    }
+  }
+  for (int k = j.ntaps * j.C + threadIdx.x; k < j.Kld; k += 256) row[k] = 0.f;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
@@ -1127,6 +1156,7 @@ int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Co
     j.kstepd = pk.kstepd; j.ksteph = pk.ksteph; j.kstepw = pk.kstepw;
     j.ntaps = pk.nTd * pk.nTh * pk.nTw;
     j.total = (long long)pk.O * pk.Kld;
+    j.blocks = pk.O;
   };
   if (which == 0) {
     if (max_jobs < 1) return RSP_EINVAL;
@@ -1137,6 +1167,7 @@ int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Co
       j.Cout_src = Cout_src; j.Cin_src = Cin_src; j.kT = d->kT; j.kH = d->kH; j.kW = d->kW;
       j.ntaps = d->kT * d->kH * d->kW;
       j.total = (long long)rsp_stem_packed_elems(d);
+      j.blocks = (int32_t)((j.total + 4095) / 4096);
       return 1;
     }
     PackParams pk;
@@ -1164,9 +1195,9 @@ int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Co
   return n;
 }
 
-int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, void* stream) {
-  RSP_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535, "rsp_pack_run: bad argument");
-  hipLaunchKernelGGL(pack_batch_kernel, dim3(48, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
+int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, int32_t max_blocks, void* stream) {
+  RSP_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_blocks > 0, "rsp_pack_run: bad argument");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)max_blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
   return rsp_check_launch("pack_batch_kernel");
 }
 

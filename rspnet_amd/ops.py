@@ -508,12 +508,16 @@ class HipOps:
 
 
 class PackSet:
-    """Persistent packed copies of a set of convolution weights + the device-resident job table that rebuilds them."""
+    """Persistent packed copies of a set of convolution weights + the device-resident job tables that rebuild them.
+    Forward-layout and dgrad-layout jobs run as two launches: packing both layouts of the SAME weight concurrently reads it in
+    two conflicting patterns and is several times slower than the two passes back to back (tools/pack_probe.py: 31 + 62 us
+    apart, 221 us together on a 512x512x27 filter)."""
 
     def __init__(self, be: "HipOps", entries):
         self.be = be
         self.packed = []
-        jobs = []
+        jobs = {0: [], 1: []}
+        self.max_blocks = {0: 0, 1: 0}
         dev = None
         for g, which, w_ref in entries:
             _chk(w_ref, "w_ref")
@@ -525,17 +529,19 @@ class PackSet:
             cnt = be.lib.rsp_conv3d_pack_jobs(C.byref(d), which, w_ref.shape[0], w_ref.shape[1], _ptr(w_ref), _ptr(out), buf, 64)
             if cnt < 0:
                 _lib.check(cnt, "rsp_conv3d_pack_jobs")
-            jobs.extend(bytes(buf)[i * C.sizeof(_lib.PackJob):(i + 1) * C.sizeof(_lib.PackJob)] for i in range(cnt))
+            kind = 1 if which else 0
+            jobs[kind].extend(bytes(buf)[i * C.sizeof(_lib.PackJob):(i + 1) * C.sizeof(_lib.PackJob)] for i in range(cnt))
+            self.max_blocks[kind] = max([self.max_blocks[kind]] + [int(buf[i].blocks) for i in range(cnt)])
             self.packed.append(out)
-        self.n_jobs = len(jobs)
         self.sources = [e[2] for e in entries]            # keep the weights (and their storage) alive
-        if self.n_jobs:
-            host = torch.frombuffer(bytearray(b"".join(jobs)), dtype=torch.uint8)
-            self.table = host.to(dev)
+        self.tables = {}
+        for kind, js in jobs.items():
+            if js:
+                self.tables[kind] = (torch.frombuffer(bytearray(b"".join(js)), dtype=torch.uint8).to(dev), len(js))
 
     def run(self):
-        if self.n_jobs:
-            _lib.check(self.be.lib.rsp_pack_run(_ptr(self.table), self.n_jobs, _stream()), "rsp_pack_run")
+        for kind, (table, n) in self.tables.items():
+            _lib.check(self.be.lib.rsp_pack_run(_ptr(table), n, self.max_blocks[kind], _stream()), "rsp_pack_run")
 
 
 _backend = None

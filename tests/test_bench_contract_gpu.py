@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_contract_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "2"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "2", "--cpu-steps", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -31,3 +31,16 @@ def test_bench_prints_one_contract_line():
     assert rf["traffic"] is None or rf["traffic"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "clips/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert cb["cpu_model"] and cb["s_per_step"] > 0
+    # the roofline block names the kernel that dominates THIS backbone and carries the per-kernel table
+    assert rf["kernel"].startswith("igemm_kernel<128, 128") and rf["kernel"] in rf["per_kernel"]
+    assert abs(rf["avg_launch_ms"] - rf["per_kernel"][rf["kernel"]]["avg_launch_ms"]) < 1e-3 and 0 < rf["share_of_step"] < 1
+
+
+def test_bench_roofline_is_arch_aware():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--arch", "resnet18", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert "resnet18" in d["metric"] and "cpu_baseline" not in d
+    assert d["roofline"]["kernel"].startswith("igemm_kernel<128, 64")      # R3D-18's layer-1 / stem launches dominate, not <128,128>
