@@ -37,8 +37,35 @@ struct StemParams {
   int ntaps, nchunks;
   int tiles_h, tiles_w, tiles;
   unsigned x_bytes, w_bytes;
+  int wide;   // epilogue through LDS + 16-byte stores (Cout % 4 == 0, 16-byte aligned output rows and bias)
   int tune;   // ablation bits, honoured only in -DRSP_TUNE builds
 };
+
+// Wide epilogue store.  A wave's 32 x 64 accumulator tile is column-per-lane (lane = output channel), so a direct store is 32
+// four-byte stores per lane, each wave-instruction touching two 128-byte half rows; the vmcnt(0) hipcc places in front of the
+// next patch's first LDS read then waits for all of them (SQ_WAIT_ANY 46 % in round 1).  Here each 32 x 32 half goes through a
+// 4 KB wave-private LDS square ([row][col], conflict-free both ways) and leaves as four 16-byte stores per lane — eight rows x
+// 128 contiguous bytes per wave-instruction, a quarter of the store instructions.  Needs Cout % 4 == 0 and 16-byte aligned rows.
+__device__ __forceinline__ void stem_store_wide(const StemParams& p, const floatx16 (&acc)[2], float* stage /* wave-private 4 KB */,
+                                                const long long* rowaddr /* [128] */, int wave, int lane) {
+  const int l32 = lane & 31, h = lane >> 5;
+  const int q = lane & 7, rbase = lane >> 3;   // read side: 8 lanes per row, 4 channels each
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) stage[((e >> 2) * 8 + h * 4 + (e & 3)) * 32 + l32] = acc[j][e];
+    const int col = 32 * j + 4 * q;
+    floatx4 bv = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && col < p.Cout) bv = *reinterpret_cast<const floatx4*>(p.bias + col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rbase + 8 * i;
+      const floatx4 v = *reinterpret_cast<const floatx4*>(stage + r * 32 + 4 * q);
+      const long long addr = rowaddr[wave * 32 + r];
+      if (addr >= 0 && col < p.Cout) *reinterpret_cast<floatx4*>(p.y + addr + col) = v + bv;
+    }
+  }
+}
 
 template <int G>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
@@ -185,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   }
   __syncthreads();
   float* red = Bs;   // [4 waves][64][2]; the weight buffers are idle now
+  if (p.wide) stem_store_wide(p, acc, Bs + 512 + wave * 1024, rowaddr, wave, lane);   // behind the 2 KB of `red`
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = 32 * j + l32;
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
     for (int e = 0; e < 16; ++e) {
       const long long addr = rowaddr[wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3)];
       const float v = addr >= 0 ? acc[j][e] : 0.f;
-      if (addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
+      if (!p.wide && addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
       s += v;
       ss = fmaf(v, v, ss);
     }
@@ -239,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
   int* taptab = reinterpret_cast<int*>(Bs + p.nchunks * BU * 4);               // [nchunks*TCH]
   long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nchunks * TCH);  // [128]
   float* red = reinterpret_cast<float*>(rowaddr + 128);                        // [4 waves][64][2]
+  float* stage = red + 512;                                                    // [4 waves][32][32] (wide epilogue)
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -356,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
       rowaddr[t] = (ho < p.Ho && wo < p.Wo) ? ((((long long)n * p.Do + to) * p.Ho + ho) * p.Wo + wo) * p.out_ld : -1;
     }
     __syncthreads();
+    if (p.wide) stem_store_wide(p, acc, stage + wave * 1024, rowaddr, wave, lane);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = 32 * j + l32;
@@ -366,9 +396,9 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
         const long long addr = rowaddr[wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3)];
         const float v = addr >= 0 ? acc[j][e] : 0.f;
 #ifdef RSP_TUNE
-        if (addr >= 0 && col < p.Cout && !((p.tune & 1) && v != 12345.f)) p.y[addr + col] = v + bv;
+        if (!p.wide && addr >= 0 && col < p.Cout && !((p.tune & 1) && v != 12345.f)) p.y[addr + col] = v + bv;
 #else
-        if (addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
+        if (!p.wide && addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
 #endif
         s += v;
         ss = fmaf(v, v, ss);
@@ -470,7 +500,7 @@ StemPlan stem_plan(const rsp_conv3d_desc* d) {
   s.tiles = (long long)d->N * d->Do * s.tiles_h * s.tiles_w;
   if (s.tiles >= (1ll << 31)) return s;
   const size_t lds_res = (size_t)2 * d->kT * s.npix_r * 16 + (size_t)s.nchunks * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 +
-                         128 * 8 + 2048;
+                         128 * 8 + 2048 + 16384;   // ... + stat scratch + the wide epilogue's 4 x 4 KB staging squares
   s.resident = d->kT <= 3 && lds_res <= 78 * 1024;      // two workgroups per CU at least
 #ifdef RSP_TUNE
   if (getenv("RSP_STEM_STREAM")) s.resident = false;
@@ -550,6 +580,10 @@ int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed
   p.npix = pl.npix; p.npix_r = pl.npix_r; p.FR = pl.FR;
   p.ntaps = d->kT * d->kH * d->kW; p.nchunks = pl.nchunks;
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles = (int)pl.tiles;
+  p.wide = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && (!bias || rsp_aligned16(bias));
+#ifdef RSP_TUNE
+  if (getenv("RSP_STEM_NARROW")) p.wide = 0;
+#endif
   p.x_bytes = (unsigned)((unsigned long long)d->N * d->Di * d->Hi * d->Wi * 16ull);
   p.w_bytes = (unsigned)((size_t)pl.nchunks * pl.TCH * 1024);
 #ifdef RSP_TUNE
