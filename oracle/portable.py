@@ -67,18 +67,17 @@ def summarise(name: str, arr: np.ndarray, count: int = 16) -> np.ndarray:
     return np.concatenate([[np.sqrt((flat * flat).sum()), flat.sum()], flat[idx]])
 
 
-def projections(name: str, arr: np.ndarray, count: int = 16) -> np.ndarray:
-    """`count` fixed pseudo-random +-1 projections of a tensor, <x, u_j> / sqrt(numel), float64.  With golden projections
-    g_j and measured ones m_j, sqrt(sum (m_j-g_j)^2 / sum g_j^2) estimates the relative L2 distance |m-g|/|g| of the full
-    tensors (Johnson-Lindenstrauss) — unlike the plain element sum, whose error can exceed the L2 error by sqrt(numel) when
-    the difference has a coherent component."""
+def projections(name: str, arr: np.ndarray, count: int = 64) -> np.ndarray:
+    """Count-sketch of a tensor: element i is added with a pseudo-random sign into one of `count` (<= 64) buckets, scaled by
+    1/sqrt(numel); float64.  E|S x|^2 = |x|^2, so with the golden sketch g and a measured one m,  |m - g| / |g|  estimates the
+    relative L2 distance of the full tensors to about 1/sqrt(count) of itself — unlike the plain element sum, whose error can
+    exceed the L2 error by sqrt(numel) when the difference has a coherent component.  Bucket and sign come from one byte per
+    element of numpy's PCG64 raw stream (stable by numpy's bit-generator policy), seeded from the tensor's name: one cheap pass."""
     flat = np.asarray(arr, dtype=np.float64).reshape(-1)
     n = flat.size
-    out = np.empty(count, dtype=np.float64)
-    for j in range(count):
-        sign = np.where(uniform01(f"proj{j}:" + name, 11, n) < 0.5, -1.0, 1.0)
-        out[j] = float(flat @ sign) / np.sqrt(n)
-    return out
+    raw = np.random.PCG64(0x5EED0000 + key_id("sketch:" + name)).random_raw((n + 7) // 8).view(np.uint8)[:n]
+    sign = ((raw >> 6) & 1).astype(np.float64) * 2.0 - 1.0
+    return np.bincount(raw & (count - 1), weights=flat * sign, minlength=count) / np.sqrt(n)
 
 
 def proj_rel_err(name: str, mine: np.ndarray, golden_proj: np.ndarray) -> float:

@@ -252,6 +252,35 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
   }
 }
 
+// 16-byte variants (C, pitches multiples of 4, aligned pointers): blockIdx.y = sample, threads over (position, channel quad) —
+// no per-element 64-bit division, a quarter of the memory instructions.  dmean == nullptr: forward (out = x * gate).
+__global__ __launch_bounds__(256) void gate_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                             const float* __restrict__ dmean, int P, int C, int in_ld, int out_ld,
+                                                             float* __restrict__ out) {
+  const int n = blockIdx.y, cq = C >> 2;
+  const long long rows0 = (long long)n * P;
+  const float invP = 1.f / (float)P;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P * cq; i += 256 * gridDim.x) {
+    const int pp = i / cq, c = (i - pp * cq) * 4;
+    const floatx4 v = *reinterpret_cast<const floatx4*>(x + (rows0 + pp) * in_ld + c);
+    const floatx4 g = *reinterpret_cast<const floatx4*>(gate + (long long)n * C + c);
+    floatx4 o = v * g;
+    if (dmean) o += *reinterpret_cast<const floatx4*>(dmean + (long long)n * C + c) * invP;
+    *reinterpret_cast<floatx4*>(out + (rows0 + pp) * out_ld + c) = o;
+  }
+}
+
+bool gate_vec_ok(int P, int C, int ld_a, int ld_b, const void* a, const void* b, const void* g, const void* m) {
+  return C % 4 == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && rsp_aligned16(a) && rsp_aligned16(b) && rsp_aligned16(g) &&
+         (!m || rsp_aligned16(m)) && (long long)P * (C / 4) < (1ll << 31);
+}
+
+int gate_vec_blocks(int P, int C, int N) {
+  long long b = ((long long)P * (C / 4) + 255) / 256;
+  const long long cap = 4096 / (N > 0 ? N : 1) + 1;      // ~4096 workgroups over all samples
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
 bool mp_ok(const rsp_pool3d_desc* d) {
   if (!d) return false;
   if (d->N <= 0 || d->C <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0) return false;
@@ -335,7 +364,11 @@ int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld,
   rc = rsp_check_launch("gate_fc_kernel");
   if (rc != RSP_OK) return rc;
   const long long total = (long long)N * P * C;
-  hipLaunchKernelGGL(gate_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, gate, P, C, in_ld, out_ld, total, out);
+  if (gate_vec_ok(P, C, in_ld, out_ld, x, out, gate, nullptr))
+    hipLaunchKernelGGL(gate_apply_vec_kernel, dim3(gate_vec_blocks(P, C, N), N), dim3(256), 0, s, x, gate, (const float*)nullptr, P, C,
+                       in_ld, out_ld, out);
+  else
+    hipLaunchKernelGGL(gate_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, gate, P, C, in_ld, out_ld, total, out);
   return rsp_check_launch("gate_apply_kernel");
 }
 
@@ -370,8 +403,12 @@ int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_
   rc = rsp_check_launch("gate_bwd_dmean_kernel");
   if (rc != RSP_OK) return rc;
   const long long total = (long long)N * P * C;
-  hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dout, gate, dmean, P, C, dout_ld, dx_ld,
-                     total, dx);
+  if (gate_vec_ok(P, C, dout_ld, dx_ld, dout, dx, gate, dmean))
+    hipLaunchKernelGGL(gate_apply_vec_kernel, dim3(gate_vec_blocks(P, C, N), N), dim3(256), 0, s, dout, gate, dmean, P, C, dout_ld,
+                       dx_ld, dx);
+  else
+    hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dout, gate, dmean, P, C, dout_ld, dx_ld,
+                       total, dx);
   return rsp_check_launch("gate_bwd_apply_kernel");
 }
 
