@@ -672,9 +672,23 @@ int launch_cfg(const IgemmParams& p, hipStream_t s) {
   return rsp_check_launch("igemm_kernel");
 }
 
+// N-tile width of a column segment.  Besides 128 / 64 / 32 there are two odd widths, run by 4 waves stacked along M (each wave
+// 32 rows x the whole tile width): 160 for segments of 129..160 columns and 96 for 65..96 — one pass over the A operand with
+// 90-100 % of the MFMA work useful, where 128 + a narrow second launch re-reads A for a few columns (R(2+1)D's 144-channel
+// layers, S3D-G's 96 / 160) and a 128-wide tile for 96 columns wastes a quarter of it.
+inline int tile_bn(int Cout) {
+#ifdef RSP_TUNE
+  if (getenv("RSP_NO_ODD_TILES")) return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+#endif
+  if (Cout > 128 && Cout <= 160) return 160;
+  if (Cout > 64 && Cout <= 96) return 96;
+  return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+}
+
 int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   // BM is fixed at 128 (stat partials are defined on 128-row tiles); BN follows Cout.
-  int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
+  int bn = tile_bn(p.Cout);
+  if (!vec4 && (bn == 160 || bn == 96)) bn = 128;      // the scalar-gather fallback only has the power-of-two tiles
   p.m_tiles = rsp_cdiv(p.M, 128);
   p.n_tiles = rsp_cdiv(p.Cout, bn);
 #ifdef RSP_TUNE
@@ -683,6 +697,8 @@ int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
     return launch_cfg<256, 128, 2, 2, 4, 1>(p, s);
   }
 #endif
+  if (bn == 160) return launch_cfg<128, 160, 4, 1, 4>(p, s);
+  if (bn == 96) return launch_cfg<128, 96, 4, 1, 4>(p, s);
   if (bn == 128) return vec4 ? launch_cfg<128, 128, 2, 2, 4>(p, s) : launch_cfg<128, 128, 2, 2, 1>(p, s);
   if (bn == 64) return vec4 ? launch_cfg<128, 64, 2, 2, 4>(p, s) : launch_cfg<128, 64, 2, 2, 1>(p, s);
   return vec4 ? launch_cfg<128, 32, 4, 1, 4>(p, s) : launch_cfg<128, 32, 4, 1, 1>(p, s);
@@ -702,7 +718,7 @@ struct SplitPlan {
 SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, int Cout) {
   const int tiles = m_tiles * n_tiles;
   // resident workgroups per CU of igemm_kernel<128, bn, .., VEC>: LDS-limited (DMA variants) or VGPR-limited (scalar gather)
-  const int wpc = vec4 ? (bn >= 128 ? 2 : 3) : (bn >= 64 ? 2 : 3);
+  const int wpc = vec4 ? (bn >= 96 ? 2 : 3) : (bn >= 64 ? 2 : 3);
   const int slots = 256 * wpc;
   SplitPlan best = {tiles, 1, nchunks};
   if (nchunks < 8) return best;
@@ -764,7 +780,6 @@ void fill_reduce(ReduceParams& r, const IgemmParams& p) {
   r.out_ld = p.out_ld;
 }
 
-inline int tile_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
 size_t split_partial_bytes(const SplitPlan& sp, long long M, int n_tiles, int Cout) {
   if (sp.splitk <= 1) return 0;
@@ -790,7 +805,8 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   }
 #endif
   p.nchunks = rsp_cdiv(p.K, BK);
-  const int bn = tile_bn(p.Cout);
+  int bn = tile_bn(p.Cout);
+  if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
   SplitPlan sp = plan_split(m_tiles, n_tiles, bn, vec4, p.nchunks, p.Cout);
 #ifdef RSP_TUNE
@@ -848,7 +864,7 @@ Segments plan_segments(int Cout) {
 #ifdef RSP_TUNE
   if (getenv("RSP_NO_SEGMENTS")) return {1, {0, 0}, {Cout, 0}};
 #endif
-  if (full == 0 || r == 0 || r > 64) {
+  if (full == 0 || r == 0 || r > 64 || tile_bn(Cout) == 160) {
     g.n = 1; g.c0[0] = 0; g.width[0] = Cout; g.c0[1] = 0; g.width[1] = 0;
   } else {
     g.n = 2; g.c0[0] = 0; g.width[0] = full; g.c0[1] = full; g.width[1] = r;
@@ -891,11 +907,11 @@ size_t igemm_partial_bytes_segment(long long M, int Cout, int K) {
 #ifdef RSP_TUNE
   if (getenv("RSP_SPLIT")) return (size_t)16 * M * Cout * sizeof(float);   // room for any forced split
 #endif
-  const int bn = tile_bn(Cout);
-  const int m_tiles = rsp_cdiv(M, 128), n_tiles = rsp_cdiv(Cout, bn);
+  const int bn = tile_bn(Cout), bn_s = (bn == 160 || bn == 96) ? 128 : bn;     // scalar-gather fallback: power-of-two tiles only
+  const int m_tiles = rsp_cdiv(M, 128), n_tiles = rsp_cdiv(Cout, bn), n_tiles_s = rsp_cdiv(Cout, bn_s);
   // the gather variant (hence the plan) depends on pointer alignment, unknown here: size for the larger of the two
   const size_t a = split_partial_bytes(plan_split(m_tiles, n_tiles, bn, true, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
-  const size_t b = split_partial_bytes(plan_split(m_tiles, n_tiles, bn, false, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
+  const size_t b = split_partial_bytes(plan_split(m_tiles, n_tiles_s, bn_s, false, rsp_cdiv(K, BK), Cout), M, n_tiles_s, Cout);
   return a > b ? a : b;
 }
 
