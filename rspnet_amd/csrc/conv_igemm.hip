@@ -54,8 +54,10 @@ struct IgemmParams {
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
-__global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
+// `bid` / `nblk`: this workgroup's index and the number of workgroups of ITS problem (blockIdx.x / gridDim.x for a single
+// problem; offsets into a shared grid when several problems run in one launch, igemm_multi_kernel).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC>
+__device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, const int nblk) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
@@ -86,11 +88,11 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   // K-slice u / R, so neighbouring units share the weight slice in L2) and leave fp32 partials for splitk_reduce_kernel.
   int tile, z = 0;
   bool is_partial = false;
-  if ((int)blockIdx.x < p.full_tiles) {
-    tile = rsp_xcd_remap(blockIdx.x, p.full_tiles);
+  if (bid < p.full_tiles) {
+    tile = rsp_xcd_remap(bid, p.full_tiles);
   } else {
     const int R = p.m_tiles * p.n_tiles - p.full_tiles;
-    const int u = rsp_xcd_remap(blockIdx.x - p.full_tiles, (int)gridDim.x - p.full_tiles);
+    const int u = rsp_xcd_remap(bid - p.full_tiles, nblk - p.full_tiles);
     z = u / R;
     tile = p.full_tiles + (u - z * R);
     is_partial = p.splitk > 1;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
 #ifdef RSP_TUNE
   // experiment: start the second workgroup of each CU half a chunk late so that the two co-resident waves of a SIMD
   // alternate (one in its MFMA burst while the other fetches) instead of running their phases in lockstep
-  if ((p.tune & 16) && ((blockIdx.x >> 8) & 1)) {
+  if ((p.tune & 16) && ((bid >> 8) & 1)) {
     const int reps = (p.tune >> 8) & 0xff;
     for (int i = 0; i < (reps ? reps : 4); ++i) __builtin_amdgcn_s_sleep(16);
   }
@@ -430,6 +432,29 @@ __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
       }
     }
   }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
+  igemm_body<BM, BN, WAVES_M, WAVES_N, VEC>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several independent problems of one tile shape in a single launch: the stride-parity classes of a strided convolution's
+// input gradient (8 for stride (2,2,2)) are small GEMMs — R3D-18's layer4.0: 8 x (512 rows x 256 columns) — that each left
+// most of the machine idle as launches of their own (0.32 ms for 3.6 GFLOP).  Workgroup b belongs to class c with
+// start[c] <= b < start[c+1] and runs that class's tile b - start[c]; no K split in this mode.
+constexpr int MAX_MULTI = 8;
+struct IgemmMulti {
+  int n;
+  int start[MAX_MULTI + 1];
+  IgemmParams p[MAX_MULTI];
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void igemm_multi_kernel(const IgemmMulti m) {
+  int c = 0;
+  while (c + 1 < m.n && (int)blockIdx.x >= m.start[c + 1]) ++c;
+  igemm_body<BM, BN, WAVES_M, WAVES_N, VEC>(m.p[c], (int)blockIdx.x - m.start[c], m.start[c + 1] - m.start[c]);
 }
 
 // split-K reduction: y[row] = sum_z partial[z][row] + bias, stats per 128-row tile.
@@ -683,6 +708,20 @@ inline int tile_bn(int Cout) {
   if (Cout > 128 && Cout <= 160) return 160;
   if (Cout > 64 && Cout <= 96) return 96;
   return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
+int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)(max_taps + 1) * sizeof(int4) + BM * sizeof(long long);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const size_t lds_max = (size_t)2 * (BM + BN) * BK * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) + BM * sizeof(long long);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_multi_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_multi_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>), dim3(m.start[m.n]), dim3(256), lds, s, m);
+  return rsp_check_launch("igemm_multi_kernel");
 }
 
 int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
@@ -1075,12 +1114,16 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
       (void)hipMemset2DAsync(dx, (size_t)d->in_ld * 4, 0, (size_t)d->Cin * 4, rows, s);
     }
   }
+  // per-class GEMM descriptions
+  IgemmParams cls[64];
+  bool cvec[64];
+  int ncls = 0, max_taps = 0;
   size_t woff = 0;
   for (int c = 0; c < nclass; ++c) {
     const DgradClass g = dgrad_class(d, c);
     if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
     const int Kld = (int)rsp_align_up((size_t)g.nt * g.nh * g.nw * d->Cout, 4);
-    IgemmParams p;
+    IgemmParams& p = cls[ncls];
     memset(&p, 0, sizeof p);
     p.x = dy; p.w = wpk + woff; p.bias = nullptr; p.y = dx; p.stat = nullptr;
     p.M = d->N * g.Gd * g.Gh * g.Gw;
@@ -1103,11 +1146,64 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
     const unsigned long long wb = (unsigned long long)d->Cin * Kld * 4ull;
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
-    const bool vec4 = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && rsp_aligned16(p.w) && xb < (1ull << 32) &&
-                      wb < (1ull << 32) && g.nt <= 8 && g.nh <= 8 && g.nw <= 8;
-    int rc = run_igemm(p, vec4, part, part_bytes, s);
-    if (rc != RSP_OK) return rc;
+    cvec[ncls] = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && rsp_aligned16(p.w) && xb < (1ull << 32) &&
+                 wb < (1ull << 32) && g.nt <= 8 && g.nh <= 8 && g.nw <= 8;
+    max_taps = max_taps > g.nt * g.nh * g.nw ? max_taps : g.nt * g.nh * g.nw;
     woff += (size_t)d->Cin * Kld;
+    ++ncls;
+  }
+  // Small classes of a strided convolution share ONE launch (igemm_multi_kernel): every class on the LDS-DMA path, a single
+  // column segment, and few enough tiles that separate launches would each leave most of the machine idle.
+  bool multi = ncls >= 2 && ncls <= MAX_MULTI && plan_segments(d->Cin).n == 1;
+#ifdef RSP_TUNE
+  if (getenv("RSP_NO_MULTI")) multi = false;
+#endif
+  long long tiles_all = 0;
+  const int bn = tile_bn(d->Cin);
+  for (int i = 0; i < ncls && multi; ++i) {
+    multi = cvec[i];
+    tiles_all += (long long)rsp_cdiv(cls[i].M, 128) * rsp_cdiv(d->Cin, bn);
+  }
+  // (below ~one round of resident workgroups the classes need the K split of the single-problem path to fill the machine —
+  //  R3D-18 layer4.0: 64 tiles of 128 chunks; above a few thousand tiles each class fills it on its own)
+  if (multi && tiles_all >= 512 && tiles_all <= 4096) {
+    static const float* zero_page = nullptr;
+    if (!zero_page) {
+      void* z = nullptr;
+      if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero)) != hipSuccess || !z) {
+        rsp_set_error("hipGetSymbolAddress(g_zero) failed");
+        return RSP_ELAUNCH;
+      }
+      zero_page = reinterpret_cast<const float*>(z);
+    }
+    IgemmMulti m;
+    memset(&m, 0, sizeof m);
+    m.n = ncls;
+    for (int i = 0; i < ncls; ++i) {
+      IgemmParams& p = cls[i];
+      p.zero = zero_page;
+      p.stat_ld = p.Cout;
+      p.nchunks = rsp_cdiv(p.K, BK);
+      p.m_tiles = rsp_cdiv(p.M, 128);
+      p.n_tiles = rsp_cdiv(p.Cout, bn);
+      p.full_tiles = p.m_tiles * p.n_tiles;
+      p.splitk = 1;
+      p.chunks_per_split = p.nchunks;
+      p.tail_row0 = p.m_tiles * 128;
+      m.p[i] = p;
+      m.start[i + 1] = m.start[i] + p.full_tiles;
+    }
+    switch (bn) {
+      case 160: return launch_multi_cfg<128, 160, 4, 1, 4>(m, max_taps, s);
+      case 128: return launch_multi_cfg<128, 128, 2, 2, 4>(m, max_taps, s);
+      case 96: return launch_multi_cfg<128, 96, 4, 1, 4>(m, max_taps, s);
+      case 64: return launch_multi_cfg<128, 64, 2, 2, 4>(m, max_taps, s);
+      default: return launch_multi_cfg<128, 32, 4, 1, 4>(m, max_taps, s);
+    }
+  }
+  for (int i = 0; i < ncls; ++i) {
+    int rc = run_igemm(cls[i], cvec[i], part, part_bytes, s);
+    if (rc != RSP_OK) return rc;
   }
   return RSP_OK;
 }

@@ -1,0 +1,52 @@
+"""GPU, needs >= 2 devices (skipped on the 1-GPU test box): the 2-rank DDP fixtures through REAL RCCL — one process per GPU,
+`nccl` backend, the product's clip all-to-all (uneven splits), fused key all-gather, bucketed gradient all-reduce launched
+from inside backward and the gloo side group next to the RCCL group — compared with the reference-under-DDP goldens exactly as
+tests/test_distributed_cpu.py does over gloo with the checker backend and tests/test_two_rank_gpu.py does with the HIP kernels
+over the in-process threaded group.  This is the only test that executes the RCCL collectives themselves."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from golden_util import cases_for
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, ws, arch, seed, port, tmp):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from golden_util import build_inputs, compare_to_golden, grad_tol, load_case, worst_grad_err
+    from model_util import run_model_step
+    from rspnet_amd import ops
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=dev)
+    assert ops.backend().name == "hip"
+    z, meta = load_case(arch, ws, seed)
+    spec, inputs = build_inputs(arch, meta)
+    res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, dev, "fused")
+    compare_to_golden(z, rank, res, post, mom_post, tol=1e-3, tol_grad=grad_tol(arch))
+    wkey, worst = worst_grad_err(z, rank, grads)
+    assert worst <= grad_tol(arch), (wkey, worst)
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([worst]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
+@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "c3d:linear:4", "resnet18") for a, w, s in cases_for(arch, 2)][:3])
+def test_two_ranks_over_rccl_match_the_ddp_fixture(arch, seed):
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, arch, seed, _free_port(), tmp), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
