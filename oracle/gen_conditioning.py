@@ -4,7 +4,8 @@
 on the same inputs with the same code — fp32 as the reference does (oneDNN convolutions, fused batch_norm), fp64, fp32 with
 oneDNN switched off (ATen's native convolution) and fp32 with BatchNorm evaluated in its folded scale/shift form (what a fused
 conv+BN kernel computes): the same function in other summation / evaluation orders, which is all that separates any two
-correct fp32 implementations — and records, per case, the relative L2 distance of the variants' parameter gradients (max and
+correct fp32 implementations — plus, as a fourth order, the product's host logic on the torch checker backend compared with
+the gradients stored in the fixture — and records, per case, the relative L2 distance of the variants' parameter gradients (max and
 median over tensors) and logits from the default run in tests/golden/conditioning.json; `grad_rel_l2_max` is the larger one.
 
 Why: in a ReLU / max-pool network the backward pass is discontinuous in the forward values.  Two correct fp32
@@ -39,6 +40,7 @@ def measure(tag, seed, meta=None, spec=None, fast=False):
     if spec is None:
         with open(os.path.join(GOLDEN, f"state_spec_{G.tag_file(tag)}.json")) as f:
             spec = {k: (tuple(s), d) for k, (s, d) in json.load(f).items()}
+    z = None
     if meta is None:
         z = np.load(os.path.join(GOLDEN, G.case_name(tag, 1, seed) + ".npz"))
         meta = json.loads(str(z["meta"]))
@@ -76,6 +78,10 @@ def measure(tag, seed, meta=None, spec=None, fast=False):
         out[f"grad_rel_l2_max_{tag_v}"] = max(errs)
         out[f"grad_rel_l2_median_{tag_v}"] = float(np.median(errs))
         out[f"logits_rel_{tag_v}"] = float((other["logits1"].double() - o32["logits1"].double()).abs().max() / o32["logits1"].abs().max())
+    if z is not None and "r0.gradproj." + next(k for k, g in o32["grads"].items() if g is not None) in z.files:
+        # fourth evaluation order: the product's host logic on the torch checker backend (channels-last convolutions, folded
+        # BatchNorm, fused sibling GEMMs) against the reference's own gradients stored in the fixture (sketch estimate)
+        out["grad_rel_l2_max_checker"] = G.checker_grad_error(tag, meta, spec, z)
     out["grad_rel_l2_max"] = max(v for k, v in out.items() if k.startswith("grad_rel_l2_max_"))
     return out
 
@@ -83,7 +89,9 @@ def measure(tag, seed, meta=None, spec=None, fast=False):
 def main():
     only = sys.argv[1:]
     path = os.path.join(GOLDEN, "conditioning.json")
-    out = json.load(open(path)) if os.path.exists(path) else {}
+    out = json.load(open(path)) if (only and os.path.exists(path)) else {}      # a full run starts from scratch
+    for tag in only:
+        out.pop(tag, None)
     with open(os.path.join(GOLDEN, "index.json")) as f:
         index = json.load(f)
     for tag, ws, seed in index:
@@ -91,7 +99,7 @@ def main():
             continue
         m = measure(tag, seed)
         prev = out.get(tag)
-        out[tag] = m if prev is None else {k: max(m[k], prev[k]) for k in m}       # worst over the arch's seeds
+        out[tag] = m if prev is None else {k: max(m[k], prev.get(k, 0.0)) for k in m}       # worst over the arch's seeds
         print(tag, seed, m, flush=True)
         with open(path, "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)

@@ -44,7 +44,8 @@ def product_grad_error(arch, ncls, state, x, target, grads):
         loss = torch.nn.CrossEntropyLoss()(model(torch.from_numpy(x)), torch.from_numpy(target))
         loss.backward()
         return max(P.proj_rel_err(n, p.grad.numpy(), P.projections(n, grads[n])) for n, p in model.named_parameters()
-                   if grads[n] is not None and float(np.abs(grads[n]).max()) > 0)
+                   if grads[n] is not None and float(np.sqrt((grads[n].astype(np.float64) ** 2).sum())) >= 1e-4)   # (skip the
+        # mathematically-zero gradients of conv biases in front of train-mode BN: rounding noise in the reference)
     finally:
         ops.set_backend(prev)
 

@@ -41,7 +41,8 @@ def _worker(rank, ws, arch, seed, port, tmp):
 from golden_util import cases_for
 
 
-@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "c3d:linear:4", "resnet18", "r2plus1d-vcop", "s3dg") for a, w, s in cases_for(arch, 2)])
+@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "c3d:linear:4", "resnet18") for a, w, s in cases_for(arch, 2)][1:])      # (c3d: its second 2-rank seed;
+# the R(2+1)D / S3D-G 2-rank fixtures and the first C3D one run with the HIP kernels in tests/test_two_rank_gpu.py)
 def test_two_rank_step_matches_golden(arch, seed):
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:

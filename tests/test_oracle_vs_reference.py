@@ -24,9 +24,9 @@ def test_pretext_step_restatement_equals_reference_live():
     model = R.build_reference_model(arch, K=K)
     spec = R.state_spec(model)
     state, mom, clips, perms_B, sh = G.case_inputs(spec, arch, B, HW, K, 1, seed)
-    ref = R.run_reference_step(model, state, clips[0][0], clips[0][1], [perms_B[0], sh[0], sh[1]], G.SPEED, lr=G.LR,
+    ref = R.run_reference_step(model, state, clips[0][0], clips[0][1], [perms_B[0], sh[0], sh[1]], 2, lr=G.LR,
                                momentum_buffers=mom)
-    meta = dict(arch=arch, fc_type="linear", B=B, HW=HW, K=K, ws=1, seed=seed, lr=G.LR, speed=G.SPEED, m=0.999, T=0.07,
+    meta = dict(arch=arch, fc_type="linear", B=B, HW=HW, K=K, ws=1, seed=seed, lr=G.LR, speed=2, m=0.999, T=0.07,
                 sgd_momentum=0.9, weight_decay=1e-4, margin=2.0, A=1.0, M=1.0)
     outs, states, moms = run_restatement(arch, meta, (state, mom, clips, perms_B, sh))
     o = outs[0]
