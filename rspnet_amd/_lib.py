@@ -128,6 +128,15 @@ def load() -> C.CDLL:
         raise RspError(
             f"{LIB_PATH} not found: build it with rspnet_amd/csrc/build.sh (or __graft_entry__.build()). "
             "rspnet_amd has no CPU or eager fallback.")
+    # Let PyTorch bring up the HIP runtime BEFORE this library (a HIP fat binary linked against libamdhip64) is mapped: loaded
+    # the other way round — library first, runtime initialised later by torch — every launch from the library failed with "no
+    # ROCm-capable device is detected" on the GPU box (observed with build() + smoke() in one process).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -267,7 +267,6 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
   int* taptab = reinterpret_cast<int*>(Bs + p.nchunks * BU * 4);               // [nchunks*TCH]
   long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nchunks * TCH);  // [128]
   float* red = reinterpret_cast<float*>(rowaddr + 128);                        // [4 waves][64][2]
-  float* stage = red + 512;                                                    // [4 waves][32][32] (wide epilogue)
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -385,7 +384,6 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
       rowaddr[t] = (ho < p.Ho && wo < p.Wo) ? ((((long long)n * p.Do + to) * p.Ho + ho) * p.Wo + wo) * p.out_ld : -1;
     }
     __syncthreads();
-    if (p.wide) stem_store_wide(p, acc, stage + wave * 1024, rowaddr, wave, lane);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = 32 * j + l32;
@@ -396,9 +394,9 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
         const long long addr = rowaddr[wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3)];
         const float v = addr >= 0 ? acc[j][e] : 0.f;
 #ifdef RSP_TUNE
-        if (!p.wide && addr >= 0 && col < p.Cout && !((p.tune & 1) && v != 12345.f)) p.y[addr + col] = v + bv;
+        if (addr >= 0 && col < p.Cout && !((p.tune & 1) && v != 12345.f)) p.y[addr + col] = v + bv;
 #else
-        if (!p.wide && addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
+        if (addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
 #endif
         s += v;
         ss = fmaf(v, v, ss);
@@ -500,7 +498,7 @@ StemPlan stem_plan(const rsp_conv3d_desc* d) {
   s.tiles = (long long)d->N * d->Do * s.tiles_h * s.tiles_w;
   if (s.tiles >= (1ll << 31)) return s;
   const size_t lds_res = (size_t)2 * d->kT * s.npix_r * 16 + (size_t)s.nchunks * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 +
-                         128 * 8 + 2048 + 16384;   // ... + stat scratch + the wide epilogue's 4 x 4 KB staging squares
+                         128 * 8 + 2048;
   s.resident = d->kT <= 3 && lds_res <= 78 * 1024;      // two workgroups per CU at least
 #ifdef RSP_TUNE
   if (getenv("RSP_STEM_STREAM")) s.resident = false;
@@ -580,7 +578,9 @@ int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed
   p.npix = pl.npix; p.npix_r = pl.npix_r; p.FR = pl.FR;
   p.ntaps = d->kT * d->kH * d->kW; p.nchunks = pl.nchunks;
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles = (int)pl.tiles;
-  p.wide = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && (!bias || rsp_aligned16(bias));
+  // wide epilogue only on the streaming variant, where the idle weight ring is the staging area: in the resident kernel the
+  // extra 16 KB of LDS (or the registers of a second epilogue path) cost the third workgroup per CU (C3D conv1: 1.02 -> 1.11 ms)
+  p.wide = !pl.resident && d->Cout % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && (!bias || rsp_aligned16(bias));
 #ifdef RSP_TUNE
   if (getenv("RSP_STEM_NARROW")) p.wide = 0;
 #endif
