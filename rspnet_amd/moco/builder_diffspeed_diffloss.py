@@ -129,6 +129,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._cpu_group = None
         self._last_q = None
         self._last_k = []
+        self._last_speed = None
         self._pending = []
         self._q_version = None
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
@@ -348,6 +349,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             random_indices = torch.randperm(B, device=dev)
             n1 = int(B * self.alpha)
             speed, sh1, sh2 = self._draw_step_randomness(B)
+            self._last_speed = speed
             T_real = T // speed
             step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
             step_q[random_indices[:n1].to(dev)] = 1                      # s1 rows play q,k at normal speed

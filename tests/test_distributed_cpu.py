@@ -63,3 +63,48 @@ def test_two_ranks_as_threads_device_broadcast_fallback():
         run_two_ranks(arch, seed, torch.device("cpu"))
     finally:
         ops.set_backend(prev)
+
+
+def _speed_worker(rank, ws, port, tmp):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import random
+    import torch.distributed as dist
+    from cpu_ops import CpuOps
+    from model_util import make_cfg
+    from rspnet_amd import ops
+    from rspnet_amd.moco import Loss, ModelFactory
+    torch.set_num_threads(4)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    ops.set_backend(CpuOps())
+    random.seed(100 + rank)                      # per-rank seeds, as utils.reproduction.initialize_seed(seed + local_rank)
+    torch.manual_seed(100 + rank)
+    wrapped = ModelFactory(make_cfg("c3d", 64, speeds=(4, 2, 1))).build_moco_diffloss(device=torch.device("cpu"))
+    wrapped.train()
+    crit = Loss(margin=2.0)
+    speeds, own = [], []
+    for it in range(4):
+        state = random.getstate()
+        own.append(random.choice([4, 2, 1]))     # what this rank WOULD draw on its own ...
+        random.setstate(state)                   # ... (the model draws the same value next)
+        im = torch.randn(2, 3, 32, 16, 16)
+        out, tgt, rl, rt = wrapped(im, im + 0.1 * torch.randn_like(im))
+        loss, _, _ = crit(out, tgt, rl, rt)
+        loss.backward()
+        speeds.append(wrapped.module._last_speed)
+    np.save(os.path.join(tmp, f"speeds{rank}.npy"), np.array([speeds, own]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_speed_draw_is_shared_across_ranks():
+    """diff_speed=[4,2,1] with per-rank Python RNG seeds: every rank must run rank 0's speed (T_real fixes the shapes of the clip
+    all-to-all and of the key all-gather; independent draws, as in the reference, make them disagree — ADVICE r1)."""
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_speed_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        s0, s1 = np.load(os.path.join(tmp, "speeds0.npy")), np.load(os.path.join(tmp, "speeds1.npy"))
+    assert (s0[0] == s1[0]).all() and (s0[0] == s0[1]).all()          # both ran what rank 0 drew
+    assert (s1[1] != s1[0]).any(), "the ranks' own draws never differed: the test would not notice independent speeds"
