@@ -15,6 +15,7 @@
 // against 8 x 16-B global loads per thread: staging hides completely behind the matrix pipe; tap re-reads of the
 // input are served by L2 (27 x re-read of conv2's 411 MB input = 1.6 TB/s of L2 traffic, L2 peak 34 TB/s).
 #include "common.h"
+#include <type_traits>
 #include "conv_stem.h"
 
 namespace {
@@ -25,6 +26,30 @@ constexpr int MAX_TAPS = 343;  // 7x7x7
 
 // 64 B of zeros: out-of-bounds taps / rows / K-tail lanes load from here instead of branching around the load
 __device__ __attribute__((aligned(64))) float g_zero[16];
+
+// Division by a launch constant as multiply-high + shift (the prologue of every tile decodes 4 GEMM rows per thread into
+// (n, d, h, w) and its k position into (tap, channel): with hardware-free integer division that was ~1000 instructions
+// per wave).  Exact for 0 <= n < 2^31: mul = ceil(2^(31+s) / d), s = ceil(log2 d); q = umulhi(n, mul) >> (s - 1).
+struct FastDiv {
+  unsigned mul;   // 0: divisor 1
+  unsigned shr;
+  int d;
+};
+
+inline FastDiv fastdiv_make(int d) {
+  FastDiv f = {0u, 0u, d};
+  if (d <= 1) return f;
+  int s = 0;
+  while ((1ll << s) < d) ++s;
+  const unsigned long long pw = 1ull << (31 + s);
+  f.mul = (unsigned)((pw + (unsigned long long)d - 1) / (unsigned long long)d);
+  f.shr = (unsigned)(s - 1);
+  return f;
+}
+
+__device__ __forceinline__ int fastdiv(int n, const FastDiv f) {
+  return f.mul ? (int)(__umulhi((unsigned)n, f.mul) >> f.shr) : n;
+}
 
 struct IgemmParams {
   const float* __restrict__ x;
@@ -38,6 +63,7 @@ struct IgemmParams {
   int oDm, oHm, oWm;            // output memory dims
   int oSd, oSh, oSw, oOd, oOh, oOw;  // memory coord = g*oS + oO
   int out_ld, Cout;
+  int linear_out;                // output address = row * out_ld (dense output grid): set by fill_fastdiv()
   int stat_ld;                  // channels per stat-partial row (= Cout of the whole convolution; this launch may cover a column segment)
   int Di, Hi, Wi, in_ld, Cin;   // input tensor
   int sD, sH, sW;               // in coord = g*s + off(tap)
@@ -51,8 +77,12 @@ struct IgemmParams {
   int m_tiles, n_tiles;
   const float* __restrict__ zero;  // >= 64 B of zeros (g_zero)
   unsigned x_bytes, w_bytes;       // extents for the buffer descriptors of the DMA path (< 4 GiB)
+  FastDiv dGw, dGh, dGd, dCin, dTw, dTh;   // filled by fill_fastdiv() from Gw, Gh, Gd, Cin, nTw, nTh
+  int adv_tap, adv_ci;                     // BK / Cin, BK % Cin
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
+
+inline void fill_fastdiv(IgemmParams& p);
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups of ITS problem (blockIdx.x / gridDim.x for a single
 // problem; offsets into a shared grid when several problems run in one launch, igemm_multi_kernel).
@@ -105,8 +135,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   // ---- tap table --------------------------------------------------------------------------------------
   const int ntaps = p.nTd * p.nTh * p.nTw;
   for (int i = t; i < ntaps; i += 256) {
-    const int aw = i % p.nTw, q = i / p.nTw;
-    const int ah = q % p.nTh, ad = q / p.nTh;
+    const int q = fastdiv(i, p.dTw), aw = i - q * p.nTw;
+    const int ad = fastdiv(q, p.dTh), ah = q - ad * p.nTh;
     const int od = p.off0d + ad * p.offstep, oh = p.off0h + ah * p.offstep, ow = p.off0w + aw * p.offstep;
     // DMA path: .x = the three validity bits this tap needs from a row's bit set (see rbits below); scalar path: the offsets
     taptab[i] = DMA ? make_int4((1 << ad) | (1 << (8 + ah)) | (1 << (16 + aw)), 0, 0, ((od * p.Hi + oh) * p.Wi + ow) * p.in_ld)
@@ -124,12 +154,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   for (int i = 0; i < AR; ++i) {
     const int r = m0 + arow + 32 * i;
     if (r < p.M) {
-      const int gw = r % p.Gw;
-      int q = r / p.Gw;
-      const int gh = q % p.Gh;
-      q /= p.Gh;
-      const int gd = q % p.Gd;
-      const int n = q / p.Gd;
+      const int q1 = fastdiv(r, p.dGw), gw = r - q1 * p.Gw;
+      const int q2 = fastdiv(q1, p.dGh), gh = q1 - q2 * p.Gh;
+      const int n = fastdiv(q2, p.dGd), gd = q2 - n * p.Gd;
       aid[i] = gd * p.sD;
       aih[i] = gh * p.sH;
       aiw[i] = gw * p.sW;
@@ -156,13 +183,13 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   // (tap, ci) of this thread's k position(s) in the NEXT chunk to load, advanced incrementally (no division in the loop);
   // the tap-table entry is fetched one chunk ahead so its LDS latency hides behind the MFMAs.
   constexpr int NE = VEC == 4 ? 1 : 4;
-  const int adv_tap = BK / p.Cin, adv_ci = BK % p.Cin;
+  const int adv_tap = p.adv_tap, adv_ci = p.adv_ci;
   int ntap[NE], nci[NE];
   int4 ntt[NE];
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int k = kc_begin * BK + kcol + e;
-    ntap[e] = k / p.Cin;
+    ntap[e] = fastdiv(k, p.dCin);
     nci[e] = k - ntap[e] * p.Cin;
     ntt[e] = taptab[min(ntap[e], ntaps - 1)];
   }
@@ -185,11 +212,16 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     rowok[i] = false;
     // per-row validity, one bit per tap index and dimension (bits 0-7: d, 8-15: h, 16-23: w): whether a tap is inside the
     // input for this row is then two VALU ops when the lane's tap changes, instead of three range checks per row
+    // (the taps of one dimension that fall inside the input form an interval [lo, hi]: with c the coordinate of tap 0 —
+    //  mirrored for the descending taps of dgrad — tap a is inside iff 0 <= c + a < D)
     unsigned m = 0;
     if (DMA) {
-      for (int a = 0; a < p.nTd; ++a) m |= (unsigned)((unsigned)(aid[i] + p.off0d + a * p.offstep) < (unsigned)p.Di) << a;
-      for (int a = 0; a < p.nTh; ++a) m |= (unsigned)((unsigned)(aih[i] + p.off0h + a * p.offstep) < (unsigned)p.Hi) << (8 + a);
-      for (int a = 0; a < p.nTw; ++a) m |= (unsigned)((unsigned)(aiw[i] + p.off0w + a * p.offstep) < (unsigned)p.Wi) << (16 + a);
+      auto span = [&](int base, int D, int nT) -> unsigned {
+        const int c = p.offstep > 0 ? base : D - 1 - base;
+        const int lo = min(max(0, -c), 8), hi = min(nT - 1, D - 1 - c);
+        return hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+      };
+      m = span(aid[i] + p.off0d, p.Di, p.nTd) | (span(aih[i] + p.off0h, p.Hi, p.nTh) << 8) | (span(aiw[i] + p.off0w, p.Wi, p.nTw) << 16);
     }
     rbits[i] = m;
   }
@@ -348,47 +380,64 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------
-  // row -> output address table (general affine mapping: identity for forward, strided class grid for dgrad)
-  if (t < BM) {
-    const int r = m0 + t;
-    long long addr = -1;
-    if (r < p.M) {
-      if (is_partial) {
-        addr = ((long long)z * (p.M - p.tail_row0) + (r - p.tail_row0)) * p.Cout;
-      } else {
-        const int gw = r % p.Gw;
-        int q = r / p.Gw;
-        const int gh = q % p.Gh;
-        q /= p.Gh;
-        const int gd = q % p.Gd;
-        const int n = q / p.Gd;
+  // GEMM row -> output address.  Forward outputs, stride-1 input gradients and the K-split partials are LINEAR in the row
+  // (address = base + row * pitch): plain arithmetic.  The strided parity classes of dgrad go through a per-tile table
+  // of the general affine mapping.
+  const bool linear = is_partial || p.linear_out;   // uniform
+  if (!linear) {
+    if (t < BM) {
+      const int r = m0 + t;
+      long long addr = -1;
+      if (r < p.M) {
+        const int q1 = fastdiv(r, p.dGw), gw = r - q1 * p.Gw;
+        const int q2 = fastdiv(q1, p.dGh), gh = q1 - q2 * p.Gh;
+        const int n = fastdiv(q2, p.dGd), gd = q2 - n * p.Gd;
         addr = ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw +
                 p.oOw) * p.out_ld;
       }
+      rowaddr[t] = addr;
     }
-    rowaddr[t] = addr;
+    __syncthreads();
   }
-  __syncthreads();
 
   float* dst = is_partial ? p.partial : p.y;
+  const long long lin_ld = is_partial ? p.Cout : p.out_ld;
+  const long long lin_base = is_partial ? ((long long)z * (p.M - p.tail_row0) - p.tail_row0) * p.Cout : 0ll;
+  // A tile that lies wholly inside the M rows (all but the last row of tiles) stores without per-row checks: straight-line
+  // code instead of one LDS round trip + branch in front of every store.
+  auto store_tile = [&](auto checked, auto lin) {
+    constexpr bool CHK = decltype(checked)::value, LIN = decltype(lin)::value;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * WN + j * 32 + l32;
-    if (col < p.Cout) {
-      const float bv = (p.bias && !is_partial) ? p.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WN + j * 32 + l32;
+      if (col < p.Cout) {
+        const float bv = (p.bias && !is_partial) ? p.bias[col] : 0.f;
+        float* lane0 = dst + lin_base + (long long)(m0 + wm * WM + h * 4) * lin_ld + col;   // LIN: row (i, e) = lane0 + const * pitch
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int rl = wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
-          const long long addr = rowaddr[rl];
+          for (int e = 0; e < 16; ++e) {
+            const int rl = wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
 #ifdef RSP_TUNE
-          if (addr >= 0 && !((p.tune & 256) && acc[i][j][e] != 12345.f)) dst[addr + col] = acc[i][j][e] + bv;
-#else
-          if (addr >= 0) dst[addr + col] = acc[i][j][e] + bv;
+            if ((p.tune & 256) && acc[i][j][e] != 12345.f) continue;
 #endif
-        }
+            if (LIN) {
+              if (!CHK || m0 + rl < p.M) lane0[(long long)(i * 32 + (e >> 2) * 8 + (e & 3)) * lin_ld] = acc[i][j][e] + bv;
+            } else {
+              const long long addr = rowaddr[rl];
+              if (!CHK || addr >= 0) dst[addr + col] = acc[i][j][e] + bv;
+            }
+          }
+      }
     }
+  };
+  const bool whole = m0 + BM <= p.M;
+  if (linear) {
+    if (whole) store_tile(std::false_type{}, std::true_type{});
+    else store_tile(std::true_type{}, std::true_type{});
+  } else {
+    if (whole) store_tile(std::false_type{}, std::false_type{});
+    else store_tile(std::true_type{}, std::false_type{});
   }
 
   if (p.stat && !is_partial) {
@@ -449,6 +498,7 @@ struct IgemmMulti {
   int start[MAX_MULTI + 1];
   IgemmParams p[MAX_MULTI];
 };
+static_assert(sizeof(IgemmMulti) <= 4096, "kernel argument segment");
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
 __global__ __launch_bounds__(256, MINW) void igemm_multi_kernel(const IgemmMulti m) {
@@ -724,6 +774,15 @@ int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
   return rsp_check_launch("igemm_multi_kernel");
 }
 
+inline void fill_fastdiv(IgemmParams& p) {
+  p.dGw = fastdiv_make(p.Gw); p.dGh = fastdiv_make(p.Gh); p.dGd = fastdiv_make(p.Gd);
+  p.dCin = fastdiv_make(p.Cin); p.dTw = fastdiv_make(p.nTw); p.dTh = fastdiv_make(p.nTh);
+  p.adv_tap = BK / p.Cin;
+  p.adv_ci = BK % p.Cin;
+  p.linear_out = p.oSd == 1 && p.oSh == 1 && p.oSw == 1 && p.oOd == 0 && p.oOh == 0 && p.oOw == 0 && p.oDm == p.Gd &&
+                 p.oHm == p.Gh && p.oWm == p.Gw;
+}
+
 int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   // BM is fixed at 128 (stat partials are defined on 128-row tiles); BN follows Cout.
   int bn = tile_bn(p.Cout);
@@ -844,6 +903,7 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   }
 #endif
   p.nchunks = rsp_cdiv(p.K, BK);
+  fill_fastdiv(p);
   int bn = tile_bn(p.Cout);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
@@ -1063,9 +1123,19 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   if (which == 0 && rsp_stem_applicable(d)) return rsp_stem_kernel_name(d);
   const int cin = which == 0 ? d->Cin : d->Cout, ld = which == 0 ? d->in_ld : d->out_ld, cols = which == 0 ? d->Cout : d->Cin;
   const bool vec4 = cin % 4 == 0 && ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 && d->kW <= 8;
-  const int bn = tile_bn(cols);
+  // (a convolution that runs as two column segments is named after the first, wider one)
+  int bn = tile_bn(plan_segments(cols).width[0]);
+  if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   // spelled as rocprofv3 prints the demangled instance (minus namespace and argument list)
-  if (vec4) return bn == 128 ? "igemm_kernel<128, 128, 2, 2, 4, 2>" : (bn == 64 ? "igemm_kernel<128, 64, 2, 2, 4, 2>" : "igemm_kernel<128, 32, 4, 1, 4, 2>");
+  if (vec4) {
+    switch (bn) {
+      case 160: return "igemm_kernel<128, 160, 4, 1, 4, 2>";
+      case 128: return "igemm_kernel<128, 128, 2, 2, 4, 2>";
+      case 96: return "igemm_kernel<128, 96, 4, 1, 4, 2>";
+      case 64: return "igemm_kernel<128, 64, 2, 2, 4, 2>";
+      default: return "igemm_kernel<128, 32, 4, 1, 4, 2>";
+    }
+  }
   return bn == 128 ? "igemm_kernel<128, 128, 2, 2, 1, 2>" : (bn == 64 ? "igemm_kernel<128, 64, 2, 2, 1, 2>" : "igemm_kernel<128, 32, 4, 1, 1, 2>");
 }
 
@@ -1184,6 +1254,7 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
       p.zero = zero_page;
       p.stat_ld = p.Cout;
       p.nchunks = rsp_cdiv(p.K, BK);
+      fill_fastdiv(p);
       p.m_tiles = rsp_cdiv(p.M, 128);
       p.n_tiles = rsp_cdiv(p.Cout, bn);
       p.full_tiles = p.m_tiles * p.n_tiles;
