@@ -1123,6 +1123,26 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   if (which == 0 && rsp_stem_applicable(d)) return rsp_stem_kernel_name(d);
   const int cin = which == 0 ? d->Cin : d->Cout, ld = which == 0 ? d->in_ld : d->out_ld, cols = which == 0 ? d->Cout : d->Cin;
   const bool vec4 = cin % 4 == 0 && ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 && d->kW <= 8;
+  if (which == 1 && vec4 && d->sT * d->sH * d->sW > 1 && plan_segments(cols).n == 1) {
+    // the stride-parity classes of a mid-sized strided dgrad share one launch (dgrad_run)
+    int ncls = 0;
+    long long tiles = 0;
+    for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
+      const DgradClass g = dgrad_class(d, c);
+      if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+      ++ncls;
+      tiles += (long long)rsp_cdiv(d->N * g.Gd * g.Gh * g.Gw, 128) * rsp_cdiv(cols, tile_bn(cols));
+    }
+    if (ncls >= 2 && ncls <= MAX_MULTI && tiles >= 512 && tiles <= 4096) {
+      switch (tile_bn(cols)) {
+        case 160: return "igemm_multi_kernel<128, 160, 4, 1, 4, 2>";
+        case 128: return "igemm_multi_kernel<128, 128, 2, 2, 4, 2>";
+        case 96: return "igemm_multi_kernel<128, 96, 4, 1, 4, 2>";
+        case 64: return "igemm_multi_kernel<128, 64, 2, 2, 4, 2>";
+        default: return "igemm_multi_kernel<128, 32, 4, 1, 4, 2>";
+      }
+    }
+  }
   // (a convolution that runs as two column segments is named after the first, wider one)
   int bn = tile_bn(plan_segments(cols).width[0]);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;

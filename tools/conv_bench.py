@@ -17,6 +17,7 @@ ap.add_argument("--stems", action="store_true", help="the four backbone stems (C
 ap.add_argument("--r3d", action="store_true", help="R3D-18 residual-stage conv shapes")
 ap.add_argument("--r21d", action="store_true", help="R(2+1)D factored conv shapes (mid channels zero-padded to a multiple of 4)")
 ap.add_argument("--s3dg", action="store_true", help="S3D-G conv shapes (B=16 by default for this list)")
+ap.add_argument("--layers", default="", help="comma-separated layer names to keep")
 ap.add_argument("--no-stem-kernel", action="store_true", help="ablation build only: route stems through the implicit-GEMM kernel")
 args = ap.parse_args()
 if args.tune is not None:
@@ -80,6 +81,8 @@ if args.s3dg:
 if args.r3d:
     LAYERS = R3D
 tot = {}
+if args.layers:
+    LAYERS = [L for L in LAYERS if L[0] in args.layers.split(",")]
 for L in LAYERS:
     name, T, HW, cin, cout = L[:5]
     k, s, p = L[5:] if len(L) > 5 else ((3, 3, 3), (1, 1, 1), (1, 1, 1))
