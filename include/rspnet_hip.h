@@ -107,6 +107,11 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
  * backbone and match it to the rocprofv3 kernel-trace row.  Static string, never NULL. */
 const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which);
 
+/* Host evaluation of the constant division the conv kernels use to decode GEMM rows and k positions (multiply-high by a
+ * host-computed magic number + shift, exact for 0 <= n < 2^31): returns n / d computed that way.  No GPU needed; exists so
+ * the CPU test suite can check the derivation over the full range. */
+int rsp_fastdiv_check(int d, int n);
+
 /* ---------------------------------------------------------------------------------------------------------
  * BatchNorm3d (train mode) fused with ReLU / residual add / MaxPool3d:
  * models/c3d.py:22-24 (bn+relu+pool), models/resnet.py:61-77, models/s3dg.py:23,28-33, r2plus1d_vcop.py:59-60,116-123.

@@ -154,7 +154,33 @@ struct PoolParams {
   float* __restrict__ out;
   int relu;
   int cg;  // channel groups = C / VEC
+  // thread layout: a block covers cgc (<= 256) channel groups x ppi output positions; blockIdx.y walks the channel chunks
+  int cgc, ppi;
+  long long npos;            // output positions (< 2^31)
+  FastDiv dcgc, dWo, dHo, dDo;
 };
+
+// Every thread keeps ONE channel group for its whole life (per-channel constants are loaded once) and walks output positions;
+// a position index is decoded by multiply-high constant division (the earlier kernels did five 64-bit divisions per element).
+struct Layout {
+  int cgc, ppi;
+  FastDiv dcgc, dWo, dHo, dDo;
+  long long npos;
+  dim3 grid;
+};
+
+static Layout make_layout(const rsp_pool3d_desc* d, int cg, int per_thread) {
+  Layout L;
+  L.cgc = cg < 256 ? cg : 256;
+  L.ppi = 256 / L.cgc;
+  L.dcgc = fastdiv_make(L.cgc);
+  L.dWo = fastdiv_make(d->Wo); L.dHo = fastdiv_make(d->Ho); L.dDo = fastdiv_make(d->Do);
+  L.npos = (long long)d->N * d->Do * d->Ho * d->Wo;
+  long long b = (L.npos + (long long)L.ppi * per_thread - 1) / ((long long)L.ppi * per_thread);
+  b = b > 16384 ? 16384 : (b < 1 ? 1 : b);
+  L.grid = dim3((unsigned)b, (unsigned)rsp_cdiv(cg, 256));
+  return L;
+}
 
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
@@ -178,46 +204,60 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p) {
   const rsp_pool3d_desc& d = p.d;
-  const long long total = (long long)d.N * d.Do * d.Ho * d.Wo * p.cg;
-  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
-    const int cgi = (int)(idx % p.cg);
-    long long q = idx / p.cg;
-    const int ow = (int)(q % d.Wo); q /= d.Wo;
-    const int oh = (int)(q % d.Ho); q /= d.Ho;
-    const int od = (int)(q % d.Do);
-    const int n = (int)(q / d.Do);
-    const int c = cgi * VEC;
-    float sc[VEC], sh[VEC], best[VEC];
-    load_vec<VEC>(p.ss + c, sc);
-    load_vec<VEC>(p.ss + d.C + c, sh);
+  const int t = threadIdx.x;
+  const int pl = fastdiv(t, p.dcgc);
+  const int cgi = blockIdx.y * 256 + (t - pl * p.cgc);
+  if (pl >= p.ppi || cgi >= p.cg) return;
+  const int c = cgi * VEC;
+  float sc[VEC], sh[VEC];
+  load_vec<VEC>(p.ss + c, sc);
+  load_vec<VEC>(p.ss + d.C + c, sh);
+  const bool unit = d.kT * d.kH * d.kW == 1 && d.sT == 1 && d.sH == 1 && d.sW == 1 && !(d.pT | d.pH | d.pW);   // no pooling
+  for (long long o = (long long)blockIdx.x * p.ppi + pl; o < p.npos; o += (long long)gridDim.x * p.ppi) {
+    float best[VEC];
+    if (unit) {
+      float v[VEC], r[VEC];
+      load_vec<VEC>(p.y + o * d.in_ld + c, v);
+      if (p.res) load_vec<VEC>(p.res + o * d.res_ld + c, r);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) best[e] = -INFINITY;
-    for (int kt = 0; kt < d.kT; ++kt) {
-      const int id = od * d.sT - d.pT + kt;
-      if ((unsigned)id >= (unsigned)d.Di) continue;
-      for (int kh = 0; kh < d.kH; ++kh) {
-        const int ih = oh * d.sH - d.pH + kh;
-        if ((unsigned)ih >= (unsigned)d.Hi) continue;
-        for (int kw = 0; kw < d.kW; ++kw) {
-          const int iw = ow * d.sW - d.pW + kw;
-          if ((unsigned)iw >= (unsigned)d.Wi) continue;
-          const long long pos = (((long long)n * d.Di + id) * d.Hi + ih) * d.Wi + iw;
-          float v[VEC];
-          load_vec<VEC>(p.y + pos * d.in_ld + c, v);
-          float r[VEC];
-          if (p.res) load_vec<VEC>(p.res + pos * d.res_ld + c, r);
+      for (int e = 0; e < VEC; ++e) {
+        float z = fmaf(v[e], sc[e], sh[e]);
+        if (p.res) z += r[e];
+        best[e] = p.relu ? fmaxf(z, 0.f) : z;
+      }
+    } else {
+      const int op = (int)o;
+      const int q1 = fastdiv(op, p.dWo), ow = op - q1 * d.Wo;
+      const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
+      const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            float z = fmaf(v[e], sc[e], sh[e]);
-            if (p.res) z += r[e];
-            if (p.relu) z = fmaxf(z, 0.f);
-            best[e] = fmaxf(best[e], z);
+      for (int e = 0; e < VEC; ++e) best[e] = -INFINITY;
+      for (int kt = 0; kt < d.kT; ++kt) {
+        const int id = od * d.sT - d.pT + kt;
+        if ((unsigned)id >= (unsigned)d.Di) continue;
+        for (int kh = 0; kh < d.kH; ++kh) {
+          const int ih = oh * d.sH - d.pH + kh;
+          if ((unsigned)ih >= (unsigned)d.Hi) continue;
+          for (int kw = 0; kw < d.kW; ++kw) {
+            const int iw = ow * d.sW - d.pW + kw;
+            if ((unsigned)iw >= (unsigned)d.Wi) continue;
+            const long long pos = (((long long)n * d.Di + id) * d.Hi + ih) * d.Wi + iw;
+            float v[VEC];
+            load_vec<VEC>(p.y + pos * d.in_ld + c, v);
+            float r[VEC];
+            if (p.res) load_vec<VEC>(p.res + pos * d.res_ld + c, r);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              float z = fmaf(v[e], sc[e], sh[e]);
+              if (p.res) z += r[e];
+              if (p.relu) z = fmaxf(z, 0.f);
+              best[e] = fmaxf(best[e], z);
+            }
           }
         }
       }
     }
-    const long long opos = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
-    store_vec<VEC>(p.out + opos * d.out_ld + c, best);
+    store_vec<VEC>(p.out + o * d.out_ld + c, best);
   }
 }
 
@@ -240,6 +280,9 @@ struct BwdParams {
   int cg;
   int nblocks;
   long long count;  // positions per channel of y
+  int cgc, ppi;     // thread layout of the apply kernels (see Layout)
+  long long npos;
+  FastDiv dcgc, dWo, dHo, dDo;
 };
 
 // z of one input position (post affine + residual), VEC channels
@@ -263,10 +306,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
   __shared__ float red[256][2 * VEC];
   const int cg0 = blockIdx.y * 256;
   const int cgc = min(p.cg - cg0, 256);
-  const int ppi = 256 / cgc;
+  const int ppi = p.ppi;
   const int t = threadIdx.x;
-  const int cgi = cg0 + t % cgc, pl = t / cgc;
-  const bool active = pl < ppi;
+  const int pl = fastdiv(t, p.dcgc);
+  const int cgi = cg0 + (t - pl * p.cgc);
+  const bool active = pl < ppi && (t - pl * p.cgc) < cgc;
   const int c = cgi * VEC;
   float s1[VEC], s2[VEC];
 #pragma unroll
@@ -279,11 +323,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
     load_vec<VEC>(p.mi + d.C + c, invstd);
     const long long npos = (long long)d.N * d.Do * d.Ho * d.Wo;
     for (long long op = (long long)blockIdx.x * ppi + pl; op < npos; op += (long long)gridDim.x * ppi) {
-      long long q = op;
-      const int ow = (int)(q % d.Wo); q /= d.Wo;
-      const int oh = (int)(q % d.Ho); q /= d.Ho;
-      const int od = (int)(q % d.Do);
-      const int n = (int)(q / d.Do);
+      const int q1 = fastdiv((int)op, p.dWo), ow = (int)op - q1 * d.Wo;
+      const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
+      const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
       float best[VEC], by[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; by[e] = 0.f; }
@@ -440,65 +482,86 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p) {
   const rsp_pool3d_desc& d = p.d;
-  const long long total = (long long)d.N * d.Do * d.Ho * d.Wo * p.cg;
-  const double invn = 1.0 / (double)p.count;
+  const int t = threadIdx.x;
+  const int pl = fastdiv(t, p.dcgc);
+  const int cgi = blockIdx.y * 256 + (t - pl * p.cgc);
+  if (pl >= p.ppi || cgi >= p.cg) return;
+  const int c = cgi * VEC;
   const int nwin = d.kT * d.kH * d.kW;
-  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += 256ll * gridDim.x) {
-    const int cgi = (int)(idx % p.cg);
-    long long q = idx / p.cg;
-    const long long op = q;
-    const int ow = (int)(q % d.Wo); q /= d.Wo;
-    const int oh = (int)(q % d.Ho); q /= d.Ho;
-    const int od = (int)(q % d.Do);
-    const int n = (int)(q / d.Do);
-    const int c = cgi * VEC;
-    float sc[VEC], sh[VEC], mean[VEC], invstd[VEC], gam[VEC], g[VEC], m1[VEC], m2[VEC];
-    load_vec<VEC>(p.ss + c, sc);
-    load_vec<VEC>(p.ss + d.C + c, sh);
-    load_vec<VEC>(p.mi + c, mean);
-    load_vec<VEC>(p.mi + d.C + c, invstd);
-    if (p.gamma) load_vec<VEC>(p.gamma + c, gam);
-    else {
+  // per-channel constants, once per thread: dy = k1 * dz + k2 * y + k3 with
+  //   k1 = gamma*invstd, k2 = -k1*invstd*m2, k3 = -k1*(m1 - mean*invstd*m2)       (m1 = mean dz, m2 = mean dz*xhat)
+  float sc[VEC], sh[VEC], mean[VEC], invstd[VEC], gam[VEC], m1[VEC], m2[VEC];
+  load_vec<VEC>(p.ss + c, sc);
+  load_vec<VEC>(p.ss + d.C + c, sh);
+  load_vec<VEC>(p.mi + c, mean);
+  load_vec<VEC>(p.mi + d.C + c, invstd);
+  if (p.gamma) load_vec<VEC>(p.gamma + c, gam);
+  else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) gam[e] = 1.f;
-    }
-    load_vec<VEC>(p.dout + op * d.out_ld + c, g);
+    for (int e = 0; e < VEC; ++e) gam[e] = 1.f;
+  }
+  const double invn = 1.0 / (double)p.count;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      m1[e] = (float)(p.sums[2 * (c + e)] * invn);
-      m2[e] = (float)(p.sums[2 * (c + e) + 1] * invn);
+  for (int e = 0; e < VEC; ++e) {
+    m1[e] = (float)(p.sums[2 * (c + e)] * invn);
+    m2[e] = (float)(p.sums[2 * (c + e) + 1] * invn);
+  }
+  for (long long o = (long long)blockIdx.x * p.ppi + pl; o < p.npos; o += (long long)gridDim.x * p.ppi) {
+    float g[VEC];
+    load_vec<VEC>(p.dout + o * d.out_ld + c, g);
+    if (nwin == 1) {
+      // no pooling: the position is its own window
+      float yv[VEC], z[VEC], ov[VEC], dz[VEC];
+      zval<VEC>(p, o, c, sc, sh, yv, z);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        dz[e] = (p.relu && !(z[e] > 0.f)) ? 0.f : g[e];
+        const float xhat = (yv[e] - mean[e]) * invstd[e];
+        ov[e] = gam[e] * invstd[e] * (dz[e] - m1[e] - xhat * m2[e]);
+      }
+      store_vec<VEC>(p.dy + o * d.in_ld + c, ov);
+      if (p.dres) store_vec<VEC>(p.dres + o * d.res_ld + c, dz);
+      continue;
     }
+    const int op = (int)o;
+    const int q1 = fastdiv(op, p.dWo), ow = op - q1 * d.Wo;
+    const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
+    const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
+    const long long base = (((long long)n * d.Di + od * d.sT) * d.Hi + oh * d.sH) * d.Wi + ow * d.sW;
     float yv[8][VEC], zv[8][VEC], best[VEC];
     int bi[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    // window offsets in scan order (kt, kh, kw), advanced incrementally
+    int kw = 0, kh = 0, kt = 0;
 #pragma unroll
     for (int wdx = 0; wdx < 8; ++wdx) {
       if (wdx < nwin) {
-        const int kw = wdx % d.kW, kh = (wdx / d.kW) % d.kH, kt = wdx / (d.kW * d.kH);
-        const long long pos = (((long long)n * d.Di + od * d.sT + kt) * d.Hi + oh * d.sH + kh) * d.Wi + ow * d.sW + kw;
+        const long long pos = base + ((long long)kt * d.Hi + kh) * d.Wi + kw;
         zval<VEC>(p, pos, c, sc, sh, yv[wdx], zv[wdx]);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float v = p.relu ? fmaxf(zv[wdx][e], 0.f) : zv[wdx][e];
           if (v > best[e]) { best[e] = v; bi[e] = wdx; }     // first maximum in scan order
         }
+        if (++kw == d.kW) { kw = 0; if (++kh == d.kH) { kh = 0; ++kt; } }
       }
     }
+    kw = 0; kh = 0; kt = 0;
 #pragma unroll
     for (int wdx = 0; wdx < 8; ++wdx) {
       if (wdx < nwin) {
-        const int kw = wdx % d.kW, kh = (wdx / d.kW) % d.kH, kt = wdx / (d.kW * d.kH);
-        const long long pos = (((long long)n * d.Di + od * d.sT + kt) * d.Hi + oh * d.sH + kh) * d.Wi + ow * d.sW + kw;
-        float o[VEC], dz[VEC];
+        const long long pos = base + ((long long)kt * d.Hi + kh) * d.Wi + kw;
+        float ov[VEC], dz[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           dz[e] = (bi[e] == wdx && !(p.relu && !(best[e] > 0.f))) ? g[e] : 0.f;
           const float xhat = (yv[wdx][e] - mean[e]) * invstd[e];
-          o[e] = gam[e] * invstd[e] * (dz[e] - m1[e] - xhat * m2[e]);
+          ov[e] = gam[e] * invstd[e] * (dz[e] - m1[e] - xhat * m2[e]);
         }
-        store_vec<VEC>(p.dy + pos * d.in_ld + c, o);
+        store_vec<VEC>(p.dy + pos * d.in_ld + c, ov);
         if (p.dres) store_vec<VEC>(p.dres + pos * d.res_ld + c, dz);
+        if (++kw == d.kW) { kw = 0; if (++kh == d.kH) { kh = 0; ++kt; } }
       }
     }
   }
@@ -584,9 +647,11 @@ int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* s
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(out) &&
                    rsp_aligned16(scale_shift) && (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual)));
   p.cg = vec ? d->C / 4 : d->C;
-  const long long total = (long long)d->N * d->Do * d->Ho * d->Wo * p.cg;
-  if (vec) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  const Layout L = make_layout(d, p.cg, 4);
+  RSP_REQUIRE(L.npos < (1ll << 31), "rsp_bn_act_pool_fwd: more than 2^31 - 1 output positions");
+  p.cgc = L.cgc; p.ppi = L.ppi; p.npos = L.npos; p.dcgc = L.dcgc; p.dWo = L.dWo; p.dHo = L.dHo; p.dDo = L.dDo;
+  if (vec) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<4>, L.grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<1>, L.grid, dim3(256), 0, (hipStream_t)stream, p);
   return rsp_check_launch("bn_act_pool_fwd_kernel");
 }
 
@@ -620,6 +685,9 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
   double* sums = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(workspace) +
                                            rsp_align_up((size_t)2048 * d->C * 2 * sizeof(float), 256));
   p.sums = sums;
+  const Layout L = make_layout(d, p.cg, 4);
+  RSP_REQUIRE(L.npos < (1ll << 31), "rsp_bn_act_pool_bwd: more than 2^31 - 1 output positions");
+  p.cgc = L.cgc; p.ppi = L.ppi; p.npos = L.npos; p.dcgc = L.dcgc; p.dWo = L.dWo; p.dHo = L.dHo; p.dDo = L.dDo;
   p.nblocks = reduce_blocks(d, p.cg);
   dim3 rgrid(p.nblocks, rsp_cdiv(p.cg, 256));
   if (vec) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, rgrid, dim3(256), 0, s, p);
@@ -632,9 +700,8 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
   if (rc != RSP_OK) return rc;
   const bool exact = d->Di % d->sT == 0 && d->Hi % d->sH == 0 && d->Wi % d->sW == 0 && d->kT * d->kH * d->kW <= 8;
   if (exact) {
-    const long long total = (long long)d->N * d->Do * d->Ho * d->Wo * p.cg;
-    if (vec) hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, L.grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, L.grid, dim3(256), 0, s, p);
     return rsp_check_launch("bn_bwd_apply_win_kernel");
   }
   const long long total = (long long)d->N * d->Di * d->Hi * d->Wi * p.cg;

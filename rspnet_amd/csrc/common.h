@@ -63,3 +63,27 @@ __device__ __forceinline__ float rsp_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+
+// Division by a launch constant as multiply-high + shift (the prologue of every tile decodes 4 GEMM rows per thread into
+// (n, d, h, w) and its k position into (tap, channel): with hardware-free integer division that was ~1000 instructions
+// per wave).  Exact for 0 <= n < 2^31: mul = ceil(2^(31+s) / d), s = ceil(log2 d); q = umulhi(n, mul) >> (s - 1).
+struct FastDiv {
+  unsigned mul;   // 0: divisor 1
+  unsigned shr;
+  int d;
+};
+
+static inline FastDiv fastdiv_make(int d) {
+  FastDiv f = {0u, 0u, d};
+  if (d <= 1) return f;
+  int s = 0;
+  while ((1ll << s) < d) ++s;
+  const unsigned long long pw = 1ull << (31 + s);
+  f.mul = (unsigned)((pw + (unsigned long long)d - 1) / (unsigned long long)d);
+  f.shr = (unsigned)(s - 1);
+  return f;
+}
+
+__device__ __forceinline__ int fastdiv(int n, const FastDiv f) {
+  return f.mul ? (int)(__umulhi((unsigned)n, f.mul) >> f.shr) : n;
+}

@@ -27,28 +27,18 @@ constexpr int MAX_TAPS = 343;  // 7x7x7
 // 64 B of zeros: out-of-bounds taps / rows / K-tail lanes load from here instead of branching around the load
 __device__ __attribute__((aligned(64))) float g_zero[16];
 
-// Division by a launch constant as multiply-high + shift (the prologue of every tile decodes 4 GEMM rows per thread into
-// (n, d, h, w) and its k position into (tap, channel): with hardware-free integer division that was ~1000 instructions
-// per wave).  Exact for 0 <= n < 2^31: mul = ceil(2^(31+s) / d), s = ceil(log2 d); q = umulhi(n, mul) >> (s - 1).
-struct FastDiv {
-  unsigned mul;   // 0: divisor 1
-  unsigned shr;
-  int d;
-};
-
-inline FastDiv fastdiv_make(int d) {
-  FastDiv f = {0u, 0u, d};
-  if (d <= 1) return f;
-  int s = 0;
-  while ((1ll << s) < d) ++s;
-  const unsigned long long pw = 1ull << (31 + s);
-  f.mul = (unsigned)((pw + (unsigned long long)d - 1) / (unsigned long long)d);
-  f.shr = (unsigned)(s - 1);
-  return f;
-}
-
-__device__ __forceinline__ int fastdiv(int n, const FastDiv f) {
-  return f.mul ? (int)(__umulhi((unsigned)n, f.mul) >> f.shr) : n;
+// Address of g_zero on the CURRENT device (a __device__ symbol has one instance per device; one process per GPU is the
+// supported model, but a process that drives several devices must not reuse another device's address).
+const float* igemm_zero_page() {
+  static const float* cache[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cache[dev]) {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero)) != hipSuccess || !z) return nullptr;
+    cache[dev] = reinterpret_cast<const float*>(z);
+  }
+  return cache[dev];
 }
 
 struct IgemmParams {
@@ -886,14 +876,10 @@ size_t split_partial_bytes(const SplitPlan& sp, long long M, int n_tiles, int Co
 }
 
 int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
-  static const float* zero_page = nullptr;
+  const float* zero_page = igemm_zero_page();
   if (!zero_page) {
-    void* z = nullptr;
-    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero)) != hipSuccess || !z) {
-      rsp_set_error("hipGetSymbolAddress(g_zero) failed");
-      return RSP_ELAUNCH;
-    }
-    zero_page = reinterpret_cast<const float*>(z);
+    rsp_set_error("hipGetSymbolAddress(g_zero) failed");
+    return RSP_ELAUNCH;
   }
   p.zero = zero_page;
 #ifdef RSP_TUNE
@@ -1115,6 +1101,13 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   return run_igemm(p, vec4, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// Host evaluation of the kernels' constant division (same magic numbers, same multiply-high + shift): lets the CPU test suite
+// check the derivation over the whole 31-bit range without a GPU.  Returns n / d as the device code would compute it.
+int rsp_fastdiv_check(int d, int n) {
+  const FastDiv f = fastdiv_make(d);
+  return f.mul ? (int)((unsigned)(((unsigned long long)(unsigned)n * f.mul) >> 32) >> f.shr) : n;
+}
+
 // Name of the kernel template the library dispatches for this descriptor (16-byte aligned tensors assumed), so that a
 // profiler summary row can be matched to a launch without parsing mangled names.  which: 0 forward, 1 dgrad, 2 wgrad.
 const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
@@ -1257,14 +1250,10 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
   // (below ~one round of resident workgroups the classes need the K split of the single-problem path to fill the machine —
   //  R3D-18 layer4.0: 64 tiles of 128 chunks; above a few thousand tiles each class fills it on its own)
   if (multi && tiles_all >= 512 && tiles_all <= 4096) {
-    static const float* zero_page = nullptr;
+    const float* zero_page = igemm_zero_page();
     if (!zero_page) {
-      void* z = nullptr;
-      if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero)) != hipSuccess || !z) {
-        rsp_set_error("hipGetSymbolAddress(g_zero) failed");
-        return RSP_ELAUNCH;
-      }
-      zero_page = reinterpret_cast<const float*>(z);
+      rsp_set_error("hipGetSymbolAddress(g_zero) failed");
+      return RSP_ELAUNCH;
     }
     IgemmMulti m;
     memset(&m, 0, sizeof m);

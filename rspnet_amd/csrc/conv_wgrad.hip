@@ -699,15 +699,18 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
     return RSP_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  static const float* zero_page = nullptr;
-  if (!zero_page) {
+  static const float* zero_cache[64] = {nullptr};   // per device: a __device__ symbol has one instance per device
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) dev_id = 0;
+  if (!zero_cache[dev_id]) {
     void* z = nullptr;
     if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_wzero)) != hipSuccess || !z) {
       rsp_set_error("hipGetSymbolAddress(g_wzero) failed");
       return RSP_ELAUNCH;
     }
-    zero_page = reinterpret_cast<const float*>(z);
+    zero_cache[dev_id] = reinterpret_cast<const float*>(z);
   }
+  const float* zero_page = zero_cache[dev_id];
   WgradParams p;
   memset(&p, 0, sizeof p);
   p.zero = zero_page;

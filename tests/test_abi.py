@@ -57,3 +57,23 @@ def test_missing_library_is_a_hard_error(monkeypatch):
         _lib.load()
     with pytest.raises(_lib.RspError):
         ops.HipOps()
+
+
+def test_constant_division_matches_integer_division():
+    """The conv kernels decode rows / k positions with multiply-high by a host-computed magic number (conv_igemm.hip FastDiv);
+    the same arithmetic evaluated on the host must equal n // d for every divisor a descriptor can produce, up to 2^31 - 1."""
+    import numpy as np
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    divisors = sorted(set(list(range(1, 130)) + [143, 144, 160, 192, 208, 224, 230, 232, 288, 343, 384, 460, 480, 512, 528, 832, 921,
+                                                  1024, 2048, 4095, 4096, 4097, 65535, 65536, 1 << 20, (1 << 20) + 1, (1 << 30) - 1,
+                                                  1 << 30, (1 << 31) - 1] + [int(x) for x in rng.integers(1, 1 << 31, 40)]))
+    top = (1 << 31) - 1
+    for d in divisors:
+        ns = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, top, top - 1, top - d, (top // d) * d, (top // d) * d - 1}
+        ns |= {int(x) for x in rng.integers(0, 1 << 31, 64)}
+        ns |= {k * d - 1 for k in rng.integers(1, max(2, top // d), 16)} | {k * d for k in rng.integers(1, max(2, top // d), 16)}
+        for n in ns:
+            n = int(n)
+            if 0 <= n <= top:
+                assert lib.rsp_fastdiv_check(d, n) == n // d, (d, n)
