@@ -69,6 +69,7 @@ struct IgemmParams {
   unsigned x_bytes, w_bytes;       // extents for the buffer descriptors of the DMA path (< 4 GiB)
   FastDiv dGw, dGh, dGd, dCin, dTw, dTh;   // filled by fill_fastdiv() from Gw, Gh, Gd, Cin, nTw, nTh
   int adv_tap, adv_ci;                     // BK / Cin, BK % Cin
+  int nbuf;                                // LDS tile buffers: 2, or 1 (see igemm_body)
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
@@ -92,9 +93,14 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   constexpr bool DMA = VEC == 4;
   constexpr int LDR = DMA ? BK : LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* As = reinterpret_cast<float*>(smem_raw);             // [2][BM][LDR]
-  float* Bs = As + 2 * BM * LDR;                              // [2][BN][LDR]
-  int4* taptab = reinterpret_cast<int4*>(Bs + 2 * BN * LDR);  // [ntaps] {offd, offh, offw, delta}
+  // nbuf == 1 (chosen per launch, `single_buffer()`): ONE tile buffer, re-filled after a barrier that follows the fragment
+  // reads.  The fragments of a whole chunk live in registers anyway, so the second buffer only saved that barrier; giving it
+  // up halves the LDS footprint and lets a third workgroup share the CU (VGPRs allow 3), which fills the matrix pipe better
+  // (C3D conv2 +3 %) and makes the round 768 tiles wide (conv4: 784 tiles, was 1.53 rounds of 512: +5-8 %).
+  const int nbuf = DMA ? p.nbuf : 2;
+  float* As = reinterpret_cast<float*>(smem_raw);             // [nbuf][BM][LDR]
+  float* Bs = As + nbuf * BM * LDR;                           // [nbuf][BN][LDR]
+  int4* taptab = reinterpret_cast<int4*>(Bs + nbuf * BN * LDR);  // [ntaps] {offd, offh, offw, delta}
   long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nTd * p.nTh * p.nTw + 1);  // [BM]
 
   const int t = threadIdx.x;
@@ -335,10 +341,11 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       for (int j = 0; j < TN; ++j) bf[kk][j] = *reinterpret_cast<const floatx4*>(b + j * 32 * LDR + slot);
     }
     // 2. next chunk: LDS-DMA (or global loads into registers) in flight under this chunk's MFMAs
+    if (nbuf == 1) __syncthreads();   // every wave holds its fragments: the buffer may be overwritten
 #ifdef RSP_TUNE
-    if (more && !(p.tune & 1)) load_chunk(kc + 1, buf ^ 1);
+    if (more && !(p.tune & 1)) load_chunk(kc + 1, nbuf == 1 ? 0 : buf ^ 1);
 #else
-    if (more) load_chunk(kc + 1, buf ^ 1);
+    if (more) load_chunk(kc + 1, nbuf == 1 ? 0 : buf ^ 1);
 #endif
     // 3. 16 k-steps x TM x TN MFMAs
 #ifdef RSP_TUNE
@@ -366,7 +373,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #endif
-    buf ^= 1;
+    buf = nbuf == 1 ? 0 : buf ^ 1;
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------
@@ -722,7 +729,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
 int launch_cfg(const IgemmParams& p, hipStream_t s) {
   // LDS: two tile buffers + tap table (sized by the actual tap count: short-K layers are latency-bound and want a
   // third workgroup per CU) + output-row address table
-  const size_t lds = (size_t)2 * (BM + BN) * (VEC == 4 ? BK : LDK) * sizeof(float) +
+  const size_t nb = VEC == 4 ? (size_t)p.nbuf : 2;
+  const size_t lds = nb * (BM + BN) * (VEC == 4 ? BK : LDK) * sizeof(float) +
                      (size_t)(p.nTd * p.nTh * p.nTw + 1) * sizeof(int4) + BM * sizeof(long long);
   static bool attr_set = false;
   if (!attr_set) {
@@ -803,10 +811,22 @@ struct SplitPlan {
   int cps;          // chunks per slice
 };
 
+// One LDS buffer instead of two (igemm_body): only where it buys a third workgroup per CU — the 128- and 96-wide DMA tiles
+// (166 / 148 VGPRs; the 160-wide tile's 215 VGPRs allow two, the 64- and 32-wide tiles already run 3+) — and only for launches
+// of at least one full 768-tile round: below that the dispatcher packs three workgroups onto some CUs while others idle
+// (392 tiles: +28 % time), and the 64-wide tile loses 9 % to the extra barrier without gaining a workgroup.
+bool single_buffer(int m_tiles, int n_tiles, int bn, bool vec4) {
+#ifdef RSP_TUNE
+  if (getenv("RSP_NO_SINGLE")) return false;
+#endif
+  return vec4 && (bn == 128 || bn == 96) && (long long)m_tiles * n_tiles >= 768;
+}
+
 SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, int Cout) {
   const int tiles = m_tiles * n_tiles;
   // resident workgroups per CU of igemm_kernel<128, bn, .., VEC>: LDS-limited (DMA variants) or VGPR-limited (scalar gather)
-  const int wpc = vec4 ? (bn >= 96 ? 2 : 3) : (bn >= 64 ? 2 : 3);
+  int wpc = vec4 ? (bn >= 96 ? 2 : 3) : (bn >= 64 ? 2 : 3);
+  if (single_buffer(m_tiles, n_tiles, bn, vec4)) wpc = 3;
   const int slots = 256 * wpc;
   SplitPlan best = {tiles, 1, nchunks};
   if (nchunks < 8) return best;
@@ -894,6 +914,7 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
   SplitPlan sp = plan_split(m_tiles, n_tiles, bn, vec4, p.nchunks, p.Cout);
+  p.nbuf = single_buffer(m_tiles, n_tiles, bn, vec4) ? 1 : 2;
 #ifdef RSP_TUNE
   if (p.tune & 4096) sp = {m_tiles * n_tiles, 1, p.nchunks};   // ablation: no tail split
   if (const char* e = getenv("RSP_SPLIT")) {                    // sweep: force S on the tail (RSP_FULL=0: split every tile)
@@ -1268,6 +1289,7 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
       p.n_tiles = rsp_cdiv(p.Cout, bn);
       p.full_tiles = p.m_tiles * p.n_tiles;
       p.splitk = 1;
+      p.nbuf = 2;
       p.chunks_per_split = p.nchunks;
       p.tail_row0 = p.m_tiles * 128;
       m.p[i] = p;
