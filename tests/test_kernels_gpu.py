@@ -60,6 +60,10 @@ CONV_CASES = [
     (2, 4, 9, 9, 64, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # 96-wide tile (4 waves along M); dgrad N = 64
     (2, 4, 9, 9, 96, 160, (3, 1, 1), (1, 1, 1), (1, 0, 0)),        # 160-wide tile forward, 96-wide tile in dgrad
     (1, 2, 7, 7, 160, 150, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # 150 columns in one 160-wide tile, K-split tail; dgrad N = 160
+    # >= 768 tiles: the single-LDS-buffer mode of the 128- / 96-wide tiles (three workgroups per CU), with a K-split tail
+    (1, 6, 130, 128, 16, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # 780 tiles of 128x128, K = 432
+    (1, 6, 130, 128, 16, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 780 tiles of 128x96
+    (1, 6, 130, 128, 128, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # dgrad: 780 tiles of 128x128 over K = 32 (one chunk)
     # 4-channel (zero-padded RGB) stems: direct LDS-halo kernel (conv_stem.hip)
     (2, 4, 12, 12, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # C3D conv1: all 3 time-slices resident, 14-tap chunks
     (2, 5, 18, 20, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),        # R3D stem: ring of 3 time-slices, stride 2 de-interleave
