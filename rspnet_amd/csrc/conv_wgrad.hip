@@ -581,8 +581,9 @@ WPlan wplan(const rsp_conv3d_desc* d) {
   const long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
   const int K = d->kT * d->kH * d->kW * d->Cin;
   w.Kld = (int)rsp_align_up((size_t)K, 4);
-  w.bm = d->Cout > 64 ? 128 : 64;
+  w.bm = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
   w.bn = K > 64 ? 128 : 64;
+  if (w.bm == 32 && w.bn == 64) w.bm = 64;   // (the 32-row tile stacks its four waves along k: 4 x 32 columns)
   w.co_tiles = rsp_cdiv(d->Cout, w.bm);
   w.k_tiles = rsp_cdiv(K, w.bn);
   const int tiles = w.co_tiles * w.k_tiles;
@@ -623,29 +624,45 @@ WPlan wplan(const rsp_conv3d_desc* d) {
 
 }  // namespace
 
-const char* rsp_wgrad_kernel_name(const rsp_conv3d_desc* d) {
-  if (!wdesc_ok(d)) return "invalid";
+struct WSegs { int n, at[2], width[2]; };
+WSegs wgrad_segments(const rsp_conv3d_desc* d);
+
+const char* rsp_wgrad_kernel_name(const rsp_conv3d_desc* d0) {
+  if (!wdesc_ok(d0)) return "invalid";
+  rsp_conv3d_desc first = *d0;
+  first.Cout = wgrad_segments(d0).width[0];     // a convolution run as several output-channel segments is named after the first
+  const rsp_conv3d_desc* d = &first;
   const WPlan w = wplan(d);
   const bool dma = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && d->Cin % 4 == 0 && d->in_ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 &&
                    d->kW <= 8;
+  if (w.bm == 32) return dma ? "wgrad_dma_kernel<32, 128, 1, 4>" : "wgrad_kernel<32, 128, 1, 4, *>";
   if (dma) return w.bm == 128 ? (w.bn == 128 ? "wgrad_dma_kernel<128, 128, 2, 2>" : "wgrad_dma_kernel<128, 64, 2, 2>")
                               : (w.bn == 128 ? "wgrad_dma_kernel<64, 128, 2, 2>" : "wgrad_dma_kernel<64, 64, 2, 2>");
   return w.bm == 128 ? (w.bn == 128 ? "wgrad_kernel<128, 128, 2, 2, *>" : "wgrad_kernel<128, 64, 2, 2, *>")
                      : (w.bn == 128 ? "wgrad_kernel<64, 128, 2, 2, *>" : "wgrad_kernel<64, 64, 2, 2, *>");
 }
 
-namespace {
-
-// Output-channel segments (same idea as the forward kernel's column segments, conv_igemm.hip): the Cout tiles are 128 wide
-// when Cout > 64, so e.g. Cout = 144 would run a second tile that is 1/8 full.  The part beyond the last multiple of 128 is
-// run as its own problem on the 64-wide tile when it fits one (144 = 128 + 16: 75 % useful instead of 56 %).
-int wgrad_split_at(const rsp_conv3d_desc* d) {
+// Output-channel segments (same idea as the forward kernel's column segments, conv_igemm.hip).  The Cout tiles are 128, 64 or 32
+// wide; a channel count is cut into the multiple of 128 below it plus a remainder r that runs on the narrowest tile that holds
+// it: r <= 32 -> the 32-wide tile, r <= 64 -> the 64-wide one, else one more 128-wide tile (a 64 + 32 cut of 65..96 was measured:
+// no gain on R(2+1)D's 84-channel stem, +41 % time on S3D-G's 96-channel pointwise layers — every segment is a launch triple of
+// its own).  144 = 128 + 16: 90 % of the MFMA work useful instead of 56 % (R(2+1)D conv2 spatial: 3.29 -> 2.85 ms).  The
+// segments of a call share the row-geometry table.
+WSegs wgrad_segments(const rsp_conv3d_desc* d) {
+  WSegs g;
+  memset(&g, 0, sizeof g);
+  const int C = d->Cout;
 #ifdef RSP_TUNE
-  if (getenv("RSP_NO_SEGMENTS")) return 0;
+  if (getenv("RSP_NO_SEGMENTS")) { g.n = 1; g.width[0] = C; return g; }
 #endif
-  const int full = d->Cout / 128 * 128, r = d->Cout - full;
-  return (full > 0 && r > 0 && r <= 64) ? full : 0;
+  int full = C / 128 * 128, r = C - full;
+  if (r > 64) { full = C; r = 0; }     // the remainder rides in one more 128-wide tile
+  if (full > 0) { g.at[g.n] = 0; g.width[g.n++] = full; }
+  if (r > 0) { g.at[g.n] = full; g.width[g.n++] = r; }
+  return g;
 }
+
+namespace {
 
 size_t wgrad_ws_one(const rsp_conv3d_desc* d) {
   const WPlan w = wplan(d);
@@ -653,7 +670,7 @@ size_t wgrad_ws_one(const rsp_conv3d_desc* d) {
 }
 
 int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
-              size_t workspace_bytes, void* stream);
+              size_t workspace_bytes, void* stream, bool rowgeom_ready);
 
 }  // namespace
 
@@ -661,13 +678,15 @@ extern "C" {
 
 size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d) {
   if (!wdesc_ok(d)) return 0;
-  const int at = wgrad_split_at(d);
-  if (!at) return wgrad_ws_one(d);
-  rsp_conv3d_desc a = *d, b = *d;
-  a.Cout = at;
-  b.Cout = d->Cout - at;
-  const size_t wa = wgrad_ws_one(&a), wb = wgrad_ws_one(&b);
-  return wa > wb ? wa : wb;
+  const WSegs g = wgrad_segments(d);
+  size_t best = 0;
+  for (int i = 0; i < g.n; ++i) {
+    rsp_conv3d_desc a = *d;
+    a.Cout = g.width[i];
+    const size_t b = wgrad_ws_one(&a);
+    best = b > best ? b : best;
+  }
+  return best;
 }
 
 int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
@@ -675,16 +694,17 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   RSP_REQUIRE(wdesc_ok(d), "rsp_conv3d_wgrad: bad descriptor");
   RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad: null pointer");
   RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_wgrad: workspace must be 16-byte aligned");
-  const int at = wgrad_split_at(d);
-  if (!at) return wgrad_one(d, x, dy, dw_ref, dbias, workspace, workspace_bytes, stream);
-  // two problems over disjoint output-channel ranges; dy keeps its row pitch (out_ld), dw / dbias are contiguous per channel
-  rsp_conv3d_desc a = *d, b = *d;
-  a.Cout = at;
-  b.Cout = d->Cout - at;
+  // problems over disjoint output-channel ranges; dy keeps its row pitch (out_ld), dw / dbias are contiguous per channel
+  const WSegs g = wgrad_segments(d);
   const long long per_co = (long long)d->Cin * d->kT * d->kH * d->kW;
-  int rc = wgrad_one(&a, x, dy, dw_ref, dbias, workspace, workspace_bytes, stream);
-  if (rc != RSP_OK) return rc;
-  return wgrad_one(&b, x, dy + at, dw_ref + at * per_co, dbias ? dbias + at : nullptr, workspace, workspace_bytes, stream);
+  for (int i = 0; i < g.n; ++i) {
+    rsp_conv3d_desc a = *d;
+    a.Cout = g.width[i];
+    const int at = g.at[i];
+    const int rc = wgrad_one(&a, x, dy + at, dw_ref + at * per_co, dbias ? dbias + at : nullptr, workspace, workspace_bytes, stream, i > 0);
+    if (rc != RSP_OK) return rc;
+  }
+  return RSP_OK;
 }
 
 }  // extern "C"
@@ -692,7 +712,7 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
 namespace {
 
 int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
-              size_t workspace_bytes, void* stream) {
+              size_t workspace_bytes, void* stream, bool rowgeom_ready) {
   const WPlan w = wplan(d);
   if (workspace_bytes < w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes) {
     rsp_set_error("rsp_conv3d_wgrad: workspace too small");
@@ -717,7 +737,7 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
 #ifdef RSP_TUNE
   { const char* e = getenv("RSP_TUNE"); p.tune = e ? atoi(e) : 0; }
 #endif
-  p.x = x; p.dy = dy; p.partial = reinterpret_cast<float*>(workspace);
+  p.x = x; p.dy = dy; p.partial = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + w.rowgeom_bytes);
   p.M = d->N * d->Do * d->Ho * d->Wo;
   p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
   p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.in_ld = d->in_ld; p.Cin = d->Cin;
@@ -742,15 +762,19 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
   int rc;
   if (dma) {
     RowGeomParams g;
-    g.out = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(workspace) + w.partial_bytes + w.colsum_bytes);
+    g.out = reinterpret_cast<uint2*>(workspace);
     g.M = p.M; g.Gd = p.Gd; g.Gh = p.Gh; g.Gw = p.Gw; g.Di = p.Di; g.Hi = p.Hi; g.Wi = p.Wi; g.in_ld = p.in_ld;
     g.sD = p.sD; g.sH = p.sH; g.sW = p.sW; g.kT = p.kT; g.kH = p.kH; g.kW = p.kW; g.pT = p.pT; g.pH = p.pH; g.pW = p.pW;
-    hipLaunchKernelGGL(rowgeom_kernel, dim3(rsp_cdiv(p.M, 256)), dim3(256), 0, s, g);
-    rc = rsp_check_launch("rowgeom_kernel");
-    if (rc != RSP_OK) return rc;
+    if (!rowgeom_ready) {    // the table depends on the rows only: the output-channel segments of one call share it
+      hipLaunchKernelGGL(rowgeom_kernel, dim3(rsp_cdiv(p.M, 256)), dim3(256), 0, s, g);
+      rc = rsp_check_launch("rowgeom_kernel");
+      if (rc != RSP_OK) return rc;
+    }
     p.rowgeom = g.out;
   }
-  if (dma && w.bm == 128 && w.bn == 128) rc = launch_w_dma<128, 128, 2, 2>(p, s);
+  if (dma && w.bm == 32) rc = launch_w_dma<32, 128, 1, 4>(p, s);
+  else if (w.bm == 32) rc = launch_w_vec<32, 128, 1, 4>(p, va, vb, s);
+  else if (dma && w.bm == 128 && w.bn == 128) rc = launch_w_dma<128, 128, 2, 2>(p, s);
   else if (dma && w.bm == 128) rc = launch_w_dma<128, 64, 2, 2>(p, s);
   else if (dma && w.bn == 128) rc = launch_w_dma<64, 128, 2, 2>(p, s);
   else if (dma) rc = launch_w_dma<64, 64, 2, 2>(p, s);
@@ -768,7 +792,7 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
     if (rc != RSP_OK) return rc;
   }
   if (dbias) {
-    float* part = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + w.partial_bytes);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + w.rowgeom_bytes + w.partial_bytes);
     const int nblk = rsp_cdiv(p.M, 1024);
     hipLaunchKernelGGL(colsum_stage1, dim3(nblk, rsp_cdiv(d->Cout, 64)), dim3(256), 0, s, dy, (long long)p.M, d->Cout,
                        d->out_ld, part, 1024);

@@ -64,6 +64,9 @@ CONV_CASES = [
     (1, 6, 130, 128, 16, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # 780 tiles of 128x128, K = 432
     (1, 6, 130, 128, 16, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 780 tiles of 128x96
     (1, 6, 130, 128, 128, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # dgrad: 780 tiles of 128x128 over K = 32 (one chunk)
+    # wgrad output-channel segments on the 32-wide tile
+    (1, 3, 20, 20, 8, 20, (1, 3, 3), (1, 1, 1), (0, 1, 1)),        # 20 channels: one 32-wide tile
+    (1, 3, 20, 20, 16, 272, (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # 272 = 256 + 16; K = 16 (64-wide k tile: the 16 ride on the 64-row tile)
     # 4-channel (zero-padded RGB) stems: direct LDS-halo kernel (conv_stem.hip)
     (2, 4, 12, 12, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # C3D conv1: all 3 time-slices resident, 14-tap chunks
     (2, 5, 18, 20, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),        # R3D stem: ring of 3 time-slices, stride 2 de-interleave
