@@ -249,7 +249,7 @@ class HipOps:
             stat_ld = stats.stride(0) // 2
         mi = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
         ss = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
-        wsb = (64 if tiles >= 4096 else (16 if tiles >= 64 else 1)) * Cc * 16   # == rsp_bn_finalize_workspace(tiles, Cc)
+        wsb = int(self.lib.rsp_bn_finalize_workspace(tiles, Cc))
         ws = self._workspace(stats.device, wsb)
         _lib.check(self.lib.rsp_bn_finalize(_ptr(stats), tiles, Cc, stat_ld, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta), eps,
                                             momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi), _ptr(ss), _ptr(ws),
