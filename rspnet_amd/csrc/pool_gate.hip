@@ -78,9 +78,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const MPParams p) {
 // position decode and the window bounds are computed once per 16 bytes and every access is a 16-byte transaction.
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
+// KT/KH/KW > 0: window dims known at compile time — the tap loops unroll into straight-line code whose loads are all issued
+// before the first compare (an out-of-range tap reads a clamped, valid address and is masked to -inf), instead of one
+// load-compare round trip per tap behind three run-time loops with `continue`s.  KEEP = false (key-encoder passes): value only.
+template <bool KEEP, int KT, int KH, int KW>
 __global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) {
   const rsp_pool3d_desc& d = p.d;
   const int C4 = d.C >> 2;
+  const int kT = KT > 0 ? KT : d.kT, kH = KH > 0 ? KH : d.kH, kW = KW > 0 ? KW : d.kW;
   const long long total = (long long)d.N * d.Do * d.Ho * d.Wo * C4;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
     const int c = (int)(i % C4) * 4;
@@ -92,26 +97,60 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) 
     floatx4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     intx4 bi = {-1, -1, -1, -1};
     const float* xn = p.x + (long long)n * d.Di * d.Hi * d.Wi * d.in_ld + c;
-    for (int kt = 0; kt < d.kT; ++kt) {
-      const int id = od * d.sT - d.pT + kt;
-      if ((unsigned)id >= (unsigned)d.Di) continue;
-      for (int kh = 0; kh < d.kH; ++kh) {
-        const int ih = oh * d.sH - d.pH + kh;
-        if ((unsigned)ih >= (unsigned)d.Hi) continue;
-        for (int kw = 0; kw < d.kW; ++kw) {
-          const int iw = ow * d.sW - d.pW + kw;
-          if ((unsigned)iw >= (unsigned)d.Wi) continue;
-          const int lin = (id * d.Hi + ih) * d.Wi + iw;
-          const floatx4 v = *reinterpret_cast<const floatx4*>(xn + (long long)lin * d.in_ld);
+    if (KT > 0) {
+      floatx4 v[KT * KH * KW > 0 ? KT * KH * KW : 1];
+      int lin[KT * KH * KW > 0 ? KT * KH * KW : 1];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KW; ++kw) {
+            const int id = od * d.sT - d.pT + kt, ih = oh * d.sH - d.pH + kh, iw = ow * d.sW - d.pW + kw;
+            const bool ok = (unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi && (unsigned)iw < (unsigned)d.Wi;
+            const int l = (min(max(id, 0), d.Di - 1) * d.Hi + min(max(ih, 0), d.Hi - 1)) * d.Wi + min(max(iw, 0), d.Wi - 1);
+            const int t = (kt * KH + kh) * KW + kw;
+            lin[t] = ok ? l : -1;
+            v[t] = *reinterpret_cast<const floatx4*>(xn + (long long)l * d.in_ld);
+          }
+#pragma unroll
+      for (int t = 0; t < KT * KH * KW; ++t) {
+        if (KEEP) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (v[e] > best[e] || bi[e] < 0) { best[e] = v[e]; bi[e] = lin; }   // first maximum in scan order
+            if (lin[t] >= 0 && (v[t][e] > best[e] || bi[e] < 0)) { best[e] = v[t][e]; bi[e] = lin[t]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) best[e] = lin[t] >= 0 ? fmaxf(best[e], v[t][e]) : best[e];
+        }
+      }
+    } else {
+      for (int kt = 0; kt < kT; ++kt) {
+        const int id = od * d.sT - d.pT + kt;
+        if ((unsigned)id >= (unsigned)d.Di) continue;
+        for (int kh = 0; kh < kH; ++kh) {
+          const int ih = oh * d.sH - d.pH + kh;
+          if ((unsigned)ih >= (unsigned)d.Hi) continue;
+          for (int kw = 0; kw < kW; ++kw) {
+            const int iw = ow * d.sW - d.pW + kw;
+            if ((unsigned)iw >= (unsigned)d.Wi) continue;
+            const int lin = (id * d.Hi + ih) * d.Wi + iw;
+            const floatx4 v = *reinterpret_cast<const floatx4*>(xn + (long long)lin * d.in_ld);
+            if (KEEP) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (v[e] > best[e] || bi[e] < 0) { best[e] = v[e]; bi[e] = lin; }   // first maximum in scan order
+            } else {     // value only: same result as the tracked scan for finite inputs
+#pragma unroll
+              for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v[e]);
+            }
+          }
         }
       }
     }
     const long long o = (((long long)n * d.Do + od) * d.Ho + oh) * d.Wo + ow;
     *reinterpret_cast<floatx4*>(p.out + o * d.out_ld + c) = best;
-    if (p.idx) *reinterpret_cast<intx4*>(p.idx + o * d.C + c) = bi;
+    if (KEEP) *reinterpret_cast<intx4*>(p.idx + o * d.C + c) = bi;
   }
 }
 
@@ -366,10 +405,21 @@ int rsp_maxpool3d_fwd(const rsp_pool3d_desc* d, const float* x, float* out, int3
   p.d = *d; p.x = x; p.out = out; p.idx = argmax;
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(x) && rsp_aligned16(out) &&
                    (!argmax || rsp_aligned16(argmax)) && (long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4) < (1ll << 31);
-  if (vec)
-    hipLaunchKernelGGL(maxpool_fwd_vec_kernel, dim3(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, p);
-  else
+  if (vec) {
+    const dim3 grid(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4)));
+    hipStream_t st = (hipStream_t)stream;
+    const int kkk = d->kT * 100 + d->kH * 10 + d->kW;
+    if (kkk == 333) {
+      if (argmax) hipLaunchKernelGGL((maxpool_fwd_vec_kernel<true, 3, 3, 3>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((maxpool_fwd_vec_kernel<false, 3, 3, 3>), grid, dim3(256), 0, st, p);
+    } else if (kkk == 133) {
+      if (argmax) hipLaunchKernelGGL((maxpool_fwd_vec_kernel<true, 1, 3, 3>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((maxpool_fwd_vec_kernel<false, 1, 3, 3>), grid, dim3(256), 0, st, p);
+    } else {
+      if (argmax) hipLaunchKernelGGL((maxpool_fwd_vec_kernel<true, 0, 0, 0>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((maxpool_fwd_vec_kernel<false, 0, 0, 0>), grid, dim3(256), 0, st, p);
+    }
+  } else
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * d->C)), dim3(256), 0,
                        (hipStream_t)stream, p);
   return rsp_check_launch("maxpool_fwd_kernel");

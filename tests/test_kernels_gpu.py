@@ -359,6 +359,11 @@ MAXPOOL_CASES = [
     (2, 3, 8, 8, 192, (1, 3, 3), (1, 2, 2), (0, 1, 1)),    # S3D-G maxPool1/2
     (2, 4, 6, 6, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # S3D-G inception branch3 (stride 1)
     (2, 4, 6, 6, 83, (2, 2, 2), (2, 2, 2), (0, 0, 0)),     # disjoint, odd channels
+    # stride 1 along W, 3-wide: the four-outputs-per-thread row kernel (ragged last quad, no W padding, strided H, Wo == 4)
+    (1, 3, 7, 13, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 2, 5, 9, 8, (1, 3, 3), (1, 2, 1), (0, 0, 0)),
+    (1, 2, 4, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 5, 9, 6, 192, (2, 1, 3), (2, 1, 1), (0, 0, 1)),
 ]
 
 
