@@ -41,6 +41,19 @@ const float* igemm_zero_page() {
   return cache[dev];
 }
 
+// K order of the packed weights / of the chunks the kernels walk.  Tap-major (k = tap*C + c) makes a 256-channel row come back
+// every 8 chunks per tap and every input row be fetched 27 times from beyond L2 (the 96 tiles an XCD runs at once stream tens
+// of MB between two visits); channel-slice-major (all taps of a 32-channel slice back to back: k = slice*ntaps*32 + tap*32 + c%32)
+// puts a row's w-neighbour taps in adjacent chunks.  Measured on C3D (PMC FETCH_SIZE x2 per launch): conv3b 4.5 -> 0.95 GB,
+// conv4b 1.8 -> 0.67 GB, conv2 dgrad 9.7 -> 1.5 GB (conv2 fwd + dgrad average), at unchanged time.  Used when the GEMM's
+// channel count is a multiple of 32 (every chunk is then one tap of one slice), there is more than one tap, and K is long
+// (>= 96 chunks): the order switches taps in every chunk instead of every C/32 chunks (~20 VALU per thread), which the short-K
+// layers of R(2+1)D / S3D-G — whose 64..192-channel rows never thrashed — paid with 1-2 % of their step.
+__host__ __device__ inline bool k_slice_major(int C, int ntaps) { return ntaps > 1 && (C & 31) == 0 && C * ntaps >= 96 * 32; }
+__host__ __device__ inline int k_index(bool slice_major, int tap, int c, int C, int ntaps) {
+  return slice_major ? (c >> 5) * (ntaps * 32) + tap * 32 + (c & 31) : tap * C + c;
+}
+
 struct IgemmParams {
   const float* __restrict__ x;
   const float* __restrict__ w;     // packed [Cout][Kld]
@@ -70,6 +83,8 @@ struct IgemmParams {
   FastDiv dGw, dGh, dGd, dCin, dTw, dTh;   // filled by fill_fastdiv() from Gw, Gh, Gd, Cin, nTw, nTh
   int adv_tap, adv_ci;                     // BK / Cin, BK % Cin
   int nbuf;                                // LDS tile buffers: 2, or 1 (see igemm_body)
+  int kmajor;                              // 1: channel-slice-major K order (k_slice_major)
+  FastDiv dNt;                             // taps per slice (kmajor)
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
@@ -77,8 +92,11 @@ inline void fill_fastdiv(IgemmParams& p);
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups of ITS problem (blockIdx.x / gridDim.x for a single
 // problem; offsets into a shared grid when several problems run in one launch, igemm_multi_kernel).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC>
+// KS: the channel-slice-major K walk of the DMA path (k_slice_major) with wave-uniform tap counters — its own instantiation so
+// that neither variant carries the other's state (the 128x128 tile sits 2 VGPRs under the limit for three workgroups per CU).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, bool KS = false>
 __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, const int nblk) {
+  static_assert(!KS || VEC == 4, "slice-major walk: DMA path only");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
@@ -183,10 +201,16 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   int ntap[NE], nci[NE];
   int4 ntt[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
+  for (int e = 0; e < NE && !KS; ++e) {
     const int k = kc_begin * BK + kcol + e;
-    ntap[e] = fastdiv(k, p.dCin);
-    nci[e] = k - ntap[e] * p.Cin;
+    if (p.kmajor) {   // chunk kc = (slice kc / ntaps, tap kc % ntaps); this lane's channel = slice*32 + its offset in the chunk
+      const int sl = fastdiv(kc_begin, p.dNt);
+      ntap[e] = kc_begin - sl * ntaps;
+      nci[e] = sl * BK + kcol + e;
+    } else {
+      ntap[e] = fastdiv(k, p.dCin);
+      nci[e] = k - ntap[e] * p.Cin;
+    }
     ntt[e] = taptab[min(ntap[e], ntaps - 1)];
   }
   const float* const zero = p.zero;
@@ -224,8 +248,50 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
 #pragma unroll
   for (int i = 0; i < BR; ++i) wrowoff[i] = (unsigned)(n0 + arow + 32 * i) * (unsigned)p.Kld * 4u;
 
+  // Channel-slice-major K order on the DMA path: every chunk is ONE tap of ONE 32-channel slice, the same for all lanes, so
+  // the walk (kw fastest, then kh, kd, then the next slice) is kept in wave-uniform counters — scalar arithmetic beside the
+  // matrix pipe — and a row costs and + compare + add + select per chunk; no tap table, no per-lane tap tracking.
+  int ukw = 0, ukh = 0, ukd = 0, uslice = 0;
+  if (KS) {
+    uslice = fastdiv(kc_begin, p.dNt);
+    const int tap0 = kc_begin - uslice * ntaps;
+    const int q = fastdiv(tap0, p.dTw);
+    ukw = tap0 - q * p.nTw;
+    ukd = fastdiv(q, p.dTh);
+    ukh = q - ukd * p.nTh;
+  }
+
   auto load_chunk = [&](int kc, int buf) {
     const int k = kc * BK + kcol;
+    if (KS) {
+      const unsigned k4 = (unsigned)k * 4u;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const unsigned off = wok[i] ? wrowoff[i] + k4 : 0xffffffffu;      // K = ntaps * Cin is a whole number of chunks: no K tail
+        float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, off, 0, 0, 0);
+      }
+      const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
+      const int od = p.off0d + ukd * p.offstep, oh = p.off0h + ukh * p.offstep, ow = p.off0w + ukw * p.offstep;
+      const unsigned delta4 = (unsigned)((((od * p.Hi + oh) * p.Wi + ow) * p.in_ld + uslice * BK) * 4) + (unsigned)kcol * 4u;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const unsigned off = (rbits[i] & need) == need ? abase32[i] + delta4 : 0xffffffffu;
+        float* dst = As + buf * BM * LDR + i * 32 * LDR + wave * 64 * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
+      }
+      if (++ukw == p.nTw) {
+        ukw = 0;
+        if (++ukh == p.nTh) {
+          ukh = 0;
+          if (++ukd == p.nTd) {
+            ukd = 0;
+            ++uslice;
+          }
+        }
+      }
+      return;
+    }
     // current chunk's tap state; then advance and prefetch the following chunk's tap entry BEFORE any DMA is issued
     int ctap[NE], cci[NE];
     int4 ctt[NE];
@@ -234,11 +300,18 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       ctap[e] = ntap[e];
       cci[e] = nci[e];
       ctt[e] = ntt[e];
-      nci[e] += adv_ci;
-      ntap[e] += adv_tap;
-      if (nci[e] >= p.Cin) {
-        nci[e] -= p.Cin;
-        ++ntap[e];
+      if (p.kmajor) {
+        if (++ntap[e] >= ntaps) {
+          ntap[e] = 0;
+          nci[e] += BK;
+        }
+      } else {
+        nci[e] += adv_ci;
+        ntap[e] += adv_tap;
+        if (nci[e] >= p.Cin) {
+          nci[e] -= p.Cin;
+          ++ntap[e];
+        }
       }
       ntt[e] = taptab[min(ntap[e], ntaps - 1)];
     }
@@ -484,6 +557,11 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
 __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
   igemm_body<BM, BN, WAVES_M, WAVES_N, VEC>(p, (int)blockIdx.x, (int)gridDim.x);
 }
+// the same tile with the channel-slice-major K walk (LDS-DMA path)
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void igemm_ks_kernel(const IgemmParams p) {
+  igemm_body<BM, BN, WAVES_M, WAVES_N, 4, true>(p, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // Several independent problems of one tile shape in a single launch: the stride-parity classes of a strided convolution's
 // input gradient (8 for stride (2,2,2)) are small GEMMs — R3D-18's layer4.0: 8 x (512 rows x 256 columns) — that each left
@@ -654,7 +732,15 @@ __global__ void pack_weight_kernel(const PackParams p) {
     float v = 0.f;
     const int ntaps = p.nTd * p.nTh * p.nTw;
     if (k < ntaps * p.C) {
-      const int tap = k / p.C, c = k - tap * p.C;
+      int tap, c;
+      if (k_slice_major(p.C, ntaps)) {
+        const int sl = k / (ntaps * 32), r = k - sl * (ntaps * 32);
+        tap = r >> 5;
+        c = sl * 32 + (r & 31);
+      } else {
+        tap = k / p.C;
+        c = k - tap * p.C;
+      }
       const int aw = tap % p.nTw, q = tap / p.nTw;
       const int ah = q % p.nTh, ad = q / p.nTh;
       const int kt = p.k0d + ad * p.kstepd, kh = p.k0h + ah * p.ksteph, kw = p.k0w + aw * p.kstepw;
@@ -702,6 +788,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const rsp_pack_job* __r
     tsrc_of[tap] = ((j.k0d + ad * j.kstepd) * j.kH + (j.k0h + ah * j.ksteph)) * j.kW + (j.k0w + aw * j.kstepw);
   }
   const int T = j.kT * j.kH * j.kW;
+  const bool kmaj = k_slice_major(j.C, j.ntaps);
   const int CH = T >= 4096 ? 1 : (4096 / T > 128 ? 128 : 4096 / T);
   const bool o_in = o < (j.transpose ? j.Cin_src : j.Cout_src);
   const int c_in = j.transpose ? j.Cout_src : j.Cin_src;
@@ -719,10 +806,25 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const rsp_pack_job* __r
     __syncthreads();
     for (int e = threadIdx.x; e < j.ntaps * nc; e += 256) {
       const int tap = e / nc, cl = e - tap * nc;
-      row[tap * j.C + c0 + cl] = tile[cl * T + tsrc_of[tap]];
+      row[k_index(kmaj, tap, c0 + cl, j.C, j.ntaps)] = tile[cl * T + tsrc_of[tap]];
     }
   }
   for (int k = j.ntaps * j.C + threadIdx.x; k < j.Kld; k += 256) row[k] = 0.f;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_ks_cfg(const IgemmParams& p, hipStream_t s) {
+  const size_t lds = (size_t)p.nbuf * (BM + BN) * BK * sizeof(float) + (size_t)(p.nTd * p.nTh * p.nTw + 1) * sizeof(int4) + BM * sizeof(long long);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const size_t lds_max = (size_t)2 * (BM + BN) * BK * sizeof(float) + (MAX_TAPS + 1) * sizeof(int4) + BM * sizeof(long long);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ks_kernel<BM, BN, WAVES_M, WAVES_N>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    attr_set = true;
+  }
+  dim3 grid(p.full_tiles + (p.m_tiles * p.n_tiles - p.full_tiles) * p.splitk);
+  hipLaunchKernelGGL((igemm_ks_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds, s, p);
+  return rsp_check_launch("igemm_ks_kernel");
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
@@ -777,6 +879,8 @@ inline void fill_fastdiv(IgemmParams& p) {
   p.dCin = fastdiv_make(p.Cin); p.dTw = fastdiv_make(p.nTw); p.dTh = fastdiv_make(p.nTh);
   p.adv_tap = BK / p.Cin;
   p.adv_ci = BK % p.Cin;
+  p.kmajor = k_slice_major(p.Cin, p.nTd * p.nTh * p.nTw) ? 1 : 0;
+  p.dNt = fastdiv_make(p.nTd * p.nTh * p.nTw);
   p.linear_out = p.oSd == 1 && p.oSh == 1 && p.oSw == 1 && p.oOd == 0 && p.oOh == 0 && p.oOw == 0 && p.oDm == p.Gd &&
                  p.oHm == p.Gh && p.oWm == p.Gw;
 }
@@ -793,6 +897,15 @@ int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
     return launch_cfg<256, 128, 2, 2, 4, 1>(p, s);
   }
 #endif
+  if (vec4 && p.kmajor) {
+    switch (bn) {
+      case 160: return launch_ks_cfg<128, 160, 4, 1>(p, s);
+      case 128: return launch_ks_cfg<128, 128, 2, 2>(p, s);
+      case 96: return launch_ks_cfg<128, 96, 4, 1>(p, s);
+      case 64: return launch_ks_cfg<128, 64, 2, 2>(p, s);
+      default: return launch_ks_cfg<128, 32, 4, 1>(p, s);
+    }
+  }
   if (bn == 160) return launch_cfg<128, 160, 4, 1, 4>(p, s);
   if (bn == 96) return launch_cfg<128, 96, 4, 1, 4>(p, s);
   if (bn == 128) return vec4 ? launch_cfg<128, 128, 2, 2, 4>(p, s) : launch_cfg<128, 128, 2, 2, 1>(p, s);
@@ -1161,6 +1274,24 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   int bn = tile_bn(plan_segments(cols).width[0]);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   // spelled as rocprofv3 prints the demangled instance (minus namespace and argument list)
+  if (vec4 && which == 0 && k_slice_major(d->Cin, d->kT * d->kH * d->kW)) {
+    switch (bn) {
+      case 160: return "igemm_ks_kernel<128, 160, 4, 1>";
+      case 128: return "igemm_ks_kernel<128, 128, 2, 2>";
+      case 96: return "igemm_ks_kernel<128, 96, 4, 1>";
+      case 64: return "igemm_ks_kernel<128, 64, 2, 2>";
+      default: return "igemm_ks_kernel<128, 32, 4, 1>";
+    }
+  }
+  if (vec4 && which == 1 && d->sT * d->sH * d->sW == 1 && k_slice_major(d->Cout, d->kT * d->kH * d->kW)) {
+    switch (bn) {
+      case 160: return "igemm_ks_kernel<128, 160, 4, 1>";
+      case 128: return "igemm_ks_kernel<128, 128, 2, 2>";
+      case 96: return "igemm_ks_kernel<128, 96, 4, 1>";
+      case 64: return "igemm_ks_kernel<128, 64, 2, 2>";
+      default: return "igemm_ks_kernel<128, 32, 4, 1>";
+    }
+  }
   if (vec4) {
     switch (bn) {
       case 160: return "igemm_kernel<128, 160, 4, 1, 4, 2>";
@@ -1265,7 +1396,7 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
   long long tiles_all = 0;
   const int bn = tile_bn(d->Cin);
   for (int i = 0; i < ncls && multi; ++i) {
-    multi = cvec[i];
+    multi = cvec[i] && !k_slice_major(cls[i].Cin, cls[i].nTd * cls[i].nTh * cls[i].nTw);   // (one K walk per launch: the tap-major one)
     tiles_all += (long long)rsp_cdiv(cls[i].M, 128) * rsp_cdiv(d->Cin, bn);
   }
   // (below ~one round of resident workgroups the classes need the K split of the single-problem path to fill the machine —

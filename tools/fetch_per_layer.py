@@ -32,7 +32,7 @@ def alg(l, what):
 
 def conv_rows(kind):
     f = glob.glob(f"{ROOT}/gpurun_out/pmc_{kind}_{tag}_c3d/*/*_counter_collection.csv")[0]
-    return [r for r in csv.DictReader(open(f)) if any(s in r["Kernel_Name"] for s in ("igemm_kernel", "stem_resident", "stem_kernel", "wgrad_dma"))]
+    return [r for r in csv.DictReader(open(f)) if any(s in r["Kernel_Name"] for s in ("igemm_kernel", "igemm_ks_kernel", "igemm_multi_kernel", "stem_resident", "stem_kernel", "wgrad_dma"))]
 
 
 fr, wr = conv_rows("fetch"), conv_rows("write")
