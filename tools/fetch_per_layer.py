@@ -5,7 +5,7 @@ launch of the last profiled step, beside the launch's algorithmic bytes (input +
 FETCH_SIZE counts the requests that leave the XCD's L2 — Infinity-Cache (256 MiB) hits included — so it bounds HBM reads from
 above; weights (<= 28 MB per layer) and the smaller activations are served from the Infinity Cache.
 
-    python tools/fetch_per_layer.py r2p > profiles/r02/fetch_per_layer_c3d_r2p.txt"""
+    python tools/fetch_per_layer.py r2t > profiles/r02/fetch_per_layer_c3d_r2t.txt"""
 import csv
 import glob
 import os
