@@ -64,6 +64,11 @@ CONV_CASES = [
     (1, 6, 130, 128, 16, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # 780 tiles of 128x128, K = 432
     (1, 6, 130, 128, 16, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 780 tiles of 128x96
     (1, 6, 130, 128, 128, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # dgrad: 780 tiles of 128x128 over K = 32 (one chunk)
+    # channel-slice-major K order (igemm_ks_kernel: C % 32 == 0, >= 96 chunks) on the 96-, 64- and 32-wide tiles; strided: per-class choice
+    (1, 2, 6, 6, 128, 96, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 2, 6, 6, 128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 2, 6, 6, 128, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 4, 8, 8, 32, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1)),        # dgrad C = 512: the 8-tap class is slice-major, the others tap-major
     # wgrad output-channel segments on the 32-wide tile
     (1, 3, 20, 20, 8, 20, (1, 3, 3), (1, 1, 1), (0, 1, 1)),        # 20 channels: one 32-wide tile
     (1, 3, 20, 20, 16, 272, (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # 272 = 256 + 16; K = 16 (64-wide k tile: the 16 ride on the 64-row tile)
