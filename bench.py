@@ -17,7 +17,12 @@ Prints ONE JSON line on rank 0 (see the driver contract): value = whole-job clip
                  algorithmic FLOPs / HIP-event time on the launch stream against the fp32-input MFMA peak (157.3 TFLOP/s,
                  MI355X_MICROARCH.md); the block's headline is the kernel with the largest share of the step for THIS arch;
   cpu_baseline — the oracle restatement (oracle/restatement.py, proven equal to the reference) timed on this host's
-                 physical cores on BASELINE config 1 (32 clips; 1 warm-up + 2 timed steps) — rank 0, N=1 only.
+                 physical cores on BASELINE config 1 (32 clips; 1 warm-up + 2 timed steps) — rank 0, N=1 only;
+  parity       — the CPU leg's warm-up step REPLAYS the GPU run's first step (same pre-step state, clips, permutations):
+                 relative errors of loss / logits / features / queue slab / whole gradient at the measured size;
+  steps_ms     — p50 / min / max / p90 of the GPU-side per-step intervals + the host's enqueue time per step;
+  comm_ms      — N > 1: per-step stall of this rank's compute stream behind each collective;
+  other_workloads — N = 1 default run: BASELINE configs 3-5 (R3D-18, R(2+1)D B=32; S3D-G B=16 at 224^2), 10 + 30 steps each.
 """
 import argparse
 import json
@@ -52,6 +57,16 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32, help="clips per CPU-baseline step (BASELINE config 1: 32)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps after one warm-up step")
+    ap.add_argument("--no-other-workloads", dest="other_workloads", action="store_false",
+                    help="skip BASELINE configs 3-5 (R3D-18, R(2+1)D, S3D-G) that the default N=1 C3D run appends")
+    ap.add_argument("--other-steps", type=int, default=30)
+    ap.add_argument("--other-warmup", type=int, default=10)
+    ap.add_argument("--deadline", type=float, default=float(os.environ.get("RSP_BENCH_DEADLINE", 1500)),
+                    help="self-launcher only: seconds after which a still-running job is killed and rc=124 returned")
+    ap.add_argument("--collective-timeout", type=float, default=300.0,
+                    help="process-group timeout (rendezvous and every collective), seconds")
+    ap.add_argument("--selftest-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-parity", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher / host-logic self-test without a GPU: gloo + the tests' checker op backend on tiny clips; "
                          "the printed line says data='selftest-cpu' and is not a measurement")
@@ -69,9 +84,12 @@ def _free_port() -> int:
     return port
 
 
-def launch(n: int, argv) -> int:
-    """Start n rank processes of this file, wait, return the job's exit code (non-zero if any rank failed)."""
+def launch(n: int, argv, deadline_s: float) -> int:
+    """Start n rank processes of this file, wait, return the job's exit code: non-zero if any rank failed, or if the job is
+    still running `deadline_s` seconds after the start (a rank stuck in a collective, a dead peer) — every rank is killed then,
+    so the caller gets a diagnosable failure instead of a node held until its own limit."""
     port = _free_port()
+    t_start = time.monotonic()
     procs = []
     for r in range(n):
         env = dict(os.environ)
@@ -84,6 +102,11 @@ def launch(n: int, argv) -> int:
         live = list(procs)
         while live:
             time.sleep(0.05)
+            if time.monotonic() - t_start > deadline_s:
+                print(f"bench.py: job exceeded its deadline of {deadline_s:.0f} s with ranks "
+                      f"{[procs.index(p) for p in live]} still running; killing all ranks", file=sys.stderr)
+                rc = 124
+                break
             for p in list(live):
                 code = p.poll()
                 if code is None:
@@ -126,41 +149,86 @@ def host_cpu():
     return model, max(1, min(len(pairs) or avail, avail))
 
 
-def cpu_baseline(arch, hw, sample_b, steps, K):
+def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
+    """Oracle restatement timed on this host (reported baseline).  With `parity` = what the GPU's first step consumed and
+    produced (bench.py:parity_capture), the untimed warm-up step replays THAT step — same pre-step state, clips, diff-speed
+    permutation and shuffle permutations — and the line gets a "parity" object: BASELINE config 2's "loss match vs
+    reference" re-proved on every bench run at the measured size (loss / logits within 1e-3 relative is the north-star bar)."""
+    import numpy as np
     import torch
     from oracle import portable as P
     from oracle import restatement as S
-    with open(os.path.join(ROOT, "tests", "golden", f"state_spec_{arch.replace('-', '_')}.json")) as f:
-        spec = {k: (tuple(s), d) for k, (s, d) in json.load(f).items()}
-    spec["queue"] = ((128, K), "float32")
     model, cores = host_cpu()
     torch.set_num_threads(cores)
-    state = {k: torch.from_numpy(v) for k, v in P.fill_state(spec, 1).items()}
-    moms = [{}]
     g = torch.Generator().manual_seed(0)
-    im_q = torch.randn(sample_b, 3, 32, hw, hw, generator=g)
-    im_k = torch.randn(sample_b, 3, 32, hw, hw, generator=g)
+    par = None
+    if parity is not None:
+        state = parity["state"]
+        im_q, im_k = parity["im_q"], parity["im_k"]
+        sample_b = im_q.shape[0]
+        first = (parity["perm"], (parity["sh1"], parity["sh2"]), parity["speed"])
+    else:
+        with open(os.path.join(ROOT, "tests", "golden", f"state_spec_{arch.replace('-', '_')}.json")) as f:
+            spec = {k: (tuple(s), d) for k, (s, d) in json.load(f).items()}
+        spec["queue"] = ((128, K), "float32")
+        state = {k: torch.from_numpy(v) for k, v in P.fill_state(spec, 1).items()}
+        im_q = torch.randn(sample_b, 3, 32, hw, hw, generator=g)
+        im_k = torch.randn(sample_b, 3, 32, hw, hw, generator=g)
+        first = None
+    moms = [{}]
     times = []
     for it in range(1 + steps):                      # step 0 = warm-up (allocator, oneDNN primitive caches)
-        perm = torch.randperm(sample_b, generator=g)
-        sh = (torch.randperm(sample_b, generator=g), torch.randperm(sample_b, generator=g))
+        if it == 0 and first is not None:
+            perm, sh, speed = first
+        else:
+            perm = torch.randperm(sample_b, generator=g)
+            sh = (torch.randperm(sample_b, generator=g), torch.randperm(sample_b, generator=g))
+            speed = 2
         t0 = time.perf_counter()
-        S.moco_step(arch, [state], [im_q], [im_k], [perm], sh, 2, K=K, lr=0.05, momentum_buffers=moms)
+        outs = S.moco_step(arch, [state], [im_q], [im_k], [perm], sh, speed, K=K, lr=lr, momentum_buffers=moms)
         times.append(time.perf_counter() - t0)
+        if it == 0 and first is not None:
+            o, got = outs[0], parity["out"]
+
+            def rel(a, b):
+                a, b = a.double(), b.double()
+                return float((a - b).abs().max() / b.abs().max().clamp_min(1e-5))
+
+            num = den = 0.0
+            for k, gr in o["grads"].items():
+                if gr is not None:
+                    d = (parity["grads"][k].double() - gr.double())
+                    num, den = num + float((d * d).sum()), den + float((gr.double() ** 2).sum())
+            ptr0 = parity["ptr0"]
+            par = {"vs": "oracle/restatement.py:moco_step (pinned to the reference) replaying the GPU run's first step: same "
+                         "pre-step state, clips, diff-speed and shuffle permutations",
+                   "loss_rel": rel(got["loss"], o["loss"]), "loss_A_rel": rel(got["loss_A"], o["loss_A"]),
+                   "loss_M_rel": rel(got["loss_M"], o["loss_M"]),
+                   "logits_rel": max(rel(got["logits1"], o["logits1"]), rel(got["logits2"], o["logits2"])),
+                   "ranking_logits_rel": max(rel(got["l_pos_M"], o["l_pos_M"]), rel(got["l_neg_M"], o["l_neg_M"])),
+                   "features_rel": max(rel(got["q_A"], o["q_A"]), rel(got["q_M"], o["q_M"])),
+                   "queue_slab_rel": rel(got["queue_slab"], state["queue"][:, ptr0:ptr0 + sample_b]),
+                   "grad_rel_l2": (num / den) ** 0.5 if den > 0 else None,
+                   "loss_gpu": float(got["loss"]), "loss_oracle": float(o["loss"]), "tolerance": 1e-3}
+            par = {k: (float(f"{v:.3e}") if isinstance(v, float) and k.endswith(("_rel", "_l2")) else v) for k, v in par.items()}
+            par["ok"] = bool(all(par[k] <= 1e-3 for k in ("loss_rel", "loss_A_rel", "loss_M_rel", "logits_rel",
+                                                          "ranking_logits_rel", "features_rel", "queue_slab_rel")))
     timed = times[1:] or times
     dt = sum(timed) / len(timed)
-    return {"value": round(sample_b / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": model,
-            "s_per_step": round(dt, 2),
-            "sample": f"{arch} full pretext step (2 key passes + query fwd/bwd + losses + SGD) on {sample_b} synthetic clips "
-                      f"3x32x{hw}x{hw}, K={K}; 1 warm-up step ({times[0]:.1f} s) + mean of {len(timed)} timed; torch "
-                      f"{torch.__version__} CPU ops, {cores} threads = physical cores of {model}"}
+    res = {"value": round(sample_b / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": model,
+           "s_per_step": round(dt, 2),
+           "sample": f"{arch} full pretext step (2 key passes + query fwd/bwd + losses + SGD) on {sample_b} synthetic clips "
+                     f"3x32x{hw}x{hw}, K={K}; 1 warm-up step ({times[0]:.1f} s"
+                     f"{', the replay of the GPU run first step' if first is not None else ''}) + mean of {len(timed)} timed; torch "
+                     f"{torch.__version__} CPU ops, {cores} threads = physical cores of {model}"}
+    return res, par
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------------------------------------------------
 def load_traffic(arch, B, kernel):
-    """Measured HBM bytes per launch of `kernel` (PMC passes, profiles/traffic.json), GB, or None."""
+    """Measured L2-miss bytes per launch of `kernel` (PMC passes, profiles/traffic.json), GB, or None."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, None
@@ -172,42 +240,22 @@ def load_traffic(arch, B, kernel):
     return round(ent["hbm_bytes_per_launch"] / 1e9, 4), ent.get("source")
 
 
-def run_rank(args):
+def _pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))] if xs else None
+
+
+def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parity=False):
+    """Build the pretext model of `arch`, run `warmup` untimed + `steps` timed steps, return (result dict, parity capture)."""
     import torch
     import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}")
-    cpu_selftest = args.selftest_cpu
-    if cpu_selftest:
-        dev = torch.device("cpu")
-        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(ws, 1) // 2))
-    else:
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-    if ws > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if cpu_selftest:
-            dist.init_process_group("gloo", rank=rank, world_size=ws)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=dev)
-
     from rspnet_amd import ops
-    if cpu_selftest:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from cpu_ops import CpuOps                     # TEST backend: exercises launcher + host logic only
-        ops.set_backend(CpuOps())
     from rspnet_amd.moco import Loss, ModelFactory
     from rspnet_amd.optim import SGD
 
-    B, hw, base_lr = ARCHS[args.arch]
-    B = args.batch or B
-    hw = args.hw or hw
+    cuda = dev.type == "cuda"
     K = args.queue // (B * ws) * (B * ws)                  # utils/moco.py:8-10 trim
-    cfg = {"model": {"arch": args.arch},
+    cfg = {"model": {"arch": arch},
            "moco": {"dim": 128, "k": K, "m": 0.999, "t": 0.07, "fc_type": "linear", "diff_speed": [2]}}
     torch.manual_seed(1234)
     model = ModelFactory(cfg).build_moco_diffloss(device=dev)
@@ -225,82 +273,216 @@ def run_rank(args):
         opt.zero_grad()
         loss.backward()
         opt.step()
-        return loss
+        return loss, loss_A, loss_M, out, rl
 
     def fence():
         if ws > 1:
             dist.barrier()
-        if dev.type == "cuda":
+        if cuda:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    capture = None
+    if want_parity:
+        # one extra untimed step in front of the warm-up, replayed afterwards on the CPU oracle (cpu_baseline)
+        inner = model.module
+        state = {k: v.detach().cpu().clone() for k, v in inner.state_dict().items()}
+        ptr0 = int(state["queue_ptr"])
+        loss, loss_A, loss_M, out, rl = step()
+        names = {id(p): n for n, p in inner.named_parameters()}
+        perm, speed, sh1, sh2 = inner._last_draw
+        q_A, q_M = inner._last_q
+        capture = {"state": state, "im_q": im_q.cpu(), "im_k": im_k.cpu(), "perm": perm.cpu(), "speed": int(speed),
+                   "sh1": torch.from_numpy(sh1.copy()), "sh2": torch.from_numpy(sh2.copy()), "ptr0": ptr0, "K": K, "lr": lr,
+                   "grads": {names[id(p)]: p.grad.detach().cpu().clone() for p in inner.encoder_q.parameters()
+                             if p.grad is not None},
+                   "out": {"loss": loss.detach().cpu(), "loss_A": loss_A.cpu(), "loss_M": loss_M.cpu(),
+                           "logits1": out[0].detach().cpu(), "logits2": out[1].detach().cpu(), "l_pos_M": rl[0].detach().cpu(),
+                           "l_neg_M": rl[1].detach().cpu(), "q_A": q_A.cpu(), "q_M": q_M.cpu(),
+                           "queue_slab": inner.queue[:, ptr0:ptr0 + B].cpu()}}
+        del loss, loss_A, loss_M, out, rl
+
+    for _ in range(warmup):
         step()
     be = ops.backend()
+    inner = model.module
     fence()
-    if dev.type == "cuda":
+    if cuda:
         be.event_log = []
+    if ws > 1:
+        inner.comm_log = {}
+    marks, host = [], []
+    if cuda:
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        loss = step()[0]
+        host.append((time.perf_counter() - h0) * 1e3)       # time the host needs to ENQUEUE a step (it runs ahead of the GPU)
+        if cuda:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
     fence()
     dt = time.perf_counter() - t0
     log = []
-    if dev.type == "cuda":
+    if cuda:
         log, be.event_log = be.event_log, None
+    comm, inner.comm_log = inner.comm_log, None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if ws > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     final_loss = float(loss.detach())
-
-    if rank == 0:
+    step_ms = dt / steps * 1e3
+    res = {"clips_per_s": ws * B * steps / dt, "ms_per_step": step_ms, "final_loss": final_loss, "K": K, "lr": lr, "B": B,
+           "hw": hw}
+    if marks:
+        per = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        res["steps_ms"] = {"p50": round(_pct(per, 0.5), 3), "min": round(min(per), 3), "max": round(max(per), 3),
+                           "p90": round(_pct(per, 0.9), 3), "first": round(per[0], 3),
+                           "host_enqueue_p50": round(_pct(host, 0.5), 3), "host_enqueue_max": round(max(host), 3),
+                           "note": "GPU-side step intervals (HIP events on the launch stream at step boundaries); host_enqueue = "
+                                   "host time to issue one step"}
+    if comm:
+        # per-rank stall of the compute stream behind each collective, ms per step (this rank)
+        cm = {}
+        for name, items in comm.items():
+            tot = sum((a.elapsed_time(b) if not isinstance(a, float) else a) for a, b in items) if cuda else sum(items)
+            cm[name] = round(tot / steps, 3)
+        res["comm_ms"] = cm
+    if log:
         per_kernel, per_kind = {}, {}
-        for kind, f, e0, e1, kernel in log:
+        for kind, f, e0, e1, kernel, nbytes in log:
             ms = e0.elapsed_time(e1)
             for table, key in ((per_kernel, kernel), (per_kind, kind)):
-                a = table.setdefault(key, [0.0, 0.0, 0])
+                a = table.setdefault(key, [0.0, 0.0, 0, 0.0])
                 a[0] += f
                 a[1] += ms
                 a[2] += 1
+                a[3] += nbytes
         flops = sum(v[0] for v in per_kernel.values())
         ms = sum(v[1] for v in per_kernel.values())
         all_tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # dominant kernel of THIS backbone = the template instance with the largest share of the timed step.  Each timed
         # group also holds the small helpers launched with it (split-K reduce, dgrad weight re-pack, wgrad slab reduce).
-        dom = max(per_kernel, key=lambda k: per_kernel[k][1]) if per_kernel else None
-        dflops, dms, dn = per_kernel[dom] if dom else (0.0, 0.0, 0)
+        dom = max(per_kernel, key=lambda k: per_kernel[k][1])
+        dflops, dms, dn, dbytes = per_kernel[dom]
         achieved = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-        traffic, traffic_src = load_traffic(args.arch, B, dom) if dom else (None, None)
-        clips = ws * B * args.steps / dt
+        traffic, traffic_src = load_traffic(arch, B, dom)
+        alg_gb = dbytes / max(dn, 1) / 1e9
+        whole = flops / steps / (step_ms * 1e-3) / 1e12
+        res["roofline"] = {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "GB of L2-miss (fabric) traffic per launch: PMC FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache "
+                            "hits (MI355X_MICROARCH.md), so an upper bound of the HBM bytes",
+            "algorithmic_gb_per_launch": round(alg_gb, 4),
+            "traffic_over_algorithmic": None if traffic is None or alg_gb <= 0 else round(traffic / alg_gb, 2),
+            "traffic_source": traffic_src,
+            "kernel": dom, "launches": dn, "avg_launch_ms": round(dms / max(dn, 1), 4),
+            "share_of_step": round(dms / steps / step_ms, 4),
+            "algorithmic_gflop_per_launch": round(dflops / max(dn, 1) / 1e9, 2),
+            "whole_step": {"algorithmic_conv_gflop_per_clip": round(flops / steps / B / 1e9, 2),
+                           "achieved": round(whole, 2), "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4)},
+            "all_conv_launches": {"achieved": round(all_tf, 2), "frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "ms_per_step": round(ms / steps, 3), "launches": len(log)},
+            "per_kernel": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms_per_step": round(v[1] / steps, 3),
+                               "launches_per_step": round(v[2] / steps, 2),
+                               "avg_launch_ms": round(v[1] / v[2], 4)}
+                           for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
+            "per_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in per_kind.items()},
+            "per_kind_ms_per_step": {k: round(v[1] / steps, 3) for k, v in per_kind.items()}}
+    # let the next workload start from an empty device
+    del model, opt, im_q, im_k, inner
+    if cuda:
+        torch.cuda.synchronize()
+        be._ws.clear()
+        torch.cuda.empty_cache()
+    return res, capture
+
+
+def run_rank(args):
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}")
+    cpu_selftest = args.selftest_cpu
+    if cpu_selftest and args.selftest_hang_rank == rank:
+        time.sleep(3600)                                    # launcher-deadline self-test: this rank never joins the group
+    if cpu_selftest:
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(ws, 1) // 2))
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that never arrives / a collective that never completes ends the job with rc != 0 (watchdog abort) instead of
+        # holding the node until the driver's own limit
+        tmo = datetime.timedelta(seconds=args.collective_timeout)
+        if cpu_selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=ws, timeout=tmo)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=dev, timeout=tmo)
+
+    from rspnet_amd import ops
+    if cpu_selftest:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from cpu_ops import CpuOps                     # TEST backend: exercises launcher + host logic only
+        ops.set_backend(CpuOps())
+
+    B, hw, base_lr = ARCHS[args.arch]
+    B = args.batch or B
+    hw = args.hw or hw
+    want_cpu = ws == 1 and not args.no_cpu_baseline and (not cpu_selftest or args.selftest_parity)
+    m, capture = measure(args, args.arch, B, hw, base_lr, args.steps, args.warmup, dev, rank, ws,
+                         want_parity=want_cpu and args.cpu_sample == B)
+    if rank == 0:
+        K, lr = m["K"], m["lr"]
         res = {
             "metric": f"clips/sec pretext step ({args.arch} 16x{hw}x{hw}, B={B}/GPU)",
-            "value": round(clips, 3), "unit": "clips/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(m["clips_per_s"], 3), "unit": "clips/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(m["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "selftest-cpu" if cpu_selftest else "synthetic",
             "config": {"workload": f"{args.arch} pretext step, {B} synthetic clips/GPU, model input {B}x3x32x{hw}x{hw} "
                                    f"(encoder 3x16x{hw}x{hw}), K={K}, dim=128, T=0.07, m=0.999, SGD lr={lr:g}",
                        "global_batch": B * ws, "parallelism": f"dp{ws}"},
-            "final_loss": round(final_loss, 5),
+            "final_loss": round(m["final_loss"], 5),
         }
-        if log:
-            step_ms = dt / args.steps * 1e3
-            res["roofline"] = {
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "GB HBM per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                "kernel": dom, "launches": dn, "avg_launch_ms": round(dms / max(dn, 1), 4),
-                "share_of_step": round(dms / args.steps / step_ms, 4),
-                "algorithmic_gflop_per_launch": round(dflops / max(dn, 1) / 1e9, 2),
-                "all_conv_launches": {"achieved": round(all_tf, 2), "frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                                      "ms_per_step": round(ms / args.steps, 3), "launches": len(log)},
-                "per_kernel": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms_per_step": round(v[1] / args.steps, 3),
-                                   "launches_per_step": round(v[2] / args.steps, 2),
-                                   "avg_launch_ms": round(v[1] / v[2], 4)}
-                               for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
-                "per_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in per_kind.items()},
-                "per_kind_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in per_kind.items()}}
-        if ws == 1 and not args.no_cpu_baseline and not cpu_selftest:
-            res["cpu_baseline"] = cpu_baseline(args.arch, hw, args.cpu_sample, args.cpu_steps, 16384)
+        for k in ("steps_ms", "comm_ms", "roofline"):
+            if k in m:
+                res[k] = m[k]
+    # BASELINE.json configs 3-5 on the same box (N=1, default run only): the other three backbones at their own batch / clip
+    # size, a shorter run each — whole-step and dominant-kernel roofline fractions next to the headline
+    if ws == 1 and not cpu_selftest and args.other_workloads and args.arch == "c3d" and not args.batch and not args.hw:
+        others = {}
+        for arch in ("resnet18", "r2plus1d-vcop", "s3dg"):
+            oB, ohw, olr = ARCHS[arch]
+            om, _ = measure(args, arch, oB, ohw, olr, args.other_steps, args.other_warmup, dev, rank, ws)
+            rf = om["roofline"]
+            others[arch] = {"workload": f"{arch} pretext step, {oB} clips/GPU, encoder 3x16x{ohw}x{ohw}, K={om['K']}",
+                            "clips_per_s": round(om["clips_per_s"], 2), "ms_per_step": round(om["ms_per_step"], 3),
+                            "steps": args.other_steps, "warmup": args.other_warmup, "steps_ms": om.get("steps_ms"),
+                            "whole_step_frac": rf["whole_step"]["frac"],
+                            "algorithmic_conv_gflop_per_clip": rf["whole_step"]["algorithmic_conv_gflop_per_clip"],
+                            "conv_launches_frac": rf["all_conv_launches"]["frac"],
+                            "conv_ms_per_step": rf["all_conv_launches"]["ms_per_step"],
+                            "dominant_kernel": rf["kernel"], "dominant_kernel_frac": rf["frac"],
+                            "dominant_kernel_share_of_step": rf["share_of_step"], "final_loss": round(om["final_loss"], 5)}
+        res["other_workloads"] = others
+    if rank == 0:
+        if want_cpu:
+            cb, par = cpu_baseline(args.arch, hw, args.cpu_sample, args.cpu_steps, m["K"], m["lr"], parity=capture)
+            res["cpu_baseline"] = cb
+            res["vs_cpu_baseline"] = round(res["value"] / cb["value"], 1) if cb["value"] > 0 else None
+            if par is not None:
+                res["parity"] = par
         print(json.dumps(res), flush=True)
     if ws > 1:
         dist.barrier()
@@ -311,7 +493,7 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch(args.gpus, argv))
+        sys.exit(launch(args.gpus, argv, args.deadline))
     run_rank(args)
 
 

@@ -34,6 +34,37 @@ def _world():
     return 0, 1
 
 
+class _CommTimer:
+    """Books how long the compute stream is held up by a collective: HIP events on the current stream around the blocking
+    call / the wait (the collective itself runs on RCCL's stream), host wall time for CPU process groups."""
+
+    def __init__(self, log, name, device):
+        self.log, self.name, self.cuda = log, name, device.type == "cuda"
+
+    def __enter__(self):
+        if self.log is None:
+            return self
+        if self.cuda:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        else:
+            import time
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.log is None:
+            return False
+        if self.cuda:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.log.setdefault(self.name, []).append((self.e0, e1))
+        else:
+            import time
+            self.log.setdefault(self.name, []).append((time.perf_counter() - self.t0) * 1e3)
+        return False
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, l1, l2, lp, ln, margin, A, M):
@@ -130,6 +161,8 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._last_q = None
         self._last_k = []
         self._last_speed = None
+        self._last_draw = None
+        self.comm_log = None                  # set to {} to collect per-collective stall times (see _comm)
         self._pending = []
         self._q_version = None
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
@@ -244,15 +277,18 @@ class MoCoDiffLossTwoFc(nn.Module):
         return speed, sh1.numpy().astype(np.int64), sh2.numpy().astype(np.int64)
 
     @torch.no_grad()
-    def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
-        """Key pass with shuffle-BN (:408-419) under the global permutation `idx`.  Returns (features [A | M] of my samples in
-        my order, features of ALL samples in global order (B*ws rows), width of the A part)."""
+    def _shuffle_exchange(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
+        """First half of a key pass: shuffle-BN's sample exchange (:361-387) under the global permutation `idx`.  The clips
+        are sub-sampled first (each has exactly one destination rank) and travel in ONE all-to-all, issued asynchronously:
+        both key passes' exchanges are started back to back at the top of the step — the permutations are known then — so
+        the second one runs over xGMI under the first key pass's convolutions.  Returns the state `_key_pass` consumes."""
         be = _ops.backend()
         rank, ws = _world()
         B = im.shape[0]
         dev = im.device
         G = idx.reshape(ws, B)
         owner = G // B
+        handle = None
         if ws == 1:
             src = torch.from_numpy(idx.astype(np.int32)).to(dev, non_blocking=True)
             x = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
@@ -267,27 +303,52 @@ class MoCoDiffLossTwoFc(nn.Module):
             src = torch.from_numpy(send_src).to(dev, non_blocking=True)
             xs = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
             x = torch.empty_like(xs)
-            dist.all_to_all_single(x, xs, out_splits, in_splits)
-        self._nbt_k += 1
-        a, m, _ = self.encoder_k.forward_ndhwc(x, keep=False)
-        feats = torch.cat([a, m], dim=1)
-        # introspection only (tests compare with the reference's encoder_k outputs): this rank's key features in arrival
-        # order + the position each arrival has in the reference's shuffled batch G[rank]
-        self._last_k.append((feats, np.argsort(owner[rank], kind="stable") if ws > 1 else np.arange(B)))
+            handle = dist.all_to_all_single(x, xs, out_splits, in_splits, async_op=True)
         # where does global sample g end up?  rank r = position(g)//B; inside r's batch, clips arrive ordered by
         # source rank, then by their order in G[r]
         loc = np.empty(B * ws, dtype=np.int64)
         for r in range(ws):
             order = np.argsort(owner[r], kind="stable")
             loc[G[r][order]] = r * B + np.arange(B)
+        loc_t = torch.from_numpy(loc.astype(np.int32)).to(dev, non_blocking=True)
+        arrival = np.argsort(owner[rank], kind="stable") if ws > 1 else np.arange(B)
+        return x, handle, loc_t, arrival
+
+    @torch.no_grad()
+    def _key_pass(self, exchange, tag: str):
+        """Second half (:408-419): encoder_k on the exchanged clips, then ONE all-gather of the fused (A | M) features that
+        serves both the un-shuffle (:389-406) and the queue's key all-gather (:348).  Returns (features [A | M] of my samples
+        in my order, features of ALL samples in global order (B*ws rows), width of the A part)."""
+        be = _ops.backend()
+        rank, ws = _world()
+        x, handle, loc_t, arrival = exchange
+        B = x.shape[0]
+        if handle is not None:
+            with self._comm("all_to_all_" + tag):
+                handle.wait()
+        self._nbt_k += 1
+        a, m, _ = self.encoder_k.forward_ndhwc(x, keep=False)
+        feats = torch.cat([a, m], dim=1)
+        # introspection only (tests compare with the reference's encoder_k outputs): this rank's key features in arrival
+        # order + the position each arrival has in the reference's shuffled batch G[rank]
+        self._last_k.append((feats, arrival))
         if ws > 1:
-            gathered = torch.empty((B * ws, feats.shape[1]), dtype=feats.dtype, device=dev)
-            dist.all_gather_into_tensor(gathered, feats)
+            gathered = torch.empty((B * ws, feats.shape[1]), dtype=feats.dtype, device=feats.device)
+            with self._comm("all_gather_" + tag):
+                dist.all_gather_into_tensor(gathered, feats)
         else:
             gathered = feats
-        loc_t = torch.from_numpy(loc.astype(np.int32)).to(dev, non_blocking=True)
         all_feats = be.rows_gather(gathered, loc_t)
         return all_feats[rank * B:(rank + 1) * B], all_feats, a.shape[1]
+
+    def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
+        """Key pass with shuffle-BN (:408-419) under the global permutation `idx` (exchange + pass, back to back)."""
+        return self._key_pass(self._shuffle_exchange(im, step, T_out, idx), "k")
+
+    def _comm(self, name: str):
+        """Context that books the time the compute stream (CPU backends: the host) is stalled by a collective under `name` in
+        `self.comm_log` (a dict the caller installs, e.g. bench.py at N > 1); a no-op otherwise."""
+        return _CommTimer(self.comm_log, name, self.queue.device)
 
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys_all: Tensor):
@@ -327,8 +388,10 @@ class MoCoDiffLossTwoFc(nn.Module):
         for bi, (s, e, ids) in enumerate(buckets):
             if bi not in launched:
                 handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
-        for h in handles:
-            h.wait()
+        if handles:
+            with self._comm("allreduce_wait"):
+                for h in handles:
+                    h.wait()
         if ws > 1:
             flat.g_flat.mul_(1.0 / ws)
         flat.attach_grads()
@@ -350,16 +413,23 @@ class MoCoDiffLossTwoFc(nn.Module):
             n1 = int(B * self.alpha)
             speed, sh1, sh2 = self._draw_step_randomness(B)
             self._last_speed = speed
+            # introspection only (parity checks replay the step on the checker with the same draws): device tensor, not read here
+            self._last_draw = (random_indices, speed, sh1, sh2)
             T_real = T // speed
             step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
             step_q[random_indices[:n1].to(dev)] = 1                      # s1 rows play q,k at normal speed
             step_kn = (1 + speed) - step_q if speed != 1 else step_q.clone()   # k_negative swaps the speeds
-            kneg_mine, kneg_all, dim = self._forward_encoder_k(im_k, step_kn, T_real, sh1)
-            k_mine, _, _ = self._forward_encoder_k(im_k, step_q, T_real, sh2)
-            k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
-            kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
+            # both shuffle-BN exchanges and the query clips are issued up front (one all-to-all each at > 1 rank: the second
+            # one overlaps the first key pass); the key passes keep the reference's order (k_negative first, :445, then k, :512)
+            ex_neg = self._shuffle_exchange(im_k, step_kn, T_real, sh1)
+            ex_k = self._shuffle_exchange(im_k, step_q, T_real, sh2)
             src = torch.arange(B, dtype=torch.int32, device=dev)
             x_q = be.clip_gather(im_q, src, step_q, T_real, max(C, INPUT_CHANNEL_PAD))
+            kneg_mine, kneg_all, dim = self._key_pass(ex_neg, "kneg")
+            k_mine, _, _ = self._key_pass(ex_k, "k")
+            del ex_neg, ex_k
+            k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
+            kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
             self._nbt_q += 1
 
         l1, l2, lp, ln = _PretextFn.apply(self, x_q, (k_A, k_M, kneg_A, kneg_M), *self._q_params)

@@ -45,6 +45,14 @@ class ConvGeom:
         """Algorithmic FLOPs of one pass (2*MACs, padded taps included — SURVEY.md §8d)."""
         return 2 * self.rows * self.Cout * (self.Cin_alg or self.Cin) * self.k[0] * self.k[1] * self.k[2]
 
+    @property
+    def bytes(self):
+        """Algorithmic bytes of one pass (forward, dgrad or wgrad alike): input + output activations + weights, each moved
+        once — what a launch must touch at least; the measured L2-miss traffic is priced against it."""
+        taps = self.k[0] * self.k[1] * self.k[2]
+        cin = self.Cin_alg or self.Cin
+        return 4 * (self.N * self.Di * self.Hi * self.Wi * cin + self.rows * self.Cout + self.Cout * cin * taps)
+
     def desc(self, in_ld=None, out_ld=None) -> _lib.ConvDesc:
         do, ho, wo = self.out_dims
         return _lib.ConvDesc(self.N, self.Di, self.Hi, self.Wi, self.Cin, do, ho, wo, self.Cout, *self.k, *self.s, *self.p,
@@ -138,7 +146,8 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
-        # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name) per MFMA launch
+        # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name, algorithmic
+        # bytes) per MFMA launch
         # group, recorded on the stream the kernels run on (torch's current stream).
         self.event_log = None
 
@@ -149,12 +158,12 @@ class HipOps:
         e.record()
         return e
 
-    def _log(self, kind, flops, e0, kernel=""):
+    def _log(self, kind, g, e0, kernel=""):
         # kernel = the template instance the library dispatches for this launch (rsp_conv3d_kernel_name)
         if e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.event_log.append((kind, flops, e0, e1, kernel))
+            self.event_log.append((kind, g.flops, e0, e1, kernel, g.bytes))
 
     # one grow-only scratch buffer per (device, stream): kernels on one stream are serialised, so they can share it; work issued
     # on different streams (independent branches of a layer graph) must not
@@ -191,7 +200,7 @@ class HipOps:
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_fwd(dref, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
                                            _ptr(ws), wsb, _stream()), "rsp_conv3d_fwd")
-        self._log("conv_fwd", g.flops, e0, names[0])
+        self._log("conv_fwd", g, e0, names[0])
         return out, stats
 
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):
@@ -203,7 +212,7 @@ class HipOps:
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_dgrad(dref, _ptr(dy), _ptr(w_ref), _ptr(dx), _ptr(ws), wsb, _stream()),
                    "rsp_conv3d_dgrad")
-        self._log("conv_dgrad", g.flops, e0, names[1])
+        self._log("conv_dgrad", g, e0, names[1])
         return dx
 
     def conv_dgrad_packed(self, g: ConvGeom, dy, w_packed):
@@ -215,7 +224,7 @@ class HipOps:
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_dgrad_packed(dref, _ptr(dy), _ptr(_chk(w_packed, "w_packed")), _ptr(dx), _ptr(ws), wsb,
                                                     _stream()), "rsp_conv3d_dgrad_packed")
-        self._log("conv_dgrad", g.flops, e0, names[1])
+        self._log("conv_dgrad", g, e0, names[1])
         return dx
 
     def pack_set(self, entries):
@@ -234,7 +243,7 @@ class HipOps:
         e0 = self._ev()
         _lib.check(self.lib.rsp_conv3d_wgrad(dref, _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
                                              _stream()), "rsp_conv3d_wgrad")
-        self._log("conv_wgrad", g.flops, e0, names[2])
+        self._log("conv_wgrad", g, e0, names[2])
 
     # ---- batch norm -------------------------------------------------------------------------------------------
     def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,

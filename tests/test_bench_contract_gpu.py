@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_contract_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "2", "--cpu-steps", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-sample", "2", "--cpu-steps", "1",
+                        "--other-steps", "2", "--other-warmup", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -36,6 +37,29 @@ def test_bench_prints_one_contract_line():
     # (the 128x128 tile: its channel-slice-major instance runs conv3-5 and their input gradients, the tap-major one conv2)
     assert rf["kernel"].startswith(("igemm_ks_kernel<128, 128", "igemm_kernel<128, 128")) and rf["kernel"] in rf["per_kernel"]
     assert abs(rf["avg_launch_ms"] - rf["per_kernel"][rf["kernel"]]["avg_launch_ms"]) < 1e-3 and 0 < rf["share_of_step"] < 1
+    # traffic is priced against the algorithmic bytes of the same launches; the whole-step fraction is in the line
+    assert rf["algorithmic_gb_per_launch"] > 0 and "L2-miss" in rf["traffic_unit"] and 0.2 < rf["whole_step"]["frac"] < 1.0
+    # per-step distribution (GPU-side intervals) next to the mean
+    sm = d["steps_ms"]
+    assert sm["min"] <= sm["p50"] <= sm["max"] and sm["host_enqueue_p50"] > 0
+    # BASELINE configs 3-5 ride on the default line
+    ow = d["other_workloads"]
+    assert set(ow) == {"resnet18", "r2plus1d-vcop", "s3dg"}
+    for a, o in ow.items():
+        assert o["clips_per_s"] > 0 and 0.1 < o["whole_step_frac"] < 1.0 and o["dominant_kernel"], a
+    assert "parity" not in d                       # --cpu-sample 2 != B: the CPU leg cannot replay the GPU's step
+
+
+def test_bench_parity_object_replays_the_first_gpu_step():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--hw", "32", "--queue", "64", "--cpu-sample", "4", "--cpu-steps", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    p = d["parity"]
+    assert p["ok"] is True, p
+    assert max(p["loss_rel"], p["logits_rel"], p["features_rel"], p["queue_slab_rel"]) <= 1e-3 and p["grad_rel_l2"] <= 2e-2, p
+    assert "other_workloads" not in d
 
 
 def test_bench_roofline_is_arch_aware():

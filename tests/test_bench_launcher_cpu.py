@@ -52,3 +52,39 @@ def test_gpus_mismatch_is_an_error():
     env.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + TINY, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_launcher_deadline_kills_a_hung_job():
+    """A rank that never joins the group: the job is killed at the launcher's deadline and reports rc=124 instead of holding
+    the node (the driver's first multi-GPU run is the first execution of the RCCL path: a hang must be diagnosable)."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-hang-rank", "1", "--deadline", "20",
+                        "--collective-timeout", "600"] + TINY, capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env())
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert "deadline" in r.stderr and time.monotonic() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_collective_timeout_fails_the_job():
+    """Same hang, but the process-group timeout fires first: the waiting rank raises, the launcher stops the sleeper, rc != 0."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-hang-rank", "1", "--deadline", "600",
+                        "--collective-timeout", "10"] + TINY, capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env())
+    assert r.returncode not in (0, 124), (r.returncode, r.stderr[-2000:])
+    assert time.monotonic() - t0 < 200
+
+
+def test_parity_leg_replays_the_first_step():
+    """The line's "parity" object: the CPU leg's warm-up step replays the measured run's first step (same state, clips,
+    permutations) — run here with the checker backend standing in for the GPU."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--selftest-cpu", "--selftest-parity", "--arch", "c3d", "--batch", "4",
+                        "--cpu-sample", "4", "--cpu-steps", "1", "--hw", "32", "--queue", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    p = d["parity"]
+    assert p["ok"] is True and p["loss_rel"] <= 1e-4 and p["logits_rel"] <= 1e-4 and p["features_rel"] <= 1e-4
+    assert p["queue_slab_rel"] <= 1e-4 and p["grad_rel_l2"] <= 1e-2
+    assert d["cpu_baseline"]["value"] > 0 and d["vs_cpu_baseline"] > 0

@@ -1,0 +1,33 @@
+"""GPU: value parity AT THE MEASURED SIZE.  One pretext step of every BASELINE.json workload (configs 2-5: C3D / R3D-18 /
+R(2+1)D at B=32, 3x16x112x112; S3D-G at B=16, 3x16x224x224; K=16384, dim=128) through the HIP kernels, and the same step on the
+oracle restatement (live, on this host's cores: ~20-60 s each) from the SAME seeded state, clips and injected permutations.
+Bar (BASELINE.json north_star): loss / logits / features / queue within 1e-3 relative; gradient-derived tensors at the
+per-architecture whole-step gate (tests/golden_util.py:grad_tol — ReLU / arg-max flips bound it).
+Reference: /root/reference/moco/builder_diffspeed_diffloss.py:492-547, /root/reference/pretrain.py:157-165.
+
+The full-size-only code paths this pins by value: BN reductions over 6.4 M elements per channel, 25 088-tile launches, the
+single-LDS-buffer mode (>= 768 tiles), 49-round grids, 512-tile split-K tails, the K=16384 logits inside a real step."""
+import pytest
+import torch
+
+from full_size_util import FWD_KEYS, step_vs_oracle
+from golden_util import grad_tol
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+# BASELINE.json configs 2-5: (arch, clips per GPU, H = W)
+WORKLOADS = [("c3d", 32, 112), ("resnet18", 32, 112), ("r2plus1d-vcop", 32, 112), ("s3dg", 16, 224)]
+
+
+@pytest.mark.parametrize("arch,B,HW", WORKLOADS, ids=[w[0] for w in WORKLOADS])
+def test_full_size_step_matches_oracle(arch, B, HW):
+    from rspnet_amd import ops
+    assert ops.backend().name == "hip"
+    errs, detail = step_vs_oracle(arch, B, HW, 16384, seed=1, device=torch.device("cuda", 0))
+    print(f"\n{arch} B={B} {HW}x{HW} K=16384 vs oracle: " + ", ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    print("   worst tensors:", detail)
+    for k in FWD_KEYS + ("queue", "bn_running_stats", "encoder_k_params"):
+        assert errs[k] <= TOL, (k, errs[k], detail.get(k))
+    gt = grad_tol(arch)
+    for k in ("grad_worst_tensor", "grad_whole", "momentum_post", "encoder_q_params_post"):
+        assert errs[k] <= gt, (k, errs[k], detail.get(k))
