@@ -305,6 +305,11 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         step()
     be = ops.backend()
     inner = model.module
+    # everything alive now (modules, plans, descriptor caches) is long-lived: move it out of the collector's reach so that a
+    # full collection in the timed region — seen as one 40-75 ms host pause per run — has nothing to scan
+    import gc
+    gc.collect()
+    gc.freeze()
     fence()
     if cuda:
         be.event_log = []
@@ -392,6 +397,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
                            for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "per_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in per_kind.items()},
             "per_kind_ms_per_step": {k: round(v[1] / steps, 3) for k, v in per_kind.items()}}
+    gc.unfreeze()
     # let the next workload start from an empty device
     del model, opt, im_q, im_k, inner
     if cuda:

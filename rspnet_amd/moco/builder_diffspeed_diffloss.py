@@ -276,42 +276,66 @@ class MoCoDiffLossTwoFc(nn.Module):
             sh1, sh2 = msg[1:1 + B * ws], msg[1 + B * ws:]
         return speed, sh1.numpy().astype(np.int64), sh2.numpy().astype(np.int64)
 
-    @torch.no_grad()
-    def _shuffle_exchange(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
-        """First half of a key pass: shuffle-BN's sample exchange (:361-387) under the global permutation `idx`.  The clips
-        are sub-sampled first (each has exactly one destination rank) and travel in ONE all-to-all, issued asynchronously:
-        both key passes' exchanges are started back to back at the top of the step — the permutations are known then — so
-        the second one runs over xGMI under the first key pass's convolutions.  Returns the state `_key_pass` consumes."""
-        be = _ops.backend()
-        rank, ws = _world()
-        B = im.shape[0]
-        dev = im.device
+    @staticmethod
+    def _exchange_plan(idx: np.ndarray, B: int, rank: int, ws: int):
+        """Host arithmetic of one shuffle-BN exchange under the global permutation `idx` (:361-387): which of my clips go
+        where (send order, all-to-all splits), where every global sample ends up (for the un-shuffle) and the position each
+        arriving clip has in the reference's shuffled batch."""
         G = idx.reshape(ws, B)
         owner = G // B
-        handle = None
         if ws == 1:
-            src = torch.from_numpy(idx.astype(np.int32)).to(dev, non_blocking=True)
-            x = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
+            send_src, in_splits, out_splits = idx.astype(np.int32), None, None
         else:
-            send_src, in_splits = [], []
+            parts, in_splits = [], []
             for r in range(ws):
                 mine = G[r][owner[r] == rank] - rank * B
-                send_src.append(mine)
+                parts.append(mine)
                 in_splits.append(int(mine.size))
-            send_src = np.concatenate(send_src).astype(np.int32)
+            send_src = np.concatenate(parts).astype(np.int32)
             out_splits = [int((owner[rank] == s).sum()) for s in range(ws)]
-            src = torch.from_numpy(send_src).to(dev, non_blocking=True)
-            xs = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
-            x = torch.empty_like(xs)
-            handle = dist.all_to_all_single(x, xs, out_splits, in_splits, async_op=True)
         # where does global sample g end up?  rank r = position(g)//B; inside r's batch, clips arrive ordered by
         # source rank, then by their order in G[r]
-        loc = np.empty(B * ws, dtype=np.int64)
+        loc = np.empty(B * ws, dtype=np.int32)
         for r in range(ws):
             order = np.argsort(owner[r], kind="stable")
             loc[G[r][order]] = r * B + np.arange(B)
-        loc_t = torch.from_numpy(loc.astype(np.int32)).to(dev, non_blocking=True)
         arrival = np.argsort(owner[rank], kind="stable") if ws > 1 else np.arange(B)
+        return send_src, loc, in_splits, out_splits, arrival
+
+    @staticmethod
+    def _upload_indices(arrays, dev):
+        """All of a step's host-computed index vectors in ONE pinned staging buffer and ONE asynchronous copy.  (A copy from
+        pageable memory — `torch.from_numpy(a).to(dev)`, or a Python scalar assigned through a tensor index — makes the HIP
+        runtime wait for the stream to drain first: the host then never runs ahead of the GPU and every host hiccup becomes
+        GPU idle time.  The pinned blocks come from torch's caching host allocator, which recycles a block only after the copy
+        that read it has completed.)"""
+        total = sum(int(a.size) for a in arrays)
+        host = torch.empty(total, dtype=torch.int32, pin_memory=(dev.type == "cuda"))
+        hv, off = host.numpy(), 0
+        for a in arrays:
+            hv[off:off + a.size] = a
+            off += a.size
+        d = host.to(dev, non_blocking=True)
+        out, off = [], 0
+        for a in arrays:
+            out.append(d[off:off + a.size])
+            off += a.size
+        return out
+
+    @torch.no_grad()
+    def _shuffle_exchange(self, im: Tensor, step: Tensor, T_out: int, plan, src: Tensor, loc_t: Tensor):
+        """First half of a key pass: shuffle-BN's sample exchange (:361-387).  The clips are sub-sampled first (each has exactly
+        one destination rank) and travel in ONE all-to-all, issued asynchronously: both key passes' exchanges are started back
+        to back at the top of the step — the permutations are known then — so the second one runs over xGMI under the first
+        key pass's convolutions.  Returns the state `_key_pass` consumes."""
+        be = _ops.backend()
+        _, ws = _world()
+        _, _, in_splits, out_splits, arrival = plan
+        handle = None
+        x = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
+        if ws > 1:
+            xs, x = x, torch.empty_like(x)
+            handle = dist.all_to_all_single(x, xs, out_splits, in_splits, async_op=True)
         return x, handle, loc_t, arrival
 
     @torch.no_grad()
@@ -343,7 +367,10 @@ class MoCoDiffLossTwoFc(nn.Module):
 
     def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
         """Key pass with shuffle-BN (:408-419) under the global permutation `idx` (exchange + pass, back to back)."""
-        return self._key_pass(self._shuffle_exchange(im, step, T_out, idx), "k")
+        rank, ws = _world()
+        plan = self._exchange_plan(idx, im.shape[0], rank, ws)
+        src, loc_t = self._upload_indices(plan[:2], im.device)
+        return self._key_pass(self._shuffle_exchange(im, step, T_out, plan, src, loc_t), "k")
 
     def _comm(self, name: str):
         """Context that books the time the compute stream (CPU backends: the host) is stalled by a collective under `name` in
@@ -417,12 +444,15 @@ class MoCoDiffLossTwoFc(nn.Module):
             self._last_draw = (random_indices, speed, sh1, sh2)
             T_real = T // speed
             step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
-            step_q[random_indices[:n1].to(dev)] = 1                      # s1 rows play q,k at normal speed
+            step_q.index_fill_(0, random_indices[:n1], 1)               # s1 rows play q,k at normal speed
             step_kn = (1 + speed) - step_q if speed != 1 else step_q.clone()   # k_negative swaps the speeds
+            rank, ws = _world()
+            plan1, plan2 = self._exchange_plan(sh1, B, rank, ws), self._exchange_plan(sh2, B, rank, ws)
+            src1, loc1, src2, loc2 = self._upload_indices(plan1[:2] + plan2[:2], dev)
             # both shuffle-BN exchanges and the query clips are issued up front (one all-to-all each at > 1 rank: the second
             # one overlaps the first key pass); the key passes keep the reference's order (k_negative first, :445, then k, :512)
-            ex_neg = self._shuffle_exchange(im_k, step_kn, T_real, sh1)
-            ex_k = self._shuffle_exchange(im_k, step_q, T_real, sh2)
+            ex_neg = self._shuffle_exchange(im_k, step_kn, T_real, plan1, src1, loc1)
+            ex_k = self._shuffle_exchange(im_k, step_q, T_real, plan2, src2, loc2)
             src = torch.arange(B, dtype=torch.int32, device=dev)
             x_q = be.clip_gather(im_q, src, step_q, T_real, max(C, INPUT_CHANNEL_PAD))
             kneg_mine, kneg_all, dim = self._key_pass(ex_neg, "kneg")
