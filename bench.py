@@ -357,7 +357,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         res["comm_ms"] = cm
     if log:
         per_kernel, per_kind = {}, {}
-        for kind, f, e0, e1, kernel, nbytes in log:
+        for kind, f, e0, e1, kernel, nbytes, _geom in log:
             ms = e0.elapsed_time(e1)
             for table, key in ((per_kernel, kernel), (per_kind, kind)):
                 a = table.setdefault(key, [0.0, 0.0, 0, 0.0])

@@ -147,7 +147,7 @@ class HipOps:
         self.lib = _lib.load()
         self._ws = {}
         # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name, algorithmic
-        # bytes) per MFMA launch
+        # bytes, geometry) per MFMA launch
         # group, recorded on the stream the kernels run on (torch's current stream).
         self.event_log = None
 
@@ -163,7 +163,7 @@ class HipOps:
         if e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.event_log.append((kind, g.flops, e0, e1, kernel, g.bytes))
+            self.event_log.append((kind, g.flops, e0, e1, kernel, g.bytes, g))
 
     # one grow-only scratch buffer per (device, stream): kernels on one stream are serialised, so they can share it; work issued
     # on different streams (independent branches of a layer graph) must not
