@@ -32,6 +32,9 @@ extern "C" {
 
 const char* rsp_strerror(int code);
 const char* rsp_last_error(void);
+/* Demangled template instance of the FIRST matrix kernel the calling thread's most recent rsp_conv3d_{fwd,dgrad,dgrad_packed,
+ * wgrad} call launched (written by the launcher itself; "" if the call launched none).  Cross-checks rsp_conv3d_kernel_name. */
+const char* rsp_last_conv_kernel(void);
 int rsp_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------

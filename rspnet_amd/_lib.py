@@ -59,6 +59,7 @@ _p = C.c_void_p
 SIGNATURES = {
     "rsp_strerror": (C.c_char_p, [C.c_int]),
     "rsp_last_error": (C.c_char_p, []),
+    "rsp_last_conv_kernel": (C.c_char_p, []),
     "rsp_version": (C.c_int, []),
     "rsp_conv3d_packed_fwd_elems": (_sz, [_PD]),
     "rsp_conv3d_pack_fwd": (C.c_int, [_PD, _p, _p, _p]),
@@ -120,22 +121,23 @@ class RspError(RuntimeError):
     pass
 
 
-def load() -> C.CDLL:
-    """Load the HIP library or raise — there is no fallback path."""
+def load(init_gpu: bool = False) -> C.CDLL:
+    """Load the HIP library or raise — there is no fallback path.  init_gpu=True (what HipOps passes) additionally brings the
+    HIP runtime up through torch; host-only users (descriptor / workspace / kernel-name queries, rsp_fastdiv_check, the ABI
+    tests, build()) get the symbols without the calling process ever initialising the GPU."""
     global _lib
+    if init_gpu:
+        _init_gpu()
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RspError(
             f"{LIB_PATH} not found: build it with rspnet_amd/csrc/build.sh (or __graft_entry__.build()). "
             "rspnet_amd has no CPU or eager fallback.")
-    # Let PyTorch bring up the HIP runtime BEFORE this library (a HIP fat binary linked against libamdhip64) is mapped: loaded
-    # the other way round — library first, runtime initialised later by torch — every launch from the library failed with "no
-    # ROCm-capable device is detected" on the GPU box (observed with build() + smoke() in one process).
+    # Map libamdhip64 through torch first (torch's copy must be the one the process ends up with), WITHOUT initialising the
+    # runtime: importing torch loads it, the runtime itself comes up lazily at the first HIP call.
     try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
+        import torch  # noqa: F401
     except ImportError:
         pass
     lib = C.CDLL(LIB_PATH)
@@ -145,6 +147,22 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_gpu_ready = False
+
+
+def _init_gpu():
+    """Let PyTorch bring up the HIP runtime before the first launch from this library: with the runtime initialised later by
+    torch — library launches first — every launch failed with "no ROCm-capable device is detected" on the GPU box (observed
+    with build() + smoke() in one process)."""
+    global _gpu_ready
+    if _gpu_ready:
+        return
+    import torch
+    if torch.cuda.is_available():      # (without a device every op still raises: HipOps only accepts HIP device tensors)
+        torch.cuda.init()
+        _gpu_ready = True
 
 
 def check(rc: int, what: str):

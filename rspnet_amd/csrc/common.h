@@ -14,6 +14,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define RSP_WAVE 64
 
 void rsp_set_error(const char* msg);
+void rsp_note_reset(void);                    // arm the per-call kernel-name note (errors.hip)
+void rsp_note_kernel(const char* fmt, ...);    // first matrix kernel launched since the last reset
 
 static inline int rsp_check_launch(const char* what) {
   hipError_t e = hipGetLastError();

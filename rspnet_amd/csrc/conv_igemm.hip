@@ -823,6 +823,7 @@ int launch_ks_cfg(const IgemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(p.full_tiles + (p.m_tiles * p.n_tiles - p.full_tiles) * p.splitk);
+  rsp_note_kernel("igemm_ks_kernel<%d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N);
   hipLaunchKernelGGL((igemm_ks_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("igemm_ks_kernel");
 }
@@ -843,6 +844,7 @@ int launch_cfg(const IgemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(p.full_tiles + (p.m_tiles * p.n_tiles - p.full_tiles) * p.splitk);
+  rsp_note_kernel("igemm_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, VEC, MINW);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("igemm_kernel");
 }
@@ -870,6 +872,7 @@ int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     attr_set = true;
   }
+  rsp_note_kernel("igemm_multi_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, VEC, MINW);
   hipLaunchKernelGGL((igemm_multi_kernel<BM, BN, WAVES_M, WAVES_N, VEC, MINW>), dim3(m.start[m.n]), dim3(256), lds, s, m);
   return rsp_check_launch("igemm_multi_kernel");
 }
@@ -1208,6 +1211,7 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   RSP_REQUIRE(desc_ok(d), "rsp_conv3d_fwd: bad descriptor");
   RSP_REQUIRE(x && w_packed && y, "rsp_conv3d_fwd: null pointer");
   RSP_REQUIRE(rsp_aligned16(w_packed), "rsp_conv3d_fwd: packed weight must be 16-byte aligned");
+  rsp_note_reset();
   if (rsp_stem_applicable(d)) return rsp_stem_fwd(d, x, w_packed, bias, y, stat_partials, (hipStream_t)stream);
   IgemmParams p;
   memset(&p, 0, sizeof p);
@@ -1446,6 +1450,7 @@ int rsp_conv3d_dgrad(const rsp_conv3d_desc* d, const float* dy, const float* w_r
   RSP_REQUIRE(desc_ok(d), "rsp_conv3d_dgrad: bad descriptor");
   RSP_REQUIRE(dy && w_ref && dx && workspace, "rsp_conv3d_dgrad: null pointer");
   RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_dgrad: workspace must be 16-byte aligned");
+  rsp_note_reset();
   hipStream_t s = (hipStream_t)stream;
   const int nclass = d->sT * d->sH * d->sW;
   unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
@@ -1482,6 +1487,7 @@ int rsp_conv3d_dgrad_packed(const rsp_conv3d_desc* d, const float* dy, const flo
   RSP_REQUIRE(dy && w_packed && dx, "rsp_conv3d_dgrad_packed: null pointer");
   RSP_REQUIRE(rsp_aligned16(w_packed) && (!workspace || rsp_aligned16(workspace)),
               "rsp_conv3d_dgrad_packed: packed weight / workspace must be 16-byte aligned");
+  rsp_note_reset();
   return dgrad_run(d, dy, w_packed, dx, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

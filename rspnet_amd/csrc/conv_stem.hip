@@ -528,9 +528,11 @@ int launch_stem(const StemParams& p, const StemPlan& pl, hipStream_t s) {
     long long per_cu = (160 * 1024) / (long long)pl.lds;
     per_cu = per_cu > 3 ? 3 : per_cu;                       // <= 170 VGPRs: three waves per SIMD
     const long long grid = pl.tiles < 256 * per_cu ? pl.tiles : 256 * per_cu;
+    rsp_note_kernel("stem_resident_kernel<%d>", G);
     hipLaunchKernelGGL((stem_resident_kernel<G>), dim3((unsigned)grid), dim3(256), pl.lds, s, p);
     return rsp_check_launch("stem_resident_kernel");
   }
+  rsp_note_kernel("stem_kernel<%d>", G);
   hipLaunchKernelGGL((stem_kernel<G>), dim3((unsigned)pl.tiles), dim3(256), pl.lds, s, p);
   return rsp_check_launch("stem_kernel");
 }

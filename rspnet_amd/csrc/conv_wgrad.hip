@@ -531,6 +531,7 @@ int launch_w(const WgradParams& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(p.co_tiles * p.k_tiles, p.splitm);
+  rsp_note_kernel("wgrad_kernel<%d, %d, %d, %d, *>", BM, BN, WAVES_M, WAVES_N);
   hipLaunchKernelGGL((wgrad_kernel<BM, BN, WAVES_M, WAVES_N, VECA, VECB>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("wgrad_kernel");
 }
@@ -545,6 +546,7 @@ int launch_w_dma(const WgradParams& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(p.co_tiles * p.k_tiles, p.splitm);
+  rsp_note_kernel("wgrad_dma_kernel<%d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N);
   hipLaunchKernelGGL((wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("wgrad_dma_kernel");
 }
@@ -694,6 +696,7 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
   RSP_REQUIRE(wdesc_ok(d), "rsp_conv3d_wgrad: bad descriptor");
   RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad: null pointer");
   RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_wgrad: workspace must be 16-byte aligned");
+  rsp_note_reset();
   // problems over disjoint output-channel ranges; dy keeps its row pitch (out_ld), dw / dbias are contiguous per channel
   const WSegs g = wgrad_segments(d);
   const long long per_co = (long long)d->Cin * d->kT * d->kH * d->kW;

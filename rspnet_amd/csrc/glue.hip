@@ -83,9 +83,10 @@ __global__ void rows_gather_kernel(const float* __restrict__ in, const int* __re
 // gradient accumulation at fan-out points of the layer graph (residual / inception branches share an input).
 // op: 0 relu fwd (y = max(a,0)), 1 relu bwd (y = a > 0 ? b : 0), 2 sigmoid fwd, 3 sigmoid bwd (y = b*a*(1-a), a = sigmoid out),
 //     4 accumulate (y = a + b)
+// `y` may alias `a` or `b` at identical indices (the engine accumulates gradients over the fresh operand, ReLU runs in place):
+// no __restrict__ on any of the three — every thread reads index i of the inputs before it writes index i of the output.
 template <int OP>
-__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                                                      long long n) {
+__global__ __launch_bounds__(256) void eltwise_kernel(const float* a, const float* b, float* y, long long n) {
   auto f = [](float u, float v) -> float {
     if (OP == 0) return fmaxf(u, 0.f);
     if (OP == 1) return u > 0.f ? v : 0.f;

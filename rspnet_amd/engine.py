@@ -133,8 +133,8 @@ class PackedWeights:
     the batch at the next rebuild."""
 
     def __init__(self):
-        self._entries = []        # (geometry, which, conv module)
-        self._index = {}          # (id(conv), which, geometry) -> (set number, position)
+        self._entries = []        # (geometry, which, conv module): ONE per distinct packed layout of a conv
+        self._index = {}          # (id(conv), which, layout signature) -> (set number, position)
         self._sets = []
         self._ptrs = []
         self._dirty = True
@@ -147,7 +147,8 @@ class PackedWeights:
         ptrs = [c.weight.data_ptr() for _, _, c in self._entries]
         if len(self._sets) > 1 or ptrs != self._ptrs:      # new members since the last rebuild, or the parameters moved
             self._sets = [be.pack_set([(g, which, c.weight.data) for g, which, c in self._entries])] if self._entries else []
-            self._index = {(id(c), which, g): (0, i) for i, (g, which, c) in enumerate(self._entries)}
+            self._index = {(id(c), which, be.pack_signature(g, which, c.weight.data)): (0, i)
+                           for i, (g, which, c) in enumerate(self._entries)}
             self._ptrs = ptrs
         for ps in self._sets:
             ps.run()
@@ -156,7 +157,9 @@ class PackedWeights:
     def _lookup(self, conv, cg: ConvGeom, which: int):
         if self._dirty:
             self._refresh()
-        key = (id(conv), which, cg)
+        # the packed layout depends on channels / kernel / stride / padding / stem applicability only: every input geometry a
+        # conv is applied to (diff_speed's T_real values, a partial last batch, eval sizes) shares one packed copy
+        key = (id(conv), which, _ops.backend().pack_signature(cg, which, conv.weight.data))
         at = self._index.get(key)
         if at is None:
             ps = _ops.backend().pack_set([(cg, which, conv.weight.data)])

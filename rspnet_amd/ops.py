@@ -96,6 +96,18 @@ def _conv_plan(lib_id, g: "ConvGeom", in_ld, out_ld):
             lib.rsp_conv3d_wgrad_workspace(ref), g.out_dims, names)
 
 
+@functools.lru_cache(maxsize=8192)
+def _pack_signature(g: "ConvGeom", which: int, cout_src: int, cin_src: int):
+    lib = _lib.load()
+    d = g.desc()
+    buf = (_lib.PackJob * 64)()
+    cnt = lib.rsp_conv3d_pack_jobs(C.byref(d), which, cout_src, cin_src, C.c_void_p(1 << 20), C.c_void_p(1 << 30), buf, 64)
+    if cnt < 0:
+        _lib.check(cnt, "rsp_conv3d_pack_jobs")
+    n = (lib.rsp_conv3d_packed_dgrad_elems if which else lib.rsp_conv3d_packed_fwd_elems)(C.byref(d))
+    return (int(n), bytes(buf)[:cnt * C.sizeof(_lib.PackJob)])
+
+
 @functools.lru_cache(maxsize=4096)
 def _pool_plan(lib_id, pg: "PoolGeom", in_ld, out_ld, res_ld):
     lib = _lib.load()
@@ -144,7 +156,7 @@ class HipOps:
     name = "hip"
 
     def __init__(self):
-        self.lib = _lib.load()
+        self.lib = _lib.load(init_gpu=True)
         self._ws = {}
         # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name, algorithmic
         # bytes, geometry) per MFMA launch
@@ -226,6 +238,11 @@ class HipOps:
                                                     _stream()), "rsp_conv3d_dgrad_packed")
         self._log("conv_dgrad", g, e0, names[1])
         return dx
+
+    def pack_signature(self, g: ConvGeom, which: int, w_ref):
+        """Hashable identity of the packed layout `pack_set` would build for (g, which): the library's own job records with the
+        pointers replaced by fixed dummies — equal for every input geometry that shares the layout."""
+        return _pack_signature(g, which, int(w_ref.shape[0]), int(w_ref.shape[1]))
 
     def pack_set(self, entries):
         """entries: list of (ConvGeom, which, w_ref) with which = 0 (forward layout) / 1 (dgrad layouts) and w_ref the LIVE

@@ -334,8 +334,30 @@ def parse_args(argv=None):
         ap.error("-c/--config is required (or --continue with a previous run)")
     args.run_dir = str(resolve_run_dir(args))     # resolved once, before the workers are spawned
     if args.world_size is None:
-        args.world_size = torch.cuda.device_count()
+        args.world_size = visible_gpu_count()
     return args
+
+
+def visible_gpu_count() -> int:
+    """Number of GPUs this launcher would spawn ranks for (the reference asks torch.cuda.device_count(), pretrain.py:318), found
+    WITHOUT touching the HIP runtime in the parent: ranks are fresh child processes and the launcher itself must stay GPU-free
+    (a process that has initialised the GPU must never be re-exec'ed or forked on this platform).  Honours
+    HIP_/ROCR_/CUDA_VISIBLE_DEVICES; otherwise counts the KFD topology nodes that are GPUs (simd_count > 0)."""
+    import glob
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            continue
+    return n
 
 
 def main(argv=None):

@@ -258,6 +258,10 @@ class CpuOps:
     def pack_set(self, entries):
         return _CpuPackSet(entries)
 
+    def pack_signature(self, g, which, w_ref):
+        # checker "layout" = zero-padded reference layout: depends on the channel counts and the kernel only
+        return (which, g.Cin, g.Cout, tuple(g.k), tuple(w_ref.shape))
+
 
 class _CpuPackSet:
     """Checker twin of rspnet_amd.ops.PackSet: the "packed" copy is the zero-padded reference-layout weight."""

@@ -473,3 +473,70 @@ def test_mlp_head_pieces(hip):
     close(hip.l2norm_fwd(r.to(DEV)), CPU.l2norm_fwd(r), 1e-6, "l2norm")
     g = rnd(B, dim, seed=8)
     close(hip.l2norm_bwd(r.to(DEV), g.to(DEV)), CPU.l2norm_bwd(r, g), 2e-5, "l2norm bwd")
+
+
+# the full-size shapes whose dispatch decisions differ: slice-major / tap-major K walk, stem (resident and streaming), odd tiles,
+# column segments, single- and multi-launch strided dgrad, the 343-tap stem on the implicit-GEMM path
+NAME_CASES = [
+    (32, 16, 112, 112, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # C3D conv1: stem_resident
+    (32, 16, 56, 56, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # conv2: tap-major 128x128
+    (32, 4, 14, 14, 512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # conv4b: slice-major
+    (32, 16, 112, 112, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),       # R3D stem
+    (32, 8, 28, 28, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),        # strided: dgrad parity classes in one launch
+    (32, 2, 7, 7, 256, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1)),         # strided, few tiles: per-class launches
+    (32, 16, 56, 56, 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # R(2+1)D: column segments
+    (32, 16, 56, 56, 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (16, 16, 224, 224, 4, 64, (1, 7, 7), (2, 2, 2), (0, 3, 3)),       # S3D-G stem (streaming stem kernel)
+    (16, 8, 28, 28, 192, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # 96-wide tile
+    (16, 4, 14, 14, 160, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # dgrad N = 160
+]
+
+
+@pytest.mark.parametrize("case", NAME_CASES, ids=lambda c: "x".join(map(str, c[:6])) + f"k{c[6]}s{c[7]}")
+def test_reported_kernel_name_is_the_kernel_that_ran(hip, case):
+    """rsp_conv3d_kernel_name (what bench.py labels its roofline block and the traffic lookup with) re-derives the dispatch
+    decision; the launchers record the instance they actually started (rsp_last_conv_kernel).  The two must agree for forward,
+    dgrad and wgrad of every dispatch family."""
+    import ctypes as C
+    N, D, H, W, cin, cout, k, s, p = case
+    g = ConvGeom(N, D, H, W, cin, cout, k, s, p)
+    d = g.desc()
+    lib = hip.lib
+    want = [lib.rsp_conv3d_kernel_name(C.byref(d), which).decode() for which in (0, 1, 2)]
+    x = torch.randn(N, D, H, W, cin, device=DEV)
+    w = torch.randn(cout, cin, *k, device=DEV) * 0.05
+    y, _ = hip.conv_fwd(g, x, hip.conv_pack_fwd(g, w), None, True)
+    assert lib.rsp_last_conv_kernel().decode() == want[0], ("fwd", want[0])
+    dy = torch.randn_like(y)
+    if cin > 4:
+        ps = hip.pack_set([(g, 1, w)])
+        ps.run()
+        hip.conv_dgrad_packed(g, dy, ps.packed[0])
+        assert lib.rsp_last_conv_kernel().decode() == want[1], ("dgrad", want[1])
+    hip.conv_wgrad(g, x, dy, torch.empty_like(w))
+    assert lib.rsp_last_conv_kernel().decode() == want[2], ("wgrad", want[2])
+
+
+def test_packed_weights_are_shared_across_input_geometries(hip):
+    """One packed copy per (conv, layout): the T_real values of diff_speed=[4,2,1], a partial batch or another clip size must
+    not add copies (rspnet_amd/engine.py PackedWeights keys on the layout signature, not on N/D/H/W)."""
+    from golden_util import load_spec
+    from model_util import make_cfg
+    from oracle import portable as P
+    from rspnet_amd.moco import ModelFactory
+    model = ModelFactory(make_cfg("c3d", 64)).build_moco_diffloss(device=DEV).module
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.fill_state(load_spec("c3d"), 5).items()})
+    enc = model.encoder_q
+    outs = {}
+    for T, HW, B in ((16, 32, 4), (8, 32, 4), (16, 48, 2), (32, 32, 3)):
+        x = torch.from_numpy(P.clips(5, 0, (B, 3, T, HW, HW))[0]).to(DEV)
+        a, m = enc(x)
+        outs[(T, HW, B)] = a
+        n_entries = len(enc._packed._entries)
+        if len(outs) == 1:
+            first = n_entries
+        assert n_entries == first, (T, HW, B, n_entries, first)
+    # same clips again through the shared copies: identical result
+    x = torch.from_numpy(P.clips(5, 0, (4, 3, 16, 32, 32))[0]).to(DEV)
+    a2, _ = enc(x)
+    assert torch.equal(a2, outs[(16, 32, 4)])

@@ -49,3 +49,11 @@ def test_pretrain_with_uint8_loader_and_fused_augmentation(tmp_path):
     from rspnet_amd.pretrain import main_worker
     stats = main_worker(0, _args(tmp_path, loader="uint8"), "")
     assert stats["loss"] == stats["loss"] and 0 < stats["loss"] < 50 and stats["clips_per_s"] > 0
+
+
+def test_launcher_counts_gpus_without_touching_the_runtime():
+    """pretrain.py's parent decides the world size from sysfs / *_VISIBLE_DEVICES (the launcher must stay GPU-free); on this box
+    it must agree with what the HIP runtime reports."""
+    import torch
+    from rspnet_amd.pretrain import visible_gpu_count
+    assert visible_gpu_count() == torch.cuda.device_count() >= 1

@@ -27,7 +27,7 @@ def _worker(rank, ws, arch, seed, port, tmp):
     from rspnet_amd import ops
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC, see DESIGN.md §6 "Environment"
     torch.cuda.set_device(rank)
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=dev)
@@ -44,7 +44,8 @@ def _worker(rank, ws, arch, seed, port, tmp):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
-@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "c3d:linear:4", "resnet18") for a, w, s in cases_for(arch, 2)][:3])
+@pytest.mark.parametrize("arch,seed", [(a, s) for arch in ("c3d", "c3d:linear:4", "resnet18", "r2plus1d-vcop", "s3dg")
+                                       for a, w, s in cases_for(arch, 2)])
 def test_two_ranks_over_rccl_match_the_ddp_fixture(arch, seed):
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:
