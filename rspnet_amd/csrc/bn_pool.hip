@@ -840,7 +840,11 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
   int rc = rsp_check_launch("bn_bwd_reduce_kernel");
   if (rc != RSP_OK) return rc;
   const bool exact = d->Di % d->sT == 0 && d->Hi % d->sH == 0 && d->Wi % d->sW == 0 && d->kT * d->kH * d->kW <= 8;
-  if (exact && p.nblocks <= 512) {   // small layer: the apply kernel reduces the few partial rows itself (no finalize launch)
+  bool fuse_bwd = exact && p.nblocks <= 512;
+#ifdef RSP_TUNE
+  if (getenv("RSP_NO_FUSED_BN")) fuse_bwd = false;
+#endif
+  if (fuse_bwd) {   // small layer: the apply kernel reduces the few partial rows itself (no finalize launch)
     p.dgamma = dgamma; p.dbeta = dbeta;
     if (vec) hipLaunchKernelGGL((bn_bwd_apply_win_kernel<4, true>), L.grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((bn_bwd_apply_win_kernel<1, true>), L.grid, dim3(256), 0, s, p);

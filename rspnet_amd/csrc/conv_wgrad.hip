@@ -30,7 +30,6 @@ struct WgradParams {
   int K, Kld;
   int rows_per_split, splitm;
   int co_tiles, k_tiles;
-  int team, tps, nteams;           // XCD teams (wgrad_unit): tiles per team, teams per slab, teams in all
   const float* __restrict__ zero;  // >= 64 B of zeros
   unsigned x_bytes, dy_bytes;      // extents for the buffer descriptors of the DMA variant
   const uint2* __restrict__ rowgeom;  // [M] row geometry (DMA variant)
@@ -40,24 +39,23 @@ struct WgradParams {
 // Workgroup -> (slab, tile).  Every (co, k) tile of a row slab reads the slab's dy rows, and tiles of neighbouring taps read the
 // same x rows; launched as a (tiles, slabs) grid the tiles of one slab were dealt round-robin over the 8 XCDs, so each XCD's L2
 // fetched the whole slab for itself and the launch left 7-9x its algorithmic bytes at the L2s (conv2: 11.7 GB for 1.23 GB).
-// The grid is now 1-D and dealt in TEAMS: workgroup L runs on XCD L % 8 (round-robin dispatch), the j = L / 8 -th workgroup of
-// an XCD is member j % team of that XCD's (j / team)-th team, and a team is `team` consecutive tiles (co-major: same dy
-// columns, neighbouring taps) of ONE slab — co-resident on one XCD and advancing chunk by chunk together, so the slab's dy
-// and x rows come through that L2 once.  A slab with more tiles than an XCD has slots is cut into `tps` teams.  Grid padding
-// (team index or tile index past the end) exits at once.
+// The grid is now 1-D over the slab-major unit list u = slab * tiles + tile (tile co-major: same dy columns, neighbouring taps)
+// and every XCD walks ONE contiguous chunk of that list (rsp_xcd_remap: workgroup L runs on XCD L % 8): the workgroups an XCD
+// has in flight at any time are consecutive tiles of the same slab, advancing chunk by chunk together, so the slab's dy and x
+// rows come through that L2 once.  Every XCD gets the same number of units (+-1) whatever the tile count — a first version that
+// dealt whole per-slab teams to the XCDs cost up to 25 % on layers whose tile count does not divide the XCD's slots.
 struct WUnit {
   int z, tile;
-  bool live;
 };
-__device__ __forceinline__ WUnit wgrad_unit(int L, int team, int tps, int nteams, int tiles) {
-  const int xcd = L & 7, j = L >> 3;
-  const int q = j / team, member = j - q * team;
-  const int t = q * 8 + xcd;
-  WUnit u;
-  u.z = t / tps;
-  u.tile = (t - u.z * tps) * team + member;
-  u.live = t < nteams && u.tile < tiles;
-  return u;
+__device__ __forceinline__ WUnit wgrad_unit(int L, int nwg, int tiles, int tune) {
+  int u = rsp_xcd_remap(L, nwg);
+#ifdef RSP_TUNE
+  if (tune & 8192) u = L;      // A/B: the round-robin deal
+#endif
+  WUnit w;
+  w.z = u / tiles;
+  w.tile = u - w.z * tiles;
+  return w;
 }
 
 struct RowPos {
@@ -97,8 +95,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const WUnit unit = wgrad_unit(blockIdx.x, p.team, p.tps, p.nteams, p.co_tiles * p.k_tiles);
-  if (!unit.live) return;
+  const WUnit unit = wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles, p.tune);
   const int tile = unit.tile;
   const int co_tile = tile / p.k_tiles, k_tile = tile - co_tile * p.k_tiles;
   const int co0 = co_tile * BM, k0 = k_tile * BN;
@@ -349,8 +346,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const WUnit unit = wgrad_unit(blockIdx.x, p.team, p.tps, p.nteams, p.co_tiles * p.k_tiles);
-  if (!unit.live) return;
+  const WUnit unit = wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles, p.tune);
   const int tile = unit.tile;
   const int co_tile = tile / p.k_tiles, k_tile = tile - co_tile * p.k_tiles;
   const int co0 = co_tile * BM, k0 = k_tile * BN;
@@ -558,7 +554,7 @@ int launch_w(const WgradParams& p, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid((unsigned)rsp_cdiv(p.nteams, 8) * 8u * (unsigned)p.team);
+  dim3 grid((unsigned)(p.co_tiles * p.k_tiles) * (unsigned)p.splitm);
   rsp_note_kernel("wgrad_kernel<%d, %d, %d, %d, *>", BM, BN, WAVES_M, WAVES_N);
   hipLaunchKernelGGL((wgrad_kernel<BM, BN, WAVES_M, WAVES_N, VECA, VECB>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("wgrad_kernel");
@@ -573,7 +569,7 @@ int launch_w_dma(const WgradParams& p, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid((unsigned)rsp_cdiv(p.nteams, 8) * 8u * (unsigned)p.team);
+  dim3 grid((unsigned)(p.co_tiles * p.k_tiles) * (unsigned)p.splitm);
   rsp_note_kernel("wgrad_dma_kernel<%d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N);
   hipLaunchKernelGGL((wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("wgrad_dma_kernel");
@@ -603,7 +599,6 @@ bool wdesc_ok(const rsp_conv3d_desc* d) {
 
 struct WPlan {
   int bm, bn, co_tiles, k_tiles, splitm, rows_per_split, Kld;
-  int team, tps;      // tiles per XCD team, teams per slab (wgrad_unit)
   size_t partial_bytes, colsum_bytes, rowgeom_bytes;
 };
 
@@ -618,21 +613,14 @@ WPlan wplan(const rsp_conv3d_desc* d) {
   w.co_tiles = rsp_cdiv(d->Cout, w.bm);
   w.k_tiles = rsp_cdiv(K, w.bn);
   const int tiles = w.co_tiles * w.k_tiles;
-  // Split the rows into `sp` slabs so that the units fill whole rounds of the resident workgroups (2 per CU for 128x128): a few
-  // stragglers spilling into an extra round cost ~15% (measured: conv2 6.4 -> 5.4 ms), a last round that is 84% full costs the
-  // missing 16%.  Utilisation first, then fewer rounds (longer units amortise the 64 KB partial write better).  Units are dealt
-  // to the XCDs in teams (wgrad_unit), so the rounds are counted per XCD: the busiest one holds ceil(teams / 8) teams.
+  // Split the rows into `sp` slabs so that the tiles*sp units fill whole rounds of the resident workgroups (512 = 2 per CU for 128x128):
+  // a few stragglers spilling into an extra round cost ~15% (measured: conv2 6.4 -> 5.4 ms), a last round that is 84% full
+  // costs the missing 16%.  Utilisation first, then fewer rounds (longer units amortise the 64 KB partial write better).
   const long long max_sp = M / 256 > 0 ? M / 256 : 1;
   long long sp = 1;
   {
     const long long lds = 2ll * RK * (w.bm + w.bn) * 4 + 1024;
-    const long long slots = 32 * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);   // per XCD; 128x128: 2 per CU, 64x128: 3, 64x64: 4
-    long long cap = slots;
-#ifdef RSP_TUNE
-    if (const char* e = getenv("RSP_WTEAM")) cap = atoi(e) > 0 ? atoi(e) : 1;   // A/B: 1 = the flat (tile, slab) deal
-#endif
-    w.tps = rsp_cdiv(tiles, cap < slots ? cap : slots);
-    w.team = rsp_cdiv(tiles, w.tps);
+    const long long slots = 256 * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);   // 128x128: 2 per CU, 64x128: 3, 64x64: 4
     double best = -1.0;
 #ifdef RSP_TUNE
     const char* e = getenv("RSP_WUNITS");
@@ -641,8 +629,8 @@ WPlan wplan(const rsp_conv3d_desc* d) {
 #else
     for (long long c = 1; c <= max_sp && c * tiles <= 8192; ++c) {
 #endif
-      const long long teams = c * w.tps, per_xcd = (teams + 7) / 8 * w.team, rounds = (per_xcd + slots - 1) / slots;
-      const double score = (double)(c * tiles) / (double)(rounds * slots * 8) - 0.004 * (double)rounds;
+      const long long units = c * tiles, rounds = (units + slots - 1) / slots;
+      const double score = (double)units / (double)(rounds * slots) - 0.004 * (double)rounds;
       if (score > best) {
         best = score;
         sp = c;
@@ -787,7 +775,6 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
   p.Kld = w.Kld;
   p.rows_per_split = w.rows_per_split; p.splitm = w.splitm;
   p.co_tiles = w.co_tiles; p.k_tiles = w.k_tiles;
-  p.team = w.team; p.tps = w.tps; p.nteams = w.splitm * w.tps;
   const bool va = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy);
   const bool vb = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x);
   const unsigned long long xb = (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;

@@ -167,6 +167,9 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load(init_gpu=True)
         self._fused_tiles = int(self.lib.rsp_bn_fused_max_tiles())
+        import os
+        if os.environ.get("RSP_NO_FUSED_BN"):          # A/B switch for tools/ only (ablation runs)
+            self._fused_tiles = 0
         self._ws = {}
         # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name, algorithmic
         # bytes, geometry) per MFMA launch
