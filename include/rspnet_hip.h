@@ -146,16 +146,6 @@ typedef struct rsp_pool3d_desc {
 int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
                         int relu, float* out, void* stream);
 
-/* rsp_bn_finalize + rsp_bn_act_pool_fwd in ONE launch for small layers (tiles <= rsp_bn_fused_max_tiles()): every workgroup
- * reduces the stat partials of its own channels, workgroup 0 also writes mean_invstd / scale_shift and moves the running
- * statistics.  Same arguments and results as the two calls (models/s3dg.py:23,28-33 runs 231 BatchNorm forwards per step, most
- * of them over < 100 stat tiles; models/resnet.py:61-77 layers 2-4). */
-int32_t rsp_bn_fused_max_tiles(void);
-int rsp_bn_finalize_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* stat_partials, int32_t tiles,
-                                 int32_t stat_ld, int64_t count, const float* conv_bias, const float* gamma, const float* beta,
-                                 float eps, float momentum, float* running_mean, float* running_var, float* mean_invstd,
-                                 float* scale_shift, const float* residual, int relu, float* out, void* stream);
-
 /* Backward of the fused block, two launches:
  *  reduce: per-channel partial sums of dz and dz*xhat (dz = grad at the BN output after pool routing + ReLU mask)
  *  apply : dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also d(residual) = dz (if dres != NULL),

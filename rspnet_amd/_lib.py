@@ -81,8 +81,6 @@ SIGNATURES = {
     "rsp_bn_stat_tiles": (_i32, [_i64]),
     "rsp_bn_stats": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "rsp_bn_act_pool_fwd": (C.c_int, [_PP, _p, _p, _p, C.c_int, _p, _p]),
-    "rsp_bn_fused_max_tiles": (_i32, []),
-    "rsp_bn_finalize_act_pool_fwd": (C.c_int, [_PP, _p, _p, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, C.c_int, _p, _p]),
     "rsp_bn_bwd_workspace": (_sz, [_PP]),
     "rsp_bn_act_pool_bwd": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_maxpool3d_fwd": (C.c_int, [_PP, _p, _p, _p, _p]),

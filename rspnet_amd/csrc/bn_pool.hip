@@ -158,18 +158,6 @@ struct PoolParams {
   int cgc, ppi;
   long long npos;            // output positions (< 2^31)
   FastDiv dcgc, dWo, dHo, dDo;
-  // fused finalize (bn_act_pool_fwd_kernel<VEC, true>): the conv epilogue's stat partials and what bn_finalize would take
-  const float* __restrict__ part;   // [tiles][stat_ld][2]
-  int tiles, stat_ld;
-  long long count;
-  const float* __restrict__ conv_bias;
-  const float* __restrict__ gamma;
-  const float* __restrict__ beta;
-  float eps, momentum;
-  float* __restrict__ running_mean;
-  float* __restrict__ running_var;
-  float* __restrict__ mi_out;       // [2][C]
-  float* __restrict__ ss_out;       // [2][C]
 };
 
 // Every thread keeps ONE channel group for its whole life (per-channel constants are loaded once) and walks output positions;
@@ -213,77 +201,17 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   }
 }
 
-// FUSED: small layers (few stat tiles) skip the separate finalize launch — every workgroup reduces the [tiles][C][2] partials for
-// its own channel groups (the `ppi` position lanes of a channel group split the tiles, fp64, fixed order -> every workgroup gets
-// the same bits), derives scale / shift exactly as bn_finalize does, and workgroup x = 0 also writes mean / invstd / scale / shift
-// and moves the running statistics.  S3D-G runs 231 BatchNorm forwards per step, most of them over < 100 tiles: the finalize
-// launches were ~7.6 us each of pure launch latency.
-template <int VEC, bool FUSED>
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p) {
   const rsp_pool3d_desc& d = p.d;
   const int t = threadIdx.x;
   const int pl = fastdiv(t, p.dcgc);
   const int cgi = blockIdx.y * 256 + (t - pl * p.cgc);
-  float sc[VEC], sh[VEC];
-  if (FUSED) {
-    __shared__ double red[256][2 * VEC];
-    const bool live = pl < p.ppi && cgi < p.cg;
-    const int c0 = cgi * VEC;
-    double a[2 * VEC];
-#pragma unroll
-    for (int e = 0; e < 2 * VEC; ++e) a[e] = 0.0;
-    if (live)
-      for (int tt = pl; tt < p.tiles; tt += p.ppi) {
-        const float* src = p.part + ((long long)tt * p.stat_ld + c0) * 2;
-        if (VEC == 4) {
-          const floatx4 u = *reinterpret_cast<const floatx4*>(src), v = *reinterpret_cast<const floatx4*>(src + 4);
-          a[0] += (double)u[0]; a[1] += (double)u[1]; a[2] += (double)u[2]; a[3] += (double)u[3];
-          a[4] += (double)v[0]; a[5] += (double)v[1]; a[6] += (double)v[2]; a[7] += (double)v[3];
-        } else {
-          a[0] += (double)src[0];
-          a[1] += (double)src[1];
-        }
-      }
-#pragma unroll
-    for (int e = 0; e < 2 * VEC; ++e) red[t][e] = a[e];
-    __syncthreads();
-    if (!live) return;
-    const int slot = t - pl * p.cgc;
-    const double n = (double)p.count;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      double s = 0.0, ss = 0.0;
-      for (int l = 0; l < p.ppi; ++l) {
-        s += red[l * p.cgc + slot][2 * e];
-        ss += red[l * p.cgc + slot][2 * e + 1];
-      }
-      const int c = c0 + e;
-      const double mean0 = s / n;                   // mean of the bias-free conv output
-      double var = ss / n - mean0 * mean0;          // biased
-      var = var > 0.0 ? var : 0.0;
-      const double mean = mean0 + (p.conv_bias ? (double)p.conv_bias[c] : 0.0);
-      const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
-      const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
-      sc[e] = g * invstd;
-      sh[e] = b - (float)mean * sc[e];
-      if (blockIdx.x == 0 && pl == 0) {
-        p.mi_out[c] = (float)mean;
-        p.mi_out[d.C + c] = invstd;
-        p.ss_out[c] = sc[e];
-        p.ss_out[d.C + c] = sh[e];
-        if (p.running_mean) p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
-        if (p.running_var) {
-          const double unbiased = p.count > 1 ? var * n / (n - 1.0) : var;
-          p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
-        }
-      }
-    }
-  } else {
-    if (pl >= p.ppi || cgi >= p.cg) return;
-    load_vec<VEC>(p.ss + cgi * VEC, sc);
-    load_vec<VEC>(p.ss + d.C + cgi * VEC, sh);
-  }
+  if (pl >= p.ppi || cgi >= p.cg) return;
   const int c = cgi * VEC;
+  float sc[VEC], sh[VEC];
+  load_vec<VEC>(p.ss + c, sc);
+  load_vec<VEC>(p.ss + d.C + c, sh);
   const bool unit = d.kT * d.kH * d.kW == 1 && d.sT == 1 && d.sH == 1 && d.sW == 1 && !(d.pT | d.pH | d.pW);   // no pooling
   for (long long o = (long long)blockIdx.x * p.ppi + pl; o < p.npos; o += (long long)gridDim.x * p.ppi) {
     float best[VEC];
@@ -355,8 +283,6 @@ struct BwdParams {
   int cgc, ppi;     // thread layout of the apply kernels (see Layout)
   long long npos;
   FastDiv dcgc, dWo, dHo, dDo;
-  float* __restrict__ dgamma;      // fused finalize (bn_bwd_apply_win_kernel<VEC, true>): written by workgroup x = 0
-  float* __restrict__ dbeta;
 };
 
 // z of one input position (post affine + residual), VEC channels
@@ -553,61 +479,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
 // pass 2, output-centric fast path: windows tile the input exactly (Di % sT == 0 ...) and hold <= 8 positions, so one
 // thread owns a whole window: every y element is read once and every dy element written once (the input-centric
 // kernel above re-reads the window for every element).
-// FUSED: few reduce blocks (small layers) — the finalize launch is folded in: every workgroup sums the reduce kernel's
-// [nblocks][C][2] partials for its own channel groups (position lanes split the rows, fp64, fixed order), workgroup x = 0 writes
-// dgamma / dbeta.
-template <int VEC, bool FUSED>
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p) {
   const rsp_pool3d_desc& d = p.d;
   const int t = threadIdx.x;
   const int pl = fastdiv(t, p.dcgc);
   const int cgi = blockIdx.y * 256 + (t - pl * p.cgc);
+  if (pl >= p.ppi || cgi >= p.cg) return;
   const int c = cgi * VEC;
-  const double invn = 1.0 / (double)p.count;
-  float m1[VEC], m2[VEC];
-  if (FUSED) {
-    __shared__ double red[256][2 * VEC];
-    const bool live = pl < p.ppi && cgi < p.cg;
-    double a[2 * VEC];
-#pragma unroll
-    for (int e = 0; e < 2 * VEC; ++e) a[e] = 0.0;
-    if (live)
-      for (int i = pl; i < p.nblocks; i += p.ppi) {
-        const float* src = p.partial + ((long long)i * d.C + c) * 2;
-#pragma unroll
-        for (int e = 0; e < 2 * VEC; ++e) a[e] += (double)src[e];
-      }
-#pragma unroll
-    for (int e = 0; e < 2 * VEC; ++e) red[t][e] = a[e];
-    __syncthreads();
-    if (!live) return;
-    const int slot = t - pl * p.cgc;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int l = 0; l < p.ppi; ++l) {
-        s1 += red[l * p.cgc + slot][2 * e];
-        s2 += red[l * p.cgc + slot][2 * e + 1];
-      }
-      m1[e] = (float)(s1 * invn);
-      m2[e] = (float)(s2 * invn);
-      if (blockIdx.x == 0 && pl == 0) {
-        if (p.dbeta) p.dbeta[c + e] = (float)s1;
-        if (p.dgamma) p.dgamma[c + e] = (float)s2;
-      }
-    }
-  } else {
-    if (pl >= p.ppi || cgi >= p.cg) return;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      m1[e] = (float)(p.sums[2 * (c + e)] * invn);
-      m2[e] = (float)(p.sums[2 * (c + e) + 1] * invn);
-    }
-  }
   const int nwin = d.kT * d.kH * d.kW;
   // per-channel constants, once per thread: dy = k1 * dz + k2 * y + k3 with
   //   k1 = gamma*invstd, k2 = -k1*invstd*m2, k3 = -k1*(m1 - mean*invstd*m2)       (m1 = mean dz, m2 = mean dz*xhat)
-  float sc[VEC], sh[VEC], mean[VEC], invstd[VEC], gam[VEC];
+  float sc[VEC], sh[VEC], mean[VEC], invstd[VEC], gam[VEC], m1[VEC], m2[VEC];
   load_vec<VEC>(p.ss + c, sc);
   load_vec<VEC>(p.ss + d.C + c, sh);
   load_vec<VEC>(p.mi + c, mean);
@@ -616,6 +499,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p
   else {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) gam[e] = 1.f;
+  }
+  const double invn = 1.0 / (double)p.count;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    m1[e] = (float)(p.sums[2 * (c + e)] * invn);
+    m2[e] = (float)(p.sums[2 * (c + e) + 1] * invn);
   }
   for (long long o = (long long)blockIdx.x * p.ppi + pl; o < p.npos; o += (long long)gridDim.x * p.ppi) {
     float g[VEC];
@@ -758,7 +647,6 @@ int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* s
   RSP_REQUIRE(pool_ok(d, false), "rsp_bn_act_pool_fwd: bad descriptor");
   RSP_REQUIRE(y && scale_shift && out, "rsp_bn_act_pool_fwd: null pointer");
   PoolParams p;
-  memset(&p, 0, sizeof p);
   p.d = *d; p.y = y; p.ss = scale_shift; p.res = residual; p.out = out; p.relu = relu;
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(out) &&
                    rsp_aligned16(scale_shift) && (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual)));
@@ -766,38 +654,9 @@ int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* s
   const Layout L = make_layout(d, p.cg, 4);
   RSP_REQUIRE(L.npos < (1ll << 31), "rsp_bn_act_pool_fwd: more than 2^31 - 1 output positions");
   p.cgc = L.cgc; p.ppi = L.ppi; p.npos = L.npos; p.dcgc = L.dcgc; p.dWo = L.dWo; p.dHo = L.dHo; p.dDo = L.dDo;
-  if (vec) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<4, false>), L.grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((bn_act_pool_fwd_kernel<1, false>), L.grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (vec) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<4>, L.grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<1>, L.grid, dim3(256), 0, (hipStream_t)stream, p);
   return rsp_check_launch("bn_act_pool_fwd_kernel");
-}
-
-// BatchNorm forward of a SMALL layer in one launch: rsp_bn_finalize + rsp_bn_act_pool_fwd fused (bn_act_pool_fwd_kernel<VEC, true>).
-// Same arguments, same results (scale / shift / mean / invstd / running statistics / activation) up to fp64 summation order.
-int32_t rsp_bn_fused_max_tiles(void) { return 256; }
-
-int rsp_bn_finalize_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* stat_partials, int32_t tiles,
-                                 int32_t stat_ld, int64_t count, const float* conv_bias, const float* gamma, const float* beta,
-                                 float eps, float momentum, float* running_mean, float* running_var, float* mean_invstd,
-                                 float* scale_shift, const float* residual, int relu, float* out, void* stream) {
-  RSP_REQUIRE(pool_ok(d, false), "rsp_bn_finalize_act_pool_fwd: bad descriptor");
-  RSP_REQUIRE(y && stat_partials && mean_invstd && scale_shift && out, "rsp_bn_finalize_act_pool_fwd: null pointer");
-  RSP_REQUIRE(tiles > 0 && tiles <= rsp_bn_fused_max_tiles() && count > 0 && stat_ld >= d->C,
-              "rsp_bn_finalize_act_pool_fwd: bad size (more than rsp_bn_fused_max_tiles() stat tiles take the two-call path)");
-  PoolParams p;
-  memset(&p, 0, sizeof p);
-  p.d = *d; p.y = y; p.ss = nullptr; p.res = residual; p.out = out; p.relu = relu;
-  const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && stat_ld % 2 == 0 && rsp_aligned16(y) &&
-                   rsp_aligned16(out) && rsp_aligned16(stat_partials) && (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual)));
-  p.cg = vec ? d->C / 4 : d->C;
-  const Layout L = make_layout(d, p.cg, 4);
-  RSP_REQUIRE(L.npos < (1ll << 31), "rsp_bn_finalize_act_pool_fwd: more than 2^31 - 1 output positions");
-  p.cgc = L.cgc; p.ppi = L.ppi; p.npos = L.npos; p.dcgc = L.dcgc; p.dWo = L.dWo; p.dHo = L.dHo; p.dDo = L.dDo;
-  p.part = stat_partials; p.tiles = tiles; p.stat_ld = stat_ld; p.count = count; p.conv_bias = conv_bias; p.gamma = gamma;
-  p.beta = beta; p.eps = eps; p.momentum = momentum; p.running_mean = running_mean; p.running_var = running_var;
-  p.mi_out = mean_invstd; p.ss_out = scale_shift;
-  if (vec) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<4, true>), L.grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((bn_act_pool_fwd_kernel<1, true>), L.grid, dim3(256), 0, (hipStream_t)stream, p);
-  return rsp_check_launch("bn_act_pool_fwd_kernel<fused>");
 }
 
 size_t rsp_bn_bwd_workspace(const rsp_pool3d_desc* d) {
@@ -839,24 +698,14 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, rgrid, dim3(256), 0, s, p);
   int rc = rsp_check_launch("bn_bwd_reduce_kernel");
   if (rc != RSP_OK) return rc;
-  const bool exact = d->Di % d->sT == 0 && d->Hi % d->sH == 0 && d->Wi % d->sW == 0 && d->kT * d->kH * d->kW <= 8;
-  bool fuse_bwd = exact && p.nblocks <= 512;
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_FUSED_BN")) fuse_bwd = false;
-#endif
-  if (fuse_bwd) {   // small layer: the apply kernel reduces the few partial rows itself (no finalize launch)
-    p.dgamma = dgamma; p.dbeta = dbeta;
-    if (vec) hipLaunchKernelGGL((bn_bwd_apply_win_kernel<4, true>), L.grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((bn_bwd_apply_win_kernel<1, true>), L.grid, dim3(256), 0, s, p);
-    return rsp_check_launch("bn_bwd_apply_win_kernel<fused>");
-  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, 64)), dim3(1024), 0, s, p.partial, p.nblocks, d->C, sums,
                      dgamma, dbeta);
   rc = rsp_check_launch("bn_bwd_finalize_kernel");
   if (rc != RSP_OK) return rc;
+  const bool exact = d->Di % d->sT == 0 && d->Hi % d->sH == 0 && d->Wi % d->sW == 0 && d->kT * d->kH * d->kW <= 8;
   if (exact) {
-    if (vec) hipLaunchKernelGGL((bn_bwd_apply_win_kernel<4, false>), L.grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((bn_bwd_apply_win_kernel<1, false>), L.grid, dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, L.grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, L.grid, dim3(256), 0, s, p);
     return rsp_check_launch("bn_bwd_apply_win_kernel");
   }
   const long long total = (long long)d->N * d->Di * d->Hi * d->Wi * p.cg;

@@ -238,26 +238,17 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
     assert training or not keep, "eval-mode forward keeps nothing for backward"
     slots: Dict[int, torch.Tensor] = {plan.input_slot: x}
     ctx = ForwardCtx(packed=packed) if keep else None
-    def bn_apply(node, y, ss, cg_cout, N, do, ho, wo, xin, fuse=None):
-        """BN apply (+ residual, ReLU, pool) into the node's destination.  fuse = (stats, rows, bias, bn): a small layer's
-        finalize rides in the same launch; returns (pool geometry, residual, mean_invstd, scale_shift)."""
+    def bn_apply(node, y, ss, cg_cout, N, do, ho, wo, xin):
         pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
         pg = PoolGeom(N, do, ho, wo, cg_cout, pk, ps, (0, 0, 0))
         res = slots[node.residual] if node.residual is not None else None
-        out = None
         if node.into is not None:
             pdo, pho, pwo = pg.out_dims
             out = _view(_slice_of(slots, node.into, (N, pdo, pho, pwo), xin.device), node.into, cg_cout)
-        mi = None
-        if fuse is not None:
-            stats, rows, bias_d, bn = fuse
-            mi, ss, o = be.bn_fwd_fused(pg, y, stats, rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum),
-                                        bn.running_mean, bn.running_var, res, node.relu, out=out)
+            be.bn_act_pool_fwd(pg, y, ss, res, node.relu, out=out)
         else:
-            o = be.bn_act_pool_fwd(pg, y, ss, res, node.relu, out=out)
-        if node.into is None:
-            slots[node.dst] = o
-        return pg, res, mi, ss
+            slots[node.dst] = be.bn_act_pool_fwd(pg, y, ss, res, node.relu)
+        return pg, res
 
     def convbn(node, key):
         xin = slots[node.src]
@@ -269,13 +260,9 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         bias = getattr(node.conv, "bias", None)
         bn = node.bn
         bias_d = None if bias is None else (bias.data if Cp == Cout else _pad_vec(bias.data, Cp))
-        fuse = None
         if training:
             y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_d, True)
-            if Cp == Cout and be.bn_fwd_fused_ok(stats, cg.rows):
-                fuse = (stats, cg.rows, bias_d, bn)          # small layer: finalize + apply in one launch (below)
-                mi = ss = None
-            elif Cp == Cout:
+            if Cp == Cout:
                 mi, ss = be.bn_finalize(stats, cg.rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps),
                                         float(bn.momentum), bn.running_mean, bn.running_var)
             else:
@@ -291,9 +278,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             if Cp != Cout:
                 ss = torch.cat([ss, torch.zeros((2, Cp - Cout), dtype=ss.dtype, device=ss.device)], dim=1).contiguous()
         do, ho, wo = cg.out_dims
-        pg, res, mi_f, ss = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin, fuse)
-        if fuse is not None:
-            mi = mi_f
+        pg, res = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin)
         if keep:
             ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, res)
 
@@ -317,13 +302,9 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         for m in ms:
             C = m.conv.weight.shape[0]
             bn = m.bn
-            st = stats[:, off:off + C]
-            if be.bn_fwd_fused_ok(st, cg.rows) and off % 2 == 0:
-                pg, _, mi, ss = bn_apply(m, y[..., off:off + C], None, C, N, do, ho, wo, xin, (st, cg.rows, None, bn))
-            else:
-                mi, ss = be.bn_finalize(st, cg.rows, None, bn.weight.data, bn.bias.data, float(bn.eps),
-                                        float(bn.momentum), bn.running_mean, bn.running_var)
-                pg, _, _, _ = bn_apply(m, y[..., off:off + C], ss, C, N, do, ho, wo, xin)
+            mi, ss = be.bn_finalize(stats[:, off:off + C], cg.rows, None, bn.weight.data, bn.bias.data, float(bn.eps),
+                                    float(bn.momentum), bn.running_mean, bn.running_var)
+            pg, _ = bn_apply(m, y[..., off:off + C], ss, C, N, do, ho, wo, xin)
             per.append((off, C, mi, ss, pg))
             off += C
         if keep:

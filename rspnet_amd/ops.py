@@ -166,10 +166,6 @@ class HipOps:
 
     def __init__(self):
         self.lib = _lib.load(init_gpu=True)
-        self._fused_tiles = int(self.lib.rsp_bn_fused_max_tiles())
-        import os
-        if os.environ.get("RSP_NO_FUSED_BN"):          # A/B switch for tools/ only (ablation runs)
-            self._fused_tiles = 0
         self._ws = {}
         # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name, algorithmic
         # bytes, geometry) per MFMA launch
@@ -303,34 +299,6 @@ class HipOps:
         _lib.check(self.lib.rsp_bn_act_pool_fwd(dref, _ptr(y), _ptr(scale_shift), _ptr(residual), int(relu), _ptr(out),
                                                 _stream()), "rsp_bn_act_pool_fwd")
         return out
-
-    def bn_fwd_fused_ok(self, stats, rows: int) -> bool:
-        """Small layer: finalize + apply run as one launch (rsp_bn_finalize_act_pool_fwd)."""
-        return stats.shape[0] <= self._fused_tiles
-
-    def bn_fwd_fused(self, pg: PoolGeom, y, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,
-                     running_var, residual, relu: bool, out=None):
-        """bn_finalize + bn_act_pool_fwd of a small layer in one launch.  Returns (mean_invstd, scale_shift, out)."""
-        tiles, Cc, _ = stats.shape
-        if stats.is_contiguous():
-            _chk(stats, "stats")
-            stat_ld = Cc
-        else:      # channel slice of a wider convolution's partials
-            if not stats.is_cuda or stats.dtype != torch.float32 or stats.stride(2) != 1 or stats.stride(1) != 2 or stats.stride(0) % 2:
-                raise _lib.RspError("stats: expected [tiles][C][2] float32 partials or a channel slice of them")
-            stat_ld = stats.stride(0) // 2
-        in_ld = _rows_ld(y, "y")
-        if out is None:
-            do, ho, wo = pg.out_dims
-            out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
-        mi = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
-        ss = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
-        d, dref, _, _ = _pool_plan(0, pg, in_ld, _rows_ld(out, "out"), None if residual is None else _rows_ld(residual, "residual"))
-        _lib.check(self.lib.rsp_bn_finalize_act_pool_fwd(dref, _ptr(y), _ptr(stats), tiles, stat_ld, count, _ptr(conv_bias), _ptr(gamma),
-                                                         _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi),
-                                                         _ptr(ss), _ptr(residual), int(relu), _ptr(out), _stream()),
-                   "rsp_bn_finalize_act_pool_fwd")
-        return mi, ss, out
 
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu: bool,
                         want_dres: bool, dgamma_out, dbeta_out, dy_out=None):

@@ -65,17 +65,6 @@ class CpuOps:
             running_var.mul_(1 - momentum).add_(momentum * unb.float())
         return mi, ss
 
-    FUSED_TILES = 256      # = rsp_bn_fused_max_tiles(): layers of up to 256 x 128 rows run finalize + apply as one launch
-
-    def bn_fwd_fused_ok(self, stats, rows):
-        # (the checker keeps ONE fp64 stat tile per convolution: decide as the device does, by the real tile count)
-        return (rows + 127) // 128 <= self.FUSED_TILES
-
-    def bn_fwd_fused(self, pg, y, stats, count, conv_bias, gamma, beta, eps, momentum, running_mean, running_var, residual, relu,
-                     out=None):
-        mi, ss = self.bn_finalize(stats, count, conv_bias, gamma, beta, eps, momentum, running_mean, running_var)
-        return mi, ss, self.bn_act_pool_fwd(pg, y, ss, residual, relu, out=out)
-
     def _act(self, pg, y, ss, residual, relu):
         z = y * ss[0] + ss[1]
         if residual is not None:

@@ -257,61 +257,6 @@ def test_bn_act_pool_fwd_bwd(hip, case):
         close(dres, dres_ref, 1e-6, "dres")
 
 
-FUSED_CASES = [
-    # N, D, H, W, C (of this BN), Ctot (channels of the convolution whose partials it slices), offset, k = s, relu, residual
-    (2, 4, 14, 14, 64, 64, 0, (1, 1, 1), True, False),
-    (2, 4, 14, 14, 96, 176, 64, (1, 1, 1), True, False),      # S3D-G inception sibling: channel slice of a 176-wide GEMM
-    (2, 4, 14, 14, 16, 176, 160, (1, 1, 1), True, False),
-    (3, 2, 7, 7, 512, 512, 0, (1, 1, 1), True, True),         # residual, > 256 channel groups? (128): several stat tiles
-    (2, 4, 8, 8, 128, 128, 0, (2, 2, 2), True, False),        # pooled
-    (2, 3, 5, 5, 83, 83, 0, (1, 1, 1), True, False),          # scalar path
-    (1, 2, 4, 4, 1152, 1152, 0, (1, 1, 1), False, False),     # > 1024 channels: two channel chunks (blockIdx.y)
-    (4, 4, 32, 32, 64, 64, 0, (1, 2, 2), True, False),        # 128 stat tiles
-]
-
-
-@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "x".join(map(str, c[:7])) + f"k{c[7]}")
-def test_bn_finalize_and_apply_in_one_launch(hip, case):
-    """rsp_bn_finalize_act_pool_fwd (small layers: every workgroup reduces the stat partials itself) against the two-call path on
-    the device and the checker: activation, mean / invstd, scale / shift and the running statistics."""
-    N, D, H, W, C, Ctot, off, k, relu, use_res = case
-    pg = PoolGeom(N, D, H, W, C, k, k, (0, 0, 0))
-    rows = N * D * H * W
-    ywide = rnd(N, D, H, W, Ctot, seed=1) * 2 + 0.3
-    tiles = (rows + 127) // 128
-    flat = ywide.reshape(rows, Ctot).double()
-    part = torch.zeros(tiles, Ctot, 2)
-    for t in range(tiles):
-        blk = flat[t * 128:(t + 1) * 128]
-        part[t, :, 0] = blk.sum(0).float()
-        part[t, :, 1] = (blk * blk).sum(0).float()
-    bias = rnd(C, seed=2) if not use_res else None
-    gamma, beta = rnd(C, seed=3) + 1.5, rnd(C, seed=4)
-    rm, rv = rnd(C, seed=5), rnd(C, seed=6) + 1.5
-    res = rnd(N, D, H, W, C, seed=7) if use_res else None
-    y = ywide[..., off:off + C]
-    rm_ref, rv_ref = rm.clone(), rv.clone()
-    mi_ref, ss_ref = CPU.bn_finalize(part[:, off:off + C], rows, bias, gamma, beta, 1e-3, 0.1, rm_ref, rv_ref)
-    out_ref = CPU.bn_act_pool_fwd(pg, y, ss_ref, res, relu)
-    part_d, yw_d = part.to(DEV), ywide.to(DEV)
-    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
-    assert hip.bn_fwd_fused_ok(part_d[:, off:off + C], rows)
-    mi, ss, out = hip.bn_fwd_fused(pg, yw_d[..., off:off + C], part_d[:, off:off + C], rows, None if bias is None else bias.to(DEV),
-                                   gamma.to(DEV), beta.to(DEV), 1e-3, 0.1, rm_d, rv_d, None if res is None else res.to(DEV), relu)
-    close(mi, mi_ref, 1e-5, "mean/invstd")
-    close(ss, ss_ref, 1e-5, "scale/shift")
-    close(rm_d, rm_ref, 1e-5, "running_mean")
-    close(rv_d, rv_ref, 1e-5, "running_var")
-    close(out, out_ref, 2e-6, "activation")
-    # and bit-for-bit what the two-call device path produces from the same partials?  Not required (fp64 summation order differs),
-    # but the activation must agree to rounding
-    rm2, rv2 = rm.to(DEV), rv.to(DEV)
-    mi2, ss2 = hip.bn_finalize(part_d[:, off:off + C], rows, None if bias is None else bias.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-3,
-                               0.1, rm2, rv2)
-    out2 = hip.bn_act_pool_fwd(pg, yw_d[..., off:off + C], ss2, None if res is None else res.to(DEV), relu)
-    close(out, out2, 1e-6, "fused vs two-call")
-
-
 @pytest.mark.parametrize("B,P,C", [(4, 8, 512), (3, 98, 512), (2, 16, 1024)])
 def test_head_fwd_bwd(hip, B, P, C):
     feat = rnd(B, P, 1, 1, C, seed=1)
