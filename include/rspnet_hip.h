@@ -104,6 +104,10 @@ int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, int32_t max_bl
 size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d);
 int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a convolution whose channels are zero padded in the descriptor (d->Cout / d->Cin) but not in the parameter:
+ * dw_ref is (cout_valid, cin_valid, kT, kH, kW), the gradients of the padding channels are dropped.  dbias must be NULL. */
+int rsp_conv3d_wgrad_v(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, int32_t cout_valid,
+                       int32_t cin_valid, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Name of the kernel template instance the library launches for this descriptor (which: 0 forward, 1 dgrad, 2 wgrad;
  * 16-byte aligned tensors assumed) -- lets bench.py label its roofline block with the kernel that actually dominates a
@@ -129,6 +133,13 @@ int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int32_
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, float* mean_invstd /*[2][C]*/, float* scale_shift /*[2][C]*/, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* The same over a convolution that ran with its output channels zero-padded from c_valid to C (models/r2plus1d_vcop.py:35-38: mid
+ * channel counts such as 83 / 230 / 921 run as 84 / 232 / 924 so that rows are 16 bytes aligned): conv_bias / gamma / beta /
+ * running_mean / running_var hold c_valid entries; channels [c_valid, C) get scale = shift = 0 and move no running statistic. */
+int rsp_bn_finalize_v(const float* stat_partials, int32_t tiles, int32_t C, int32_t c_valid, int32_t stat_ld, int64_t count,
+                      const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* mean_invstd /*[2][C]*/, float* scale_shift /*[2][C]*/, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* Standalone per-channel statistics of y (for convs whose epilogue did not produce partials): writes
  * [tiles][C][2] partials with tiles = rsp_bn_stat_tiles(rows). */
@@ -156,6 +167,11 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
                         const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
                         float* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* channel-padded variant (see rsp_bn_finalize_v): gamma / dgamma / dbeta hold c_valid entries; padding channels have gamma = 0 */
+int rsp_bn_act_pool_bwd_v(const rsp_pool3d_desc* d, const float* y, const float* residual, const float* dout,
+                          const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
+                          float* dres, float* dgamma, float* dbeta, int32_t c_valid, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* Stand-alone MaxPool3d, any window/stride/padding (models/resnet.py:139, models/s3dg.py:90,107-119).
  * argmax (nullable in forward when no backward is needed): [N,Do,Ho,Wo,C] int32, linear input position per sample. */

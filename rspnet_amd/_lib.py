@@ -74,15 +74,18 @@ SIGNATURES = {
     "rsp_pack_run": (C.c_int, [_p, _i32, _i32, _p]),
     "rsp_conv3d_wgrad_workspace": (_sz, [_PD]),
     "rsp_conv3d_wgrad": (C.c_int, [_PD, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_conv3d_wgrad_v": (C.c_int, [_PD, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
     "rsp_conv3d_kernel_name": (C.c_char_p, [_PD, C.c_int]),
     "rsp_fastdiv_check": (C.c_int, [C.c_int, C.c_int]),
     "rsp_bn_finalize_workspace": (_sz, [_i32, _i32]),
     "rsp_bn_finalize": (C.c_int, [_p, _i32, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_bn_finalize_v": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_bn_stat_tiles": (_i32, [_i64]),
     "rsp_bn_stats": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "rsp_bn_act_pool_fwd": (C.c_int, [_PP, _p, _p, _p, C.c_int, _p, _p]),
     "rsp_bn_bwd_workspace": (_sz, [_PP]),
     "rsp_bn_act_pool_bwd": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_bn_act_pool_bwd_v": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _i32, _p, _sz, _p]),
     "rsp_maxpool3d_fwd": (C.c_int, [_PP, _p, _p, _p, _p]),
     "rsp_maxpool3d_bwd": (C.c_int, [_PP, _p, _p, _p, _p]),
     "rsp_gate_fwd_workspace": (_sz, [_i32, _i32, _i32]),

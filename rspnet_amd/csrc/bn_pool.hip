@@ -37,30 +37,51 @@ __global__ __launch_bounds__(256) void bn_finalize_stage1(const float* __restric
   }
 }
 
-__global__ void bn_finalize_stage2(const double* __restrict__ part, int S, int C, long long count,
-                                   const float* __restrict__ conv_bias, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// stage 2: one workgroup of 1024 threads per 64 channels — 16 slice-lanes per channel add the S fp64 slice sums (lane-strided,
+// then a 16-way LDS tree read in index order: fixed order), the first 64 threads finalize.  (The first version ran one thread per
+// channel over all S = 256 slices on one or two CUs: 50-63 us per BatchNorm of the big layers — C3D conv1 / conv2, R(2+1)D's
+// 144-channel layers — for a few KB of data.)
+__global__ __launch_bounds__(1024) void bn_finalize_stage2(const double* __restrict__ part, int S, int C, int Cv, long long count,
+                                                           const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+  __shared__ double red[16][64][2];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double s = 0.0, ss = 0.0;
-  for (int i = 0; i < S; ++i) {
-    s += part[((long long)i * C + c) * 2 + 0];
-    ss += part[((long long)i * C + c) * 2 + 1];
+  if (c < C)
+    for (int i = rl; i < S; i += 16) {
+      s += part[((long long)i * C + c) * 2 + 0];
+      ss += part[((long long)i * C + c) * 2 + 1];
+    }
+  red[rl][cl][0] = s;
+  red[rl][cl][1] = ss;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  s = 0.0;
+  ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s += red[i][cl][0];
+    ss += red[i][cl][1];
   }
   const double n = (double)count;
   const double mean0 = s / n;                   // mean of the bias-free conv output
   double var = ss / n - mean0 * mean0;          // biased
   var = var > 0.0 ? var : 0.0;
-  const double mean = mean0 + (conv_bias ? (double)conv_bias[c] : 0.0);
+  // channels [Cv, C) are zero padding of the convolution (R(2+1)D's odd mid-channel counts run padded to a multiple of 4): the
+  // parameter vectors hold Cv entries, the pad channels get gamma = beta = 0 and move no running statistics
+  const bool valid = c < Cv;
+  const double mean = mean0 + ((conv_bias && valid) ? (double)conv_bias[c] : 0.0);
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   mean_invstd[c] = (float)mean;
   mean_invstd[C + c] = invstd;
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float g = valid ? (gamma ? gamma[c] : 1.f) : 0.f, b = (valid && beta) ? beta[c] : 0.f;
   const float sc = g * invstd;
   scale_shift[c] = sc;
   scale_shift[C + c] = b - (float)mean * sc;
+  if (!valid) return;
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
   if (running_var) {
     const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
@@ -72,7 +93,7 @@ __global__ void bn_finalize_stage2(const double* __restrict__ part, int S, int C
 // reduce the [tiles][C][2] partials in fp64 (fixed order: lane-strided, then a 16-way LDS tree read in index order), then the
 // first 64 threads finalize their channel exactly as bn_finalize_stage2 does.  Replaces two ~6 us launches per BatchNorm by one
 // (S3D-G runs 231 BatchNorm forwards per step).
-__global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __restrict__ part, int tiles, int C, int ld, long long count,
+__global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __restrict__ part, int tiles, int C, int Cv, int ld, long long count,
                                                                const float* __restrict__ conv_bias, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float momentum,
                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -102,14 +123,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __re
   const double mean0 = s / n;                   // mean of the bias-free conv output
   double var = ss / n - mean0 * mean0;          // biased
   var = var > 0.0 ? var : 0.0;
-  const double mean = mean0 + (conv_bias ? (double)conv_bias[c] : 0.0);
+  // channels [Cv, C) are zero padding of the convolution (R(2+1)D's odd mid-channel counts run padded to a multiple of 4): the
+  // parameter vectors hold Cv entries, the pad channels get gamma = beta = 0 and move no running statistics
+  const bool valid = c < Cv;
+  const double mean = mean0 + ((conv_bias && valid) ? (double)conv_bias[c] : 0.0);
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   mean_invstd[c] = (float)mean;
   mean_invstd[C + c] = invstd;
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float g = valid ? (gamma ? gamma[c] : 1.f) : 0.f, b = (valid && beta) ? beta[c] : 0.f;
   const float sc = g * invstd;
   scale_shift[c] = sc;
   scale_shift[C + c] = b - (float)mean * sc;
+  if (!valid) return;
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
   if (running_var) {
     const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
@@ -283,7 +308,19 @@ struct BwdParams {
   int cgc, ppi;     // thread layout of the apply kernels (see Layout)
   long long npos;
   FastDiv dcgc, dWo, dHo, dDo;
+  int Cv;           // valid channels: gamma / dgamma / dbeta hold Cv entries, channels [Cv, C) are zero padding (gamma = 0)
 };
+
+// gamma of VEC channels starting at c (1 when there is no affine weight, 0 for padding channels)
+template <int VEC>
+__device__ __forceinline__ void load_gamma(const BwdParams& p, int c, float (&gam)[VEC]) {
+  if (p.gamma && p.Cv == p.d.C) {
+    load_vec<VEC>(p.gamma + c, gam);
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) gam[e] = c + e < p.Cv ? (p.gamma ? p.gamma[c + e] : 1.f) : 0.f;
+  }
+}
 
 // z of one input position (post affine + residual), VEC channels
 template <int VEC>
@@ -376,7 +413,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
 }
 
 // sums[c] = (sum dz, sum dz*xhat) in double; also dgamma / dbeta.  Block = 64 channels x 16 partial-row lanes.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int Cv,
                                                                double* __restrict__ sums, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta) {
   __shared__ double red[16][64][2];
@@ -397,8 +434,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     for (int l = 0; l < 16; ++l) { a += red[l][cl][0]; b += red[l][cl][1]; }
     sums[2 * c] = a;
     sums[2 * c + 1] = b;
-    if (dbeta) dbeta[c] = (float)a;
-    if (dgamma) dgamma[c] = (float)b;
+    if (dbeta && c < Cv) dbeta[c] = (float)a;
+    if (dgamma && c < Cv) dgamma[c] = (float)b;
   }
 }
 
@@ -423,11 +460,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
     load_vec<VEC>(p.ss + d.C + c, sh);
     load_vec<VEC>(p.mi + c, mean);
     load_vec<VEC>(p.mi + d.C + c, invstd);
-    if (p.gamma) load_vec<VEC>(p.gamma + c, gam);
-    else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) gam[e] = 1.f;
-    }
+    load_gamma<VEC>(p, c, gam);
     float yv[VEC], z[VEC], dz[VEC];
     zval<VEC>(p, pos, c, sc, sh, yv, z);
 #pragma unroll
@@ -495,11 +528,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p
   load_vec<VEC>(p.ss + d.C + c, sh);
   load_vec<VEC>(p.mi + c, mean);
   load_vec<VEC>(p.mi + d.C + c, invstd);
-  if (p.gamma) load_vec<VEC>(p.gamma + c, gam);
-  else {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) gam[e] = 1.f;
-  }
+  load_gamma<VEC>(p, c, gam);
   const double invn = 1.0 / (double)p.count;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
@@ -620,8 +649,16 @@ int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int32_
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, float* mean_invstd, float* scale_shift, void* workspace,
                     size_t workspace_bytes, void* stream) {
+  return rsp_bn_finalize_v(stat_partials, tiles, C, C, stat_ld, count, conv_bias, gamma, beta, eps, momentum, running_mean, running_var,
+                           mean_invstd, scale_shift, workspace, workspace_bytes, stream);
+}
+
+int rsp_bn_finalize_v(const float* stat_partials, int32_t tiles, int32_t C, int32_t c_valid, int32_t stat_ld, int64_t count,
+                      const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* mean_invstd, float* scale_shift, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(stat_partials && mean_invstd && scale_shift && workspace, "rsp_bn_finalize: null pointer");
-  RSP_REQUIRE(tiles > 0 && C > 0 && count > 0 && stat_ld >= C, "rsp_bn_finalize: bad size");
+  RSP_REQUIRE(tiles > 0 && C > 0 && count > 0 && stat_ld >= C && c_valid > 0 && c_valid <= C, "rsp_bn_finalize: bad size");
   const int S = finalize_slices(tiles);
   if (workspace_bytes < (size_t)S * C * 2 * sizeof(double)) {
     rsp_set_error("rsp_bn_finalize: workspace too small");
@@ -629,7 +666,7 @@ int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int32_
   }
   hipStream_t s = (hipStream_t)stream;
   if (tiles <= 2048) {
-    hipLaunchKernelGGL(bn_finalize_one_kernel, dim3(rsp_cdiv(C, 64)), dim3(1024), 0, s, stat_partials, tiles, C, stat_ld, (long long)count,
+    hipLaunchKernelGGL(bn_finalize_one_kernel, dim3(rsp_cdiv(C, 64)), dim3(1024), 0, s, stat_partials, tiles, C, c_valid, stat_ld, (long long)count,
                        conv_bias, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
     return rsp_check_launch("bn_finalize_one_kernel");
   }
@@ -637,7 +674,7 @@ int rsp_bn_finalize(const float* stat_partials, int32_t tiles, int32_t C, int32_
   hipLaunchKernelGGL(bn_finalize_stage1, dim3(rsp_cdiv(C, 64), S), dim3(256), 0, s, stat_partials, tiles, C, stat_ld, S, part);
   int rc = rsp_check_launch("bn_finalize_stage1");
   if (rc != RSP_OK) return rc;
-  hipLaunchKernelGGL(bn_finalize_stage2, dim3(rsp_cdiv(C, 128)), dim3(128), 0, s, part, S, C, (long long)count, conv_bias,
+  hipLaunchKernelGGL(bn_finalize_stage2, dim3(rsp_cdiv(C, 64)), dim3(1024), 0, s, part, S, C, c_valid, (long long)count, conv_bias,
                      gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
   return rsp_check_launch("bn_finalize_stage2");
 }
@@ -668,7 +705,16 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
                         const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
                         float* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                         void* stream) {
+  return rsp_bn_act_pool_bwd_v(d, y, residual, dout, gamma, mean_invstd, scale_shift, relu, dy, dres, dgamma, dbeta, d ? d->C : 0,
+                               workspace, workspace_bytes, stream);
+}
+
+int rsp_bn_act_pool_bwd_v(const rsp_pool3d_desc* d, const float* y, const float* residual, const float* dout,
+                          const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
+                          float* dres, float* dgamma, float* dbeta, int32_t c_valid, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   RSP_REQUIRE(pool_ok(d, true), "rsp_bn_act_pool_bwd: needs disjoint windows (kernel == stride, no padding)");
+  RSP_REQUIRE(c_valid > 0 && c_valid <= d->C, "rsp_bn_act_pool_bwd: bad valid channel count");
   RSP_REQUIRE(y && dout && mean_invstd && scale_shift && dy && workspace, "rsp_bn_act_pool_bwd: null pointer");
   if (workspace_bytes < rsp_bn_bwd_workspace(d)) {
     rsp_set_error("rsp_bn_act_pool_bwd: workspace too small");
@@ -679,10 +725,11 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
   memset(&p, 0, sizeof p);
   p.d = *d; p.y = y; p.res = residual; p.dout = dout; p.gamma = gamma; p.mi = mean_invstd; p.ss = scale_shift;
   p.dy = dy; p.dres = dres; p.relu = relu;
+  p.Cv = c_valid;
   p.count = (long long)d->N * d->Di * d->Hi * d->Wi;
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(dout) &&
                    rsp_aligned16(dy) && rsp_aligned16(scale_shift) && rsp_aligned16(mean_invstd) &&
-                   (!gamma || rsp_aligned16(gamma)) &&
+                   (!gamma || c_valid != d->C || rsp_aligned16(gamma)) &&
                    (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual) && (!dres || rsp_aligned16(dres))));
   p.cg = vec ? d->C / 4 : d->C;
   p.partial = reinterpret_cast<float*>(workspace);
@@ -698,7 +745,7 @@ int rsp_bn_act_pool_bwd(const rsp_pool3d_desc* d, const float* y, const float* r
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, rgrid, dim3(256), 0, s, p);
   int rc = rsp_check_launch("bn_bwd_reduce_kernel");
   if (rc != RSP_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, 64)), dim3(1024), 0, s, p.partial, p.nblocks, d->C, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, 64)), dim3(1024), 0, s, p.partial, p.nblocks, d->C, c_valid, sums,
                      dgamma, dbeta);
   rc = rsp_check_launch("bn_bwd_finalize_kernel");
   if (rc != RSP_OK) return rc;

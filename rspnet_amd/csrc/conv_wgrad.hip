@@ -494,12 +494,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
 // dw_ref[co][ci][tap] = sum_z partial[z][co][tap*Cin + ci]   (fixed summation order)
 // Block = one output channel x up to 32 input channels: partials are read along k (contiguous ci runs per tap), summed
 // over the slabs with 4 loads in flight, transposed through LDS and written as one contiguous run of dw_ref.
+// Cin_v (<= Cin): input channels of the PARAMETER — channels beyond are zero padding of the activations whose gradients are dropped
+// (the output-channel padding is cut by the grid: blockIdx.y < valid output channels).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           int splitm, int Cout, int Cin, int taps, int Kld) {
+                                                           int splitm, int Cout, int Cin, int taps, int Kld, int Cin_v) {
   extern __shared__ float wr_tile[];   // [cit][taps]
   const int cit = Cin < 32 ? Cin : 32;
   const int ci0 = blockIdx.x * cit, co = blockIdx.y;
-  const int nci = min(cit, Cin - ci0);
+  const int nci = min(cit, Cin_v - ci0);
+  if (nci <= 0) return;
   const long long slab = (long long)Cout * Kld;
   const float* base = partial + (long long)co * Kld;
   for (int e = threadIdx.x; e < nci * taps; e += 256) {
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     wr_tile[cil * taps + tap] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
-  float* out = dw + ((long long)co * Cin + ci0) * taps;
+  float* out = dw + ((long long)co * Cin_v + ci0) * taps;
   for (int e = threadIdx.x; e < nci * taps; e += 256) out[e] = wr_tile[e];
 }
 
@@ -696,7 +699,7 @@ size_t wgrad_ws_one(const rsp_conv3d_desc* d) {
 }
 
 int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
-              size_t workspace_bytes, void* stream, bool rowgeom_ready);
+              size_t workspace_bytes, void* stream, bool rowgeom_ready, int cout_valid, int cin_valid);
 
 }  // namespace
 
@@ -715,23 +718,41 @@ size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d) {
   return best;
 }
 
+static int wgrad_all(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, int cout_valid,
+                     int cin_valid, void* workspace, size_t workspace_bytes, void* stream) {
+  rsp_note_reset();
+  // problems over disjoint output-channel ranges; dy keeps its row pitch (out_ld), dw / dbias are contiguous per channel
+  const WSegs g = wgrad_segments(d);
+  const long long per_co = (long long)cin_valid * d->kT * d->kH * d->kW;
+  for (int i = 0; i < g.n; ++i) {
+    rsp_conv3d_desc a = *d;
+    a.Cout = g.width[i];
+    const int at = g.at[i];
+    int cov = cout_valid - at;              // valid output channels inside this segment
+    cov = cov < 0 ? 0 : (cov > a.Cout ? a.Cout : cov);
+    if (cov == 0) continue;
+    const int rc = wgrad_one(&a, x, dy + at, dw_ref + at * per_co, dbias ? dbias + at : nullptr, workspace, workspace_bytes, stream,
+                             i > 0, cov, cin_valid);
+    if (rc != RSP_OK) return rc;
+  }
+  return RSP_OK;
+}
+
 int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias,
                      void* workspace, size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(wdesc_ok(d), "rsp_conv3d_wgrad: bad descriptor");
   RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad: null pointer");
   RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_wgrad: workspace must be 16-byte aligned");
-  rsp_note_reset();
-  // problems over disjoint output-channel ranges; dy keeps its row pitch (out_ld), dw / dbias are contiguous per channel
-  const WSegs g = wgrad_segments(d);
-  const long long per_co = (long long)d->Cin * d->kT * d->kH * d->kW;
-  for (int i = 0; i < g.n; ++i) {
-    rsp_conv3d_desc a = *d;
-    a.Cout = g.width[i];
-    const int at = g.at[i];
-    const int rc = wgrad_one(&a, x, dy + at, dw_ref + at * per_co, dbias ? dbias + at : nullptr, workspace, workspace_bytes, stream, i > 0);
-    if (rc != RSP_OK) return rc;
-  }
-  return RSP_OK;
+  return wgrad_all(d, x, dy, dw_ref, dbias, d->Cout, d->Cin, workspace, workspace_bytes, stream);
+}
+
+int rsp_conv3d_wgrad_v(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, int32_t cout_valid,
+                       int32_t cin_valid, void* workspace, size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(wdesc_ok(d), "rsp_conv3d_wgrad_v: bad descriptor");
+  RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad_v: null pointer");
+  RSP_REQUIRE(rsp_aligned16(workspace), "rsp_conv3d_wgrad_v: workspace must be 16-byte aligned");
+  RSP_REQUIRE(cout_valid > 0 && cout_valid <= d->Cout && cin_valid > 0 && cin_valid <= d->Cin, "rsp_conv3d_wgrad_v: bad valid channel counts");
+  return wgrad_all(d, x, dy, dw_ref, nullptr, cout_valid, cin_valid, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"
@@ -739,7 +760,7 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
 namespace {
 
 int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
-              size_t workspace_bytes, void* stream, bool rowgeom_ready) {
+              size_t workspace_bytes, void* stream, bool rowgeom_ready, int cout_valid, int cin_valid) {
   const WPlan w = wplan(d);
   if (workspace_bytes < w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes) {
     rsp_set_error("rsp_conv3d_wgrad: workspace too small");
@@ -813,8 +834,8 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
   {
     const int taps = d->kT * d->kH * d->kW;
     const int cit = d->Cin < 32 ? d->Cin : 32;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rsp_cdiv(d->Cin, cit), d->Cout), dim3(256), (size_t)cit * taps * sizeof(float), s,
-                       p.partial, dw_ref, p.splitm, d->Cout, d->Cin, taps, p.Kld);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rsp_cdiv(cin_valid, cit), cout_valid), dim3(256), (size_t)cit * taps * sizeof(float), s,
+                       p.partial, dw_ref, p.splitm, d->Cout, d->Cin, taps, p.Kld, cin_valid);
     rc = rsp_check_launch("wgrad_reduce_kernel");
     if (rc != RSP_OK) return rc;
   }

@@ -259,18 +259,15 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         cg = ConvGeom(N, D, H, W, Cin, Cp, node.k, node.s, node.p, Cin_alg=w.shape[1])
         bias = getattr(node.conv, "bias", None)
         bn = node.bn
-        bias_d = None if bias is None else (bias.data if Cp == Cout else _pad_vec(bias.data, Cp))
+        bias_d = None if bias is None else bias.data
         if training:
-            y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_d, True)
-            if Cp == Cout:
-                mi, ss = be.bn_finalize(stats, cg.rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps),
-                                        float(bn.momentum), bn.running_mean, bn.running_var)
-            else:
-                rm, rv = _pad_vec(bn.running_mean, Cp), _pad_vec(bn.running_var, Cp, 1.0)
-                mi, ss = be.bn_finalize(stats, cg.rows, bias_d, _pad_vec(bn.weight.data, Cp), _pad_vec(bn.bias.data, Cp),
-                                        float(bn.eps), float(bn.momentum), rm, rv)
-                bn.running_mean.copy_(rm[:Cout])
-                bn.running_var.copy_(rv[:Cout])
+            # (no shipped backbone has a conv bias on channel-padded units; if one does, the conv needs it at the padded length)
+            bias_conv = bias_d if (bias_d is None or Cp == Cout) else _pad_vec(bias_d, Cp)
+            y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_conv, True)
+            # (zero-padded output channels, Cp > Cout: the BatchNorm vectors keep their Cout entries, the kernels treat the rest
+            #  as gamma = beta = 0 and leave the running statistics of the real channels alone)
+            mi, ss = be.bn_finalize(stats, cg.rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps),
+                                    float(bn.momentum), bn.running_mean, bn.running_var)
         else:
             y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), None, False)     # bias folded into the shift
             ss = _eval_scale_shift(bn, bias)
@@ -378,18 +375,8 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
         else:
             dout = dslots.pop(node.dst)
         bn = node.bn
-        Cout, Cp = node.conv.weight.shape[0], sv.cg.Cout
-        if Cp == Cout:
-            dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
-                                          node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
-        else:
-            dgam = torch.empty(Cp, dtype=torch.float32, device=dout.device)
-            dbet = torch.empty(Cp, dtype=torch.float32, device=dout.device)
-            dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, _pad_vec(bn.weight.data, Cp), sv.mi, sv.ss, node.relu,
-                                          node.residual is not None, dgam, dbet)
-            for g, src in ((grad_of(bn.weight), dgam), (grad_of(bn.bias), dbet)):
-                if g is not None:
-                    g.copy_(src[:Cout])
+        dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
+                                      node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
         if node.residual is not None:
             add_grad(node.residual, dres)
         bias = getattr(node.conv, "bias", None)
@@ -399,13 +386,8 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 # A conv bias in front of train-mode BatchNorm has an identically-zero gradient (BN subtracts the
                 # batch mean); the reference's autograd produces ~1e-8 rounding noise there.
                 gb.zero_()
-        gw = grad_of(node.conv.weight)
-        if gw is not None and (gw.shape[1] != sv.cg.Cin or gw.shape[0] != Cp):   # channel-padded: drop the pad gradients
-            gpad = torch.empty((Cp, sv.cg.Cin) + tuple(gw.shape[2:]), dtype=gw.dtype, device=gw.device)
-            be.conv_wgrad(sv.cg, sv.x, dy, gpad)
-            gw.copy_(gpad[:gw.shape[0], :gw.shape[1]])
-        else:
-            be.conv_wgrad(sv.cg, sv.x, dy, gw)
+        # (a channel-padded geometry writes only the parameter's own channels: the reduce drops the padding's gradients)
+        be.conv_wgrad(sv.cg, sv.x, dy, grad_of(node.conv.weight))
         if after_param_grads is not None:
             after_param_grads(ni)
         if node.src != plan.input_slot or want_input_grad:

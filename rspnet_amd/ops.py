@@ -266,8 +266,15 @@ class HipOps:
         d, dref, _, _, _, wsb, _, names = _conv_plan(0, g, None, None)
         ws = self._workspace(x.device, wsb)
         e0 = self._ev()
-        _lib.check(self.lib.rsp_conv3d_wgrad(dref, _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
-                                             _stream()), "rsp_conv3d_wgrad")
+        if dw_out.shape[0] != g.Cout or dw_out.shape[1] != g.Cin:
+            # the geometry carries zero-padded channels the parameter does not have: their gradients are dropped by the reduce
+            if dbias_out is not None or dw_out.shape[0] > g.Cout or dw_out.shape[1] > g.Cin:
+                raise _lib.RspError("conv_wgrad: dw_out has more channels than the geometry, or a bias gradient with padded channels")
+            _lib.check(self.lib.rsp_conv3d_wgrad_v(dref, _ptr(x), _ptr(dy), _ptr(dw_out), dw_out.shape[0], dw_out.shape[1], _ptr(ws), wsb,
+                                                   _stream()), "rsp_conv3d_wgrad_v")
+        else:
+            _lib.check(self.lib.rsp_conv3d_wgrad(dref, _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
+                                                 _stream()), "rsp_conv3d_wgrad")
         self._log("conv_wgrad", g, e0, names[2])
 
     # ---- batch norm -------------------------------------------------------------------------------------------
@@ -285,9 +292,11 @@ class HipOps:
         ss = torch.empty((2, Cc), dtype=torch.float32, device=stats.device)
         wsb = int(self.lib.rsp_bn_finalize_workspace(tiles, Cc))
         ws = self._workspace(stats.device, wsb)
-        _lib.check(self.lib.rsp_bn_finalize(_ptr(stats), tiles, Cc, stat_ld, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta), eps,
-                                            momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi), _ptr(ss), _ptr(ws),
-                                            wsb, _stream()), "rsp_bn_finalize")
+        # the parameter vectors may be shorter than the convolution's (zero-padded) channel count: gamma's length says how many
+        c_valid = Cc if gamma is None else int(gamma.shape[0])
+        _lib.check(self.lib.rsp_bn_finalize_v(_ptr(stats), tiles, Cc, c_valid, stat_ld, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta),
+                                              eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi), _ptr(ss), _ptr(ws),
+                                              wsb, _stream()), "rsp_bn_finalize")
         return mi, ss
 
     def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu: bool, out=None):
@@ -315,9 +324,10 @@ class HipOps:
             dy = torch.empty_like(y)
         dres = torch.empty_like(y) if want_dres else None
         ws = self._workspace(y.device, wsb)
-        _lib.check(self.lib.rsp_bn_act_pool_bwd(dref, _ptr(y), _ptr(residual), _ptr(dout), _ptr(gamma),
-                                                _ptr(mean_invstd), _ptr(scale_shift), int(relu), _ptr(dy), _ptr(dres),
-                                                _ptr(dgamma_out), _ptr(dbeta_out), _ptr(ws), wsb, _stream()),
+        c_valid = pg.C if gamma is None else int(gamma.shape[0])      # < C: zero-padded channels (gamma / dgamma / dbeta are short)
+        _lib.check(self.lib.rsp_bn_act_pool_bwd_v(dref, _ptr(y), _ptr(residual), _ptr(dout), _ptr(gamma),
+                                                  _ptr(mean_invstd), _ptr(scale_shift), int(relu), _ptr(dy), _ptr(dres),
+                                                  _ptr(dgamma_out), _ptr(dbeta_out), c_valid, _ptr(ws), wsb, _stream()),
                    "rsp_bn_act_pool_bwd")
         return dy, dres
 

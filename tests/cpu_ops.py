@@ -43,13 +43,25 @@ class CpuOps:
         return _ndhwc(dx)
 
     def conv_wgrad(self, g: ConvGeom, x, dy, dw_out, dbias_out=None):
-        dw = torch.nn.grad.conv3d_weight(_ncdhw(x).contiguous(), tuple(dw_out.shape), _ncdhw(dy).contiguous(),
-                                         stride=g.s, padding=g.p)
-        dw_out.copy_(dw)
+        # dw_out may hold fewer channels than the (zero-padded) geometry: the padding channels' gradients are dropped
+        full = (g.Cout, g.Cin) + tuple(dw_out.shape[2:])
+        dw = torch.nn.grad.conv3d_weight(_ncdhw(x).contiguous(), full, _ncdhw(dy).contiguous(), stride=g.s, padding=g.p)
+        dw_out.copy_(dw[:dw_out.shape[0], :dw_out.shape[1]])
         if dbias_out is not None:
             dbias_out.copy_(dy.sum(dim=(0, 1, 2, 3)))
 
     def bn_finalize(self, stats, count, conv_bias, gamma, beta, eps, momentum, running_mean, running_var):
+        C, Cv = stats.shape[1], gamma.shape[0]
+        if Cv < C:        # zero-padded output channels: parameters hold Cv entries, the padding gets gamma = beta = 0
+            pad = lambda v, fill=0.0: None if v is None else torch.cat([v, torch.full((C - Cv,), fill, dtype=v.dtype)])
+            rm = None if running_mean is None else pad(running_mean)
+            rv = None if running_var is None else pad(running_var, 1.0)
+            mi, ss = self.bn_finalize(stats, count, pad(conv_bias), pad(gamma), pad(beta), eps, momentum, rm, rv)
+            if running_mean is not None:
+                running_mean.copy_(rm[:Cv])
+            if running_var is not None:
+                running_var.copy_(rv[:Cv])
+            return mi, ss
         s = stats.double().sum(dim=0)
         mean0 = s[:, 0] / count
         var = (s[:, 1] / count - mean0 * mean0).clamp_min(0)
@@ -116,6 +128,17 @@ class CpuOps:
     @torch.enable_grad()
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu, want_dres,
                         dgamma_out, dbeta_out, dy_out=None):
+        C = y.shape[-1]
+        if gamma is not None and gamma.shape[0] < C:      # zero-padded channels (see bn_finalize)
+            Cv = gamma.shape[0]
+            dg, db = torch.empty(C), torch.empty(C)
+            res = self.bn_act_pool_bwd(pg, y, residual, dout, torch.cat([gamma, torch.zeros(C - Cv)]), mean_invstd, scale_shift, relu,
+                                       want_dres, dg, db, dy_out=dy_out)
+            if dgamma_out is not None:
+                dgamma_out.copy_(dg[:Cv])
+            if dbeta_out is not None:
+                dbeta_out.copy_(db[:Cv])
+            return res
         z = self._act(pg, y, scale_shift, residual, relu).detach().requires_grad_(True)
         a = F.relu(z) if relu else z
         if pg.k != (1, 1, 1) or pg.s != (1, 1, 1):

@@ -1,7 +1,8 @@
 """CPU: rspnet_amd's host logic (plan executor, flat params, MoCo forward/backward orchestration, fused-SGD
 bookkeeping) reproduces the golden fixtures when its HIP ops are replaced by the torch checker backend.
-The kernels themselves are tested on the GPU (tests/test_kernels_gpu.py, tests/test_step_gpu.py), where every fixture family runs
-(the ResNet-34 / -50 and speed-1 cases only there: the CPU suite has to stay within a few minutes)."""
+The kernels themselves are tested on the GPU (tests/test_kernels_gpu.py, tests/test_step_gpu.py).  Every fixture family runs
+here too — ResNet-34 / -50 (Bottleneck) and the speed-1 case included — so that the teacher-forced replay's chain
+"HIP kernel == checker op at 2e-5" + "checker == reference fixture" has both links for every architecture."""
 import numpy as np
 import pytest
 import torch
@@ -21,7 +22,8 @@ def cpu_backend():
 
 _C3D = cases_for("c3d", 1)
 CASES = [(_C3D[0][0], _C3D[0][2], "fused"), (_C3D[1][0], _C3D[1][2], "torch")] + [
-    (a, s, "fused") for arch in ("resnet18", "r2plus1d-vcop", "s3dg", "c3d:mlp", "c3d:conv", "c3d:convbn", "c3d:speednet", "c3d:linear:4") for a, w, s in cases_for(arch, 1)]
+    (a, s, "fused") for arch in ("resnet18", "r2plus1d-vcop", "s3dg", "c3d:mlp", "c3d:conv", "c3d:convbn", "c3d:speednet", "c3d:linear:4", "c3d:linear:1",
+                                  "resnet34", "resnet50") for a, w, s in cases_for(arch, 1)]
 
 
 @pytest.mark.parametrize("arch,seed,optimizer", CASES)

@@ -542,3 +542,53 @@ def test_packed_weights_are_shared_across_input_geometries(hip):
     x = torch.from_numpy(P.clips(5, 0, (4, 3, 16, 32, 32))[0]).to(DEV)
     a2, _ = enc(x)
     assert torch.equal(a2, outs[(16, 32, 4)])
+
+
+def test_channel_padded_unit_uses_the_parameters_own_lengths(hip):
+    """R(2+1)D's odd mid-channel counts (83 / 230 / 921, models/r2plus1d_vcop.py:35-38) run zero-padded to a multiple of 4; the
+    BatchNorm vectors and the weight gradient keep the parameter's own shape: rsp_bn_finalize_v / rsp_bn_act_pool_bwd_v /
+    rsp_conv3d_wgrad_v treat the padding as gamma = beta = 0 and drop its gradients (no staging copies in the engine)."""
+    N, D, H, W, Cin, Cv, Cp = 2, 4, 10, 10, 64, 83, 84
+    g = ConvGeom(N, D, H, W, Cin, Cp, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    x = rnd(N, D, H, W, Cin, seed=1)
+    w = rnd(Cv, Cin, 1, 3, 3, seed=2, scale=0.1)
+    wp = torch.zeros(Cp, Cin, 1, 3, 3)
+    wp[:Cv] = w
+    y_ref, st_ref = CPU.conv_fwd(g, x, wp, None, True)
+    y, st = hip.conv_fwd(g, x.to(DEV), hip.conv_pack_fwd(g, wp.to(DEV)), None, True)
+    close(y, y_ref, 2e-5, "padded conv")
+    gamma, beta = rnd(Cv, seed=3) + 1.5, rnd(Cv, seed=4)
+    rm, rv = rnd(Cv, seed=5), rnd(Cv, seed=6) + 1.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    mi_ref, ss_ref = CPU.bn_finalize(st_ref, g.rows, None, gamma, beta, 1e-5, 0.1, rm_ref, rv_ref)
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    mi, ss = hip.bn_finalize(st, g.rows, None, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm_d, rv_d)
+    close(ss, ss_ref, 1e-5, "scale/shift (padding: 0)")
+    assert float(ss[:, Cv:].abs().max()) == 0.0
+    close(rm_d, rm_ref, 1e-5, "running_mean")
+    close(rv_d, rv_ref, 1e-5, "running_var")
+    pg = PoolGeom(N, D, H, W, Cp)
+    out = hip.bn_act_pool_fwd(pg, y, ss, None, True)
+    assert float(out[..., Cv:].abs().max()) == 0.0
+    dout = rnd(N, D, H, W, Cp, seed=7)
+    dg_ref, db_ref = torch.empty(Cv), torch.empty(Cv)
+    dy_ref, _ = CPU.bn_act_pool_bwd(pg, y_ref, None, dout, gamma, mi_ref, ss_ref, True, False, dg_ref, db_ref)
+    dg, db = torch.empty(Cv, device=DEV), torch.empty(Cv, device=DEV)
+    dy, _ = hip.bn_act_pool_bwd(pg, y, None, dout.to(DEV), gamma.to(DEV), mi, ss, True, False, dg, db)
+    close(dy, dy_ref, 2e-5, "dy")
+    close(dg, dg_ref, 2e-5, "dgamma")
+    close(db, db_ref, 2e-5, "dbeta")
+    assert float(dy[..., Cv:].abs().max()) == 0.0
+    # weight gradient straight into the (83, 64, ...) parameter gradient; and the temporal partner whose INPUT channels are padded
+    dw_ref = torch.empty_like(w)
+    CPU.conv_wgrad(g, x, dy_ref, dw_ref)
+    dw = torch.empty(Cv, Cin, 1, 3, 3, device=DEV)
+    hip.conv_wgrad(g, x.to(DEV), dy, dw)
+    close(dw, dw_ref, 2e-5, "dw (output channels padded)")
+    g2 = ConvGeom(N, D, H, W, Cp, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    dy2 = rnd(N, D, H, W, 64, seed=8)
+    dw2_ref = torch.empty(64, Cv, 3, 1, 1)
+    CPU.conv_wgrad(g2, out.cpu(), dy2, dw2_ref)
+    dw2 = torch.empty(64, Cv, 3, 1, 1, device=DEV)
+    hip.conv_wgrad(g2, out, dy2.to(DEV), dw2)
+    close(dw2, dw2_ref, 2e-5, "dw (input channels padded)")

@@ -76,4 +76,20 @@ for name, T, HW, cin, o in BLOCKS:
         return e0.elapsed_time(e1) / it * 1e3
 
     a, b_ = timeit(seq), timeit(par)
-    print(f"sepInc_{name} ({T}x{HW}x{HW}, cin {cin}): one stream {a:7.1f} us   four streams {b_:7.1f} us   x{a / b_:.2f}", flush=True)
+    # the same two schedules as captured HIP graphs: no host cost per launch, so what is measured is the GPU's own time — eager
+    # launches of this block cost the host ~15-20 us each, about as much as the small kernels run
+    side = torch.cuda.Stream(dev)
+    graphs = []
+    for fn in (seq, par):
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn(); fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        graphs.append(g)
+    ga, gb = timeit(graphs[0].replay), timeit(graphs[1].replay)
+    print(f"sepInc_{name} ({T}x{HW}x{HW}, cin {cin}): eager one stream {a:7.1f} us, four streams {b_:7.1f} us (x{a / b_:.2f}) | "
+          f"HIP graph one stream {ga:7.1f} us, four streams {gb:7.1f} us (x{ga / gb:.2f})", flush=True)
