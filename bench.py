@@ -57,6 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32, help="clips per CPU-baseline step (BASELINE config 1: 32)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps after one warm-up step")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="run the step as one replayed HIP graph (rspnet_amd/graph_step.py; N=1 only).  auto: for the backbones it "
+                         "pays for (everything but C3D, whose 250 long launches leave the host nothing to hide)")
     ap.add_argument("--no-other-workloads", dest="other_workloads", action="store_false",
                     help="skip BASELINE configs 3-5 (R3D-18, R(2+1)D, S3D-G) that the default N=1 C3D run appends")
     ap.add_argument("--other-steps", type=int, default=30)
@@ -267,13 +270,23 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     im_q = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
     im_k = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
 
-    def step():
+    use_graph = cuda and ws == 1 and (args.graph == "on" or (args.graph == "auto" and arch != "c3d"))
+    stepper = None
+    if use_graph:
+        from rspnet_amd.graph_step import GraphedPretextStep
+        stepper = GraphedPretextStep(model, crit, opt, warmup=2)
+
+    def eager_step():
         out, tgt, rl, rt = model(im_q, im_k)
         loss, loss_A, loss_M = crit(out, tgt, rl, rt)
         opt.zero_grad()
         loss.backward()
         opt.step()
         return loss, loss_A, loss_M, out, rl
+
+    def step():
+        # the reference's loop body (pretrain.py:157-165) — eagerly, or as ONE replayed HIP graph (rspnet_amd/graph_step.py)
+        return stepper(im_q, im_k) if stepper is not None else eager_step()
 
     def fence():
         if ws > 1:
@@ -311,8 +324,9 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     gc.collect()
     gc.freeze()
     fence()
-    if cuda:
-        be.event_log = []
+    graphed = stepper is not None and not stepper.disabled and len(stepper.graphs) > 0
+    if cuda and not graphed:
+        be.event_log = []                      # (a replayed graph has no per-launch events: see the roofline pass below)
     if ws > 1:
         inner.comm_log = {}
     marks, host = [], []
@@ -330,7 +344,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     fence()
     dt = time.perf_counter() - t0
     log = []
-    if cuda:
+    if cuda and not graphed:
         log, be.event_log = be.event_log, None
     comm, inner.comm_log = inner.comm_log, None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -340,7 +354,21 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     final_loss = float(loss.detach())
     step_ms = dt / steps * 1e3
     res = {"clips_per_s": ws * B * steps / dt, "ms_per_step": step_ms, "final_loss": final_loss, "K": K, "lr": lr, "B": B,
-           "hw": hw}
+           "hw": hw, "graph": bool(graphed)}
+    if stepper is not None and not graphed:
+        res["graph_fallback"] = stepper.fallback_reason or "not captured within the warm-up steps"
+    roof_steps = steps
+    if graphed:
+        # roofline pass: the same step issued eagerly with a HIP-event pair around every convolution launch (kernel durations
+        # cannot be read out of a replayed graph); outside the timed region, continuing the same training state
+        roof_steps = max(2, min(10, steps))
+        eager_step()
+        fence()
+        be.event_log = []
+        for _ in range(roof_steps):
+            eager_step()
+        fence()
+        log, be.event_log = be.event_log, None
     if marks:
         per = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         res["steps_ms"] = {"p50": round(_pct(per, 0.5), 3), "min": round(min(per), 3), "max": round(max(per), 3),
@@ -375,7 +403,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         achieved = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
         traffic, traffic_src = load_traffic(arch, B, dom)
         alg_gb = dbytes / max(dn, 1) / 1e9
-        whole = flops / steps / (step_ms * 1e-3) / 1e12
+        whole = flops / roof_steps / (step_ms * 1e-3) / 1e12
         res["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -385,18 +413,18 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
             "traffic_over_algorithmic": None if traffic is None or alg_gb <= 0 else round(traffic / alg_gb, 2),
             "traffic_source": traffic_src,
             "kernel": dom, "launches": dn, "avg_launch_ms": round(dms / max(dn, 1), 4),
-            "share_of_step": round(dms / steps / step_ms, 4),
+            "share_of_step": round(dms / roof_steps / step_ms, 4),
             "algorithmic_gflop_per_launch": round(dflops / max(dn, 1) / 1e9, 2),
-            "whole_step": {"algorithmic_conv_gflop_per_clip": round(flops / steps / B / 1e9, 2),
+            "whole_step": {"algorithmic_conv_gflop_per_clip": round(flops / roof_steps / B / 1e9, 2),
                            "achieved": round(whole, 2), "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4)},
             "all_conv_launches": {"achieved": round(all_tf, 2), "frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                                  "ms_per_step": round(ms / steps, 3), "launches": len(log)},
-            "per_kernel": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms_per_step": round(v[1] / steps, 3),
-                               "launches_per_step": round(v[2] / steps, 2),
+                                  "ms_per_step": round(ms / roof_steps, 3), "launches": len(log)},
+            "per_kernel": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms_per_step": round(v[1] / roof_steps, 3),
+                               "launches_per_step": round(v[2] / roof_steps, 2),
                                "avg_launch_ms": round(v[1] / v[2], 4)}
                            for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "per_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in per_kind.items()},
-            "per_kind_ms_per_step": {k: round(v[1] / steps, 3) for k, v in per_kind.items()}}
+            "per_kind_ms_per_step": {k: round(v[1] / roof_steps, 3) for k, v in per_kind.items()}}
     gc.unfreeze()
     # let the next workload start from an empty device
     del model, opt, im_q, im_k, inner

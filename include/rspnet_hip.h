@@ -239,6 +239,9 @@ int rsp_loss_fwd_bwd(const float* logits1, const float* logits2, const float* lp
 
 /* queue[:, ptr:ptr+n] = keys.T  (_dequeue_and_enqueue, :345-359); keys [n][dim]. */
 int rsp_queue_enqueue(float* queue, int32_t dim, int32_t K, int32_t ptr, const float* keys, int32_t n, void* stream);
+/* The same with the pointer in device memory: reads *ptr_dev (the module's int64 queue_ptr buffer, :332), writes the slab and
+ * advances *ptr_dev by n modulo K (:356-359).  No host-side pointer: a step captured in a HIP graph replays correctly. */
+int rsp_queue_enqueue_dev(float* queue, int32_t dim, int32_t K, int64_t* ptr_dev, const float* keys, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Step glue

@@ -107,6 +107,7 @@ SIGNATURES = {
     "rsp_logits_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
     "rsp_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "rsp_queue_enqueue": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
+    "rsp_queue_enqueue_dev": (C.c_int, [_p, _i32, _i32, _p, _p, _i32, _p]),
     "rsp_clip_gather": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _p]),
     "rsp_momentum_update": (C.c_int, [_p, _p, _i64, _f, _p]),
     "rsp_sgd_step": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _f, C.c_int, _p]),

@@ -312,6 +312,21 @@ __global__ void enqueue_kernel(float* __restrict__ queue, int dim, int K, int pt
   queue[(long long)c * K + ptr + j] = keys[(long long)j * dim + c];
 }
 
+// The same with the write pointer read from (and advanced in) device memory — queue_ptr is a device buffer of the module
+// (builder_diffspeed_diffloss.py:332) — so that a step captured in a HIP graph needs no host-side pointer.  Two launches: every
+// workgroup of the first reads the pointer, the second moves it.
+__global__ void enqueue_dev_kernel(float* __restrict__ queue, int dim, int K, const long long* __restrict__ ptr_dev,
+                                   const float* __restrict__ keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * dim) return;
+  const int ptr = (int)*ptr_dev;
+  const int c = i / n, j = i - c * n;
+  if (ptr >= 0 && ptr + n <= K) queue[(long long)c * K + ptr + j] = keys[(long long)j * dim + c];
+}
+__global__ void enqueue_advance_kernel(long long* __restrict__ ptr_dev, int K, int n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ptr_dev = (*ptr_dev + n) % K;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // generic small pieces for the 'mlp' projection head (split_wrapper.py:171-179): mean -> Linear -> ReLU -> Linear -> L2
 // ------------------------------------------------------------------------------------------------------------------
@@ -534,6 +549,17 @@ int rsp_queue_enqueue(float* queue, int32_t dim, int32_t K, int32_t ptr, const f
   hipLaunchKernelGGL(enqueue_kernel, dim3(rsp_cdiv((long long)n * dim, 256)), dim3(256), 0, (hipStream_t)stream, queue, dim, K,
                      ptr, keys, n);
   return rsp_check_launch("enqueue_kernel");
+}
+
+int rsp_queue_enqueue_dev(float* queue, int32_t dim, int32_t K, int64_t* ptr_dev, const float* keys, int32_t n, void* stream) {
+  RSP_REQUIRE(queue && keys && ptr_dev, "rsp_queue_enqueue_dev: null pointer");
+  RSP_REQUIRE(dim > 0 && K > 0 && n > 0 && n <= K && K % n == 0, "rsp_queue_enqueue_dev: K must be a multiple of the batch");
+  hipLaunchKernelGGL(enqueue_dev_kernel, dim3(rsp_cdiv((long long)n * dim, 256)), dim3(256), 0, (hipStream_t)stream, queue, dim, K,
+                     reinterpret_cast<const long long*>(ptr_dev), keys, n);
+  int rc = rsp_check_launch("enqueue_dev_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(enqueue_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<long long*>(ptr_dev), K, n);
+  return rsp_check_launch("enqueue_advance_kernel");
 }
 
 int rsp_spatial_mean_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t ld, float* mean, void* stream) {

@@ -40,6 +40,7 @@ class ConvBN:
     pool: Optional[Tuple[Triple, Triple]] = None   # (kernel, stride), disjoint windows only
     residual: Optional[int] = None                 # slot added before the ReLU
     into: Optional[Tuple[int, int, int]] = None    # (concat slot, channel offset, total channels): write a slice
+    branch: int = 0                                # > 0: node of a side branch that may run beside its siblings (BranchStreams)
     cout_pad: int = 0                              # run with Cout zero-padded to this many channels (0: as is).  R(2+1)D's
     #   mid-channel counts (83, 230, 921 ...) are not multiples of 4; padded, this conv's output and the next conv's input are
     #   16-byte rows and both take the LDS-DMA kernels instead of the scalar gather.  Pad channels carry zero weights and
@@ -89,6 +90,7 @@ class Pool:
     k: Triple
     s: Triple
     p: Triple = (0, 0, 0)
+    branch: int = 0
 
 
 @dataclass
@@ -98,6 +100,7 @@ class Gate:
     src: int
     dst: int
     into: Optional[Tuple[int, int, int]] = None
+    branch: int = 0
 
 
 @dataclass
@@ -207,6 +210,47 @@ def _pad_vec(v: torch.Tensor, n: int, fill: float = 0.0) -> torch.Tensor:
 INPUT_CHANNEL_PAD = 4
 
 
+class BranchStreams:
+    """Side branches of a block (S3D-G's inception branches 1-3, models/s3dg.py:80-99) on their own HIP streams — while the step is
+    being CAPTURED into a HIP graph (rspnet_amd/graph_step.py).  The late blocks launch a few dozen workgroups per kernel; as
+    graph nodes without a common stream order four of them run side by side (tools/stream_overlap_probe.py: x1.14-1.31 on one
+    block).  Issued eagerly the same forks gain nothing (x1.0: the host feeds one kernel at a time), so outside a capture
+    every node stays on the caller's stream.
+
+    Ordering: a side stream first waits for the trunk (its inputs — and every earlier reader of memory its allocator pool may
+    recycle — are complete), the trunk waits for all side streams when the next trunk node comes up; a tensor produced on a
+    side stream is consumed there or, after that join, on the trunk."""
+    _streams: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
+
+    def __init__(self, x: torch.Tensor):
+        self.dev = x.device
+        self.on = bool(x.is_cuda and _ops.backend().name == "hip" and torch.cuda.is_current_stream_capturing())
+        self.active: Dict[int, "torch.cuda.Stream"] = {}
+
+    def run(self, node, fn):
+        br = getattr(node, "branch", 0) if self.on else 0
+        if br == 0:
+            self.join()
+            return fn()
+        st = self.active.get(br)
+        if st is None:
+            key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(), br)
+            st = BranchStreams._streams.get(key)
+            if st is None:
+                st = BranchStreams._streams[key] = torch.cuda.Stream(device=self.dev)
+            st.wait_stream(torch.cuda.current_stream(self.dev))
+            self.active[br] = st
+        with torch.cuda.stream(st):
+            return fn()
+
+    def join(self):
+        if self.active:
+            main = torch.cuda.current_stream(self.dev)
+            for st in self.active.values():
+                main.wait_stream(st)
+            self.active = {}
+
+
 def _slice_of(slots, into, lead_shape, device):
     """Channel-slice view of a concat tensor, allocating the tensor on first use."""
     slot, off, total = into
@@ -307,7 +351,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         if keep:
             ctx.saved[ni] = ("group", xin, y, cg, per)
 
-    for ni, node in enumerate(plan.nodes):
+    def run_node(ni, node):
         if isinstance(node, ConvBN):
             convbn(node, ni)
         elif isinstance(node, ConvBNGroup):
@@ -341,6 +385,11 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
                 ctx.saved[ni] = (xin, mean, gate)
         else:
             raise NotImplementedError(f"plan node {type(node).__name__}")
+
+    branches = BranchStreams(x)
+    for ni, node in enumerate(plan.nodes):
+        branches.run(node, lambda: run_node(ni, node))
+    branches.join()
     out = slots[plan.output_slot]
     if keep:
         ctx.feat_shape = tuple(out.shape)
@@ -423,8 +472,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
         if ms[0].src != plan.input_slot or want_input_grad:
             add_grad(ms[0].src, be.conv_dgrad_packed(cg, dy_cat, packed.get_dgrad(node._cat_node(), cg)))
 
-    for ni in range(len(plan.nodes) - 1, -1, -1):
-        node = plan.nodes[ni]
+    def run_node(ni, node):
         if isinstance(node, ConvBN):
             convbn_bwd(node, ni, ni)
         elif isinstance(node, ConvBNGroup):
@@ -452,4 +500,12 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 after_param_grads(ni)
         else:
             raise NotImplementedError(f"plan node {type(node).__name__}")
+
+    # (side branches of a block — engine.BranchStreams — each own their slots; the fan-out sum at the block's input happens on the
+    #  trunk after the join: the block's last backward node, the grouped pointwise convolution, is a trunk node)
+    branches = BranchStreams(dfeat)
+    for ni in range(len(plan.nodes) - 1, -1, -1):
+        node = plan.nodes[ni]
+        branches.run(node, lambda: run_node(ni, node))
+    branches.join()
     return dslots.get(plan.input_slot) if want_input_grad else None

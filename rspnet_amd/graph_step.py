@@ -1,0 +1,129 @@
+"""The pretext step as ONE HIP graph.
+
+The reference's loop body (pretrain.py:157-165) —
+
+    output, target, ranking_logits, ranking_target = model(clip_q, clip_k)
+    loss, loss_A, loss_M = criterion(output, target, ranking_logits, ranking_target)
+    optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+— issues 250 (C3D) to 2 000 (S3D-G) kernel launches from Python.  `GraphedPretextStep` runs exactly these five statements under
+HIP stream capture once per (speed, learning rate, input shape) and replays the captured graph afterwards: no Python and no
+launch call per kernel, and — since a graph carries dependencies instead of one stream's order — S3D-G's independent inception
+branches (models/s3dg.py:80-99) are forked onto side streams inside the capture and run next to each other
+(engine.run_forward / run_backward; measured on one sepInc block, tools/stream_overlap_probe.py: x1.14-1.31 as a graph, x1.0
+issued eagerly).
+
+What stays on the host per step is what is DECIDED there: the speed drawn from diff_speed and the two shuffle-BN permutations
+(builder_diffspeed_diffloss.py:372,430 — `MoCoDiffLossTwoFc._host_part`); their index vectors are written into a static
+pinned buffer and copied to a static device buffer before the replay.  Everything else of the reference step is inside the
+graph: momentum update, the device-side randperm of _diff_speed (graph-safe Philox offsets), both key passes, query forward,
+logits, losses, backward, SGD, enqueue (pointer read and advanced on the device: rsp_queue_enqueue_dev).
+
+Single rank only (the collectives of the data-parallel path are issued eagerly); any failure to capture falls back to the
+eager loop with a logged warning — the result is the same either way, kernel for kernel.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+log = logging.getLogger(__name__)
+
+
+class GraphedPretextStep:
+    RING = 8
+
+    def __init__(self, model, criterion, optimizer, warmup: int = 2):
+        self.wrapped = model
+        self.model = getattr(model, "module", model)
+        self.criterion, self.optimizer = criterion, optimizer
+        self.warmup = max(1, int(warmup))
+        self.graphs: Dict[Tuple, Tuple] = {}
+        self.eager_steps: Dict[Tuple, int] = {}
+        self.static = None
+        self.disabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.fallback_reason = "more than one rank" if self.disabled else None
+
+    # ---- the five statements ------------------------------------------------------------------------------------------------
+    def _eager(self, im_q, im_k, host):
+        out, tgt, rl, rt = self.model._device_part(im_q, im_k, host)
+        loss, loss_A, loss_M = self.criterion(out, tgt, rl, rt)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return loss, loss_A, loss_M, out, rl, tgt, rt
+
+    def _key(self, im_q, host):
+        lrs = tuple(float(g["lr"]) for g in self.optimizer.param_groups)
+        return (host["speed"], tuple(im_q.shape), lrs)
+
+    def __call__(self, im_q, im_k):
+        """One training step.  Returns (loss, loss_A, loss_M, output, ranking_logits) — the tensors of a replayed step are the
+        graph's own output buffers: read them before the next call."""
+        m = self.model
+        B, dev = im_q.shape[0], im_q.device
+        if self.disabled or dev.type != "cuda":
+            return self._eager(im_q, im_k, m._host_part(B, dev))[:5]
+        if self.static is None:
+            n = 4 * B * (dist.get_world_size() if dist.is_initialized() else 1)
+            # the host runs several steps ahead of the GPU: a ring of pinned staging buffers, each guarded by the event of the
+            # copy that last read it (re-filling a slot waits for that copy — back-pressure only if the GPU is RING steps behind)
+            self.static = {"ring": [[torch.empty(n, dtype=torch.int32, pin_memory=True), None] for _ in range(self.RING)],
+                           "turn": 0, "dev": torch.empty(n, dtype=torch.int32, device=dev),
+                           "im_q": torch.empty_like(im_q), "im_k": torch.empty_like(im_k)}
+            m._ptr_on_device = True
+            m._ptr_host = None
+        st = self.static
+        if im_q.shape != st["im_q"].shape:
+            raise ValueError("GraphedPretextStep: the clip shape changed; build a new GraphedPretextStep for it")
+        if im_q.data_ptr() != st["im_q"].data_ptr():
+            st["im_q"].copy_(im_q, non_blocking=True)
+        if im_k.data_ptr() != st["im_k"].data_ptr():
+            st["im_k"].copy_(im_k, non_blocking=True)
+        slot = st["ring"][st["turn"] % self.RING]
+        st["turn"] += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        host = m._host_part(B, dev, static=(slot[0], st["dev"]))
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        key = self._key(im_q, host)
+        entry = self.graphs.get(key)
+        if entry is None:
+            # the first steps of a configuration run eagerly (lazy initialisation inside the library, allocator pools, the
+            # optimizer's momentum buffers, packed-weight sets), then the configuration is captured
+            done = self.eager_steps.get(key, 0)
+            if done < self.warmup:
+                self.eager_steps[key] = done + 1
+                return self._eager(st["im_q"], st["im_k"], host)[:5]
+            entry = self._capture(key, host)
+            if entry is None:
+                return self._eager(st["im_q"], st["im_k"], host)[:5]
+        graph, outs = entry
+        graph.replay()
+        return outs
+
+    def _capture(self, key, host):
+        from . import ops as _ops
+        st = self.static
+        be = _ops.backend()
+        if getattr(be, "event_log", None) is not None:
+            return None                                  # per-launch timing events cannot be recorded inside a capture
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, loss_A, loss_M, out, rl, _, _ = self._eager(st["im_q"], st["im_k"], host)
+            outs = (loss, loss_A, loss_M, out, rl)
+            self.graphs[key] = (g, outs)
+            log.info("rspnet_amd: pretext step captured as a HIP graph (speed %s, clips %s)", key[0], key[1])
+            # the capture itself executed nothing: run the step it stands for
+            return self.graphs[key]
+        except Exception as e:      # noqa: BLE001 - whatever refuses the capture, the eager loop still works
+            self.disabled, self.fallback_reason = True, f"{type(e).__name__}: {e}"
+            log.warning("rspnet_amd: HIP-graph capture of the pretext step failed (%s); running eagerly", self.fallback_reason)
+            torch.cuda.synchronize()
+            return None

@@ -157,6 +157,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._flat: Optional[FlatEncoderPair] = None
         self._q_params: List[nn.Parameter] = []
         self._ptr_host: Optional[int] = None
+        self._ptr_on_device = False           # True: queue_ptr lives on the device only (graph-captured steps)
         self._cpu_group = None
         self._last_q = None
         self._last_k = []
@@ -381,10 +382,15 @@ class MoCoDiffLossTwoFc(nn.Module):
     def _dequeue_and_enqueue(self, keys_all: Tensor):
         """:345-359 — keys_all is already the rank-ordered concat of k_neg_A over all ranks."""
         n = keys_all.shape[0]
+        assert self.K % n == 0  # for simplicity (reference :353)
+        if self._ptr_on_device:
+            # graph-captured steps (rspnet_amd/graph_step.py): the pointer is read and advanced on the device
+            _ops.backend().queue_enqueue_dev(self.queue, self.queue_ptr, keys_all.contiguous())
+            self._ptr_host = None
+            return
         if self._ptr_host is None:
             self._ptr_host = int(self.queue_ptr)
         ptr = self._ptr_host
-        assert self.K % n == 0  # for simplicity (reference :353)
         _ops.backend().queue_enqueue(self.queue, ptr, keys_all.contiguous())
         ptr = (ptr + n) % self.K
         self._ptr_host = ptr
@@ -424,9 +430,35 @@ class MoCoDiffLossTwoFc(nn.Module):
         flat.attach_grads()
 
     # ---- forward ------------------------------------------------------------------------------------------------------
+    def _host_part(self, B: int, dev, static=None):
+        """Everything of a step that is decided on the host: the speed drawn from diff_speed, both shuffle-BN permutations, the
+        exchange plans derived from them, and their index vectors on the device.  `static` (rspnet_amd/graph_step.py): a
+        (pinned staging tensor, device tensor) pair of 4*B*ws int32 the index vectors are written to IN PLACE, so that a step
+        captured in a HIP graph reads this step's permutations at replay."""
+        rank, ws = _world()
+        speed, sh1, sh2 = self._draw_step_randomness(B)
+        plan1, plan2 = self._exchange_plan(sh1, B, rank, ws), self._exchange_plan(sh2, B, rank, ws)
+        arrays = plan1[:2] + plan2[:2]
+        if static is None:
+            src1, loc1, src2, loc2 = self._upload_indices(arrays, dev)
+        else:
+            host, devt = static
+            hv, off, views = host.numpy(), 0, []
+            for a in arrays:
+                hv[off:off + a.size] = a
+                views.append(devt[off:off + a.size])
+                off += a.size
+            devt.copy_(host, non_blocking=True)
+            src1, loc1, src2, loc2 = views
+        return {"speed": speed, "sh": (sh1, sh2), "plans": (plan1, plan2), "idx": (src1, loc1, src2, loc2)}
+
     def forward(self, im_q: Tensor, im_k: Tensor):
         """im_q, im_k: (B, 3, T=speed*16, H, W) fp32 on this rank's device.  Returns
         ((logits1, logits2), labels_A, (l_pos_M, l_neg_M), labels_M) exactly as the reference (:492-547)."""
+        return self._device_part(im_q, im_k, self._host_part(im_q.shape[0], im_q.device))
+
+    def _device_part(self, im_q: Tensor, im_k: Tensor, host):
+        """The step's device work under the host decisions of `_host_part` (one function, so that it can be captured whole)."""
         be = _ops.backend()
         self._prepare()
         dev = im_q.device
@@ -438,7 +470,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             # _diff_speed (:421-447)
             random_indices = torch.randperm(B, device=dev)
             n1 = int(B * self.alpha)
-            speed, sh1, sh2 = self._draw_step_randomness(B)
+            speed, (sh1, sh2) = host["speed"], host["sh"]
             self._last_speed = speed
             # introspection only (parity checks replay the step on the checker with the same draws): device tensor, not read here
             self._last_draw = (random_indices, speed, sh1, sh2)
@@ -446,9 +478,8 @@ class MoCoDiffLossTwoFc(nn.Module):
             step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
             step_q.index_fill_(0, random_indices[:n1], 1)               # s1 rows play q,k at normal speed
             step_kn = (1 + speed) - step_q if speed != 1 else step_q.clone()   # k_negative swaps the speeds
-            rank, ws = _world()
-            plan1, plan2 = self._exchange_plan(sh1, B, rank, ws), self._exchange_plan(sh2, B, rank, ws)
-            src1, loc1, src2, loc2 = self._upload_indices(plan1[:2] + plan2[:2], dev)
+            plan1, plan2 = host["plans"]
+            src1, loc1, src2, loc2 = host["idx"]
             # both shuffle-BN exchanges and the query clips are issued up front (one all-to-all each at > 1 rank: the second
             # one overlaps the first key pass); the key passes keep the reference's order (k_negative first, :445, then k, :512)
             ex_neg = self._shuffle_exchange(im_k, step_kn, T_real, plan1, src1, loc1)

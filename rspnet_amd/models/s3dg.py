@@ -80,17 +80,17 @@ class S3D_G(nn.Module):
             counter[0] += 1
             return counter[0] - 1
 
-        def basic(m: BasicConv3d, src, into=None):
+        def basic(m: BasicConv3d, src, into=None, branch=0):
             dst = new()
             k, s, p = m.geom
-            nodes.append(ConvBN(m.conv3d, m.bn, src, dst, k, s, p, relu=True, into=into))
+            nodes.append(ConvBN(m.conv3d, m.bn, src, dst, k, s, p, relu=True, into=into, branch=branch))
             return dst
 
-        def sep(m: sep_conv, src, into=None):
-            a = basic(m.sep_conv[0], src)
-            b = basic(m.sep_conv[1], a)
+        def sep(m: sep_conv, src, into=None, branch=0):
+            a = basic(m.sep_conv[0], src, branch=branch)
+            b = basic(m.sep_conv[1], a, branch=branch)
             dst = new()
-            nodes.append(Gate(m.excitation, b, dst, into=into))
+            nodes.append(Gate(m.excitation, b, dst, into=into, branch=branch))
             return dst
 
         cur = 0
@@ -113,11 +113,13 @@ class S3D_G(nn.Module):
                 b1 = basic(m.branch1[0], cur)
                 b2 = basic(m.branch2[0], cur)
                 nodes[first:] = [ConvBNGroup(nodes[first:])]
-                sep(m.branch1[1], b1, into=(cat, offs[1], total))
-                sep(m.branch2[1], b2, into=(cat, offs[2], total))
+                # branches 1-3 are independent from here on: as nodes of a captured HIP graph they run side by side
+                # (engine.BranchStreams)
+                sep(m.branch1[1], b1, into=(cat, offs[1], total), branch=1)
+                sep(m.branch2[1], b2, into=(cat, offs[2], total), branch=2)
                 pooled = new()
-                nodes.append(Pool(cur, pooled, (3, 3, 3), (1, 1, 1), (1, 1, 1)))
-                basic(m.branch3[1], pooled, into=(cat, offs[3], total))
+                nodes.append(Pool(cur, pooled, (3, 3, 3), (1, 1, 1), (1, 1, 1), branch=3))
+                basic(m.branch3[1], pooled, into=(cat, offs[3], total), branch=3)
                 cur = cat
         return Plan(nodes, input_slot=0, output_slot=cur)
 

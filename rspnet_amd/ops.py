@@ -493,6 +493,13 @@ class HipOps:
         _lib.check(self.lib.rsp_queue_enqueue(_ptr(_chk(queue, "queue")), dim, K, ptr, _ptr(_chk(keys, "keys")),
                                               keys.shape[0], _stream()), "rsp_queue_enqueue")
 
+    def queue_enqueue_dev(self, queue, queue_ptr, keys):
+        """queue[:, ptr:ptr+n] = keys.T with ptr read from / advanced in the device buffer `queue_ptr` (int64, 1 element)."""
+        dim, K = queue.shape
+        _chk(queue_ptr, "queue_ptr", torch.int64)
+        _lib.check(self.lib.rsp_queue_enqueue_dev(_ptr(_chk(queue, "queue")), dim, K, _ptr(queue_ptr), _ptr(_chk(keys, "keys")),
+                                                  keys.shape[0], _stream()), "rsp_queue_enqueue_dev")
+
     # ---- glue -------------------------------------------------------------------------------------------------
     def clip_gather(self, im, src, step, T_out: int, c_out: Optional[int] = None):
         _chk(im, "im")

@@ -237,6 +237,11 @@ class CpuOps:
     def queue_enqueue(self, queue, ptr, keys):
         queue[:, ptr:ptr + keys.shape[0]] = keys.t()
 
+    def queue_enqueue_dev(self, queue, queue_ptr, keys):
+        ptr, n = int(queue_ptr), keys.shape[0]
+        queue[:, ptr:ptr + n] = keys.t()
+        queue_ptr.fill_((ptr + n) % queue.shape[1])
+
     def clip_gather(self, im, src, step, T_out, c_out=None):
         out = torch.zeros((src.shape[0], T_out, im.shape[3], im.shape[4], c_out or im.shape[1]), dtype=im.dtype)
         for j in range(src.shape[0]):

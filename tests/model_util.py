@@ -13,22 +13,28 @@ def make_cfg(arch, K, fc_type="linear", dim=128, m=0.999, T=0.07, speeds=(2,)):
 
 
 class ReplayRNG:
-    """Replays torch.randperm / random.choice in call order (same trick as oracle/ref_harness.py)."""
+    """Replays torch.randperm / random.choice (same trick as oracle/ref_harness.py).  perms = [the _diff_speed permutation of
+    range(B) — the model draws it on the DEVICE generator (builder_diffspeed_diffloss.py:423) —, shuffle #1, shuffle #2 — drawn on
+    the host generator (:372), in call order].  The product draws its host-side decisions before the device part of the step
+    (MoCoDiffLossTwoFc._host_part), so the two kinds are told apart by the `device=` argument, not by position."""
 
     def __init__(self, perms, speed):
         self.perms = [torch.from_numpy(np.asarray(p, dtype=np.int64)) for p in perms]
         self.speed = speed
-        self.n = 0
+        self.n = 1
 
     def __enter__(self):
         self._rp, self._ch = torch.randperm, random.choice
 
         def randperm(n, *a, **k):
-            p = self.perms[self.n]
-            assert p.numel() == n, (p.numel(), n)
-            self.n += 1
-            out = p.clone()
             dev = k.get("device")
+            if dev is not None:
+                p = self.perms[0]
+            else:
+                p = self.perms[self.n]
+                self.n += 1
+            assert p.numel() == n, (p.numel(), n)
+            out = p.clone()
             return out.to(dev) if dev is not None else out
 
         torch.randperm = randperm

@@ -1,0 +1,63 @@
+"""GPU: the pretext step captured as a HIP graph (rspnet_amd/graph_step.py) is the eager step, kernel for kernel: several
+consecutive steps of two identically initialised models — one driven by the reference's five-statement loop body
+(pretrain.py:157-165), one by GraphedPretextStep — must leave bit-identical losses, logits, parameters, queue and pointer."""
+import random
+
+import pytest
+import torch
+
+from golden_util import load_spec
+from model_util import make_cfg
+from oracle import portable as P
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _build(arch, K):
+    from rspnet_amd.moco import Loss, ModelFactory
+    from rspnet_amd.optim import SGD
+    wrapped = ModelFactory(make_cfg(arch, K)).build_moco_diffloss(device=DEV)
+    spec = dict(load_spec(arch))
+    spec["queue"] = ((128, K), "float32")
+    state = P.fill_state(spec, 3)
+    wrapped.module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    wrapped.train()
+    opt = SGD(wrapped.parameters(), lr=0.05, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=False)
+    return wrapped, Loss(margin=2.0, A=1.0, M=1.0), opt
+
+
+@pytest.mark.parametrize("arch,B,HW", [("c3d", 4, 32), ("s3dg", 4, 64), ("resnet18", 8, 64)])
+def test_graphed_step_equals_eager_step(arch, B, HW):
+    from rspnet_amd.graph_step import GraphedPretextStep
+    K, steps = 64, 6
+    clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(10 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
+    results = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        random.seed(7)
+        wrapped, crit, opt = _build(arch, K)
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2) if mode == "graph" else None
+        trace = []
+        for im_q, im_k in clips:
+            if stepper is None:
+                out, tgt, rl, rt = wrapped(im_q, im_k)
+                loss, la, lm = crit(out, tgt, rl, rt)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            else:
+                loss, la, lm, out, rl = stepper(im_q, im_k)
+            trace.append((loss.detach().clone(), out[0].detach().clone(), rl[0].detach().clone()))
+        torch.cuda.synchronize()
+        if stepper is not None:
+            assert not stepper.disabled, stepper.fallback_reason
+            assert len(stepper.graphs) == 1                      # warm-up steps ran eagerly, the rest replayed one graph
+        results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
+    (te, se), (tg, sg) = results
+    for i, ((l0, o0, r0), (l1, o1, r1)) in enumerate(zip(te, tg)):
+        assert torch.equal(l0, l1) and torch.equal(o0, o1) and torch.equal(r0, r1), (arch, "step", i, float(l0), float(l1))
+    assert int(sg["queue_ptr"]) == int(se["queue_ptr"]) == (steps * B) % K
+    for k in se:
+        assert torch.equal(se[k], sg[k]), (arch, k)
