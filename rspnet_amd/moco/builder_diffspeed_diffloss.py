@@ -13,6 +13,7 @@ the key passes, two train-mode key passes, queue enqueue of k_neg_A).  What diff
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import List, Optional, Tuple
 
@@ -107,7 +108,8 @@ class _PretextFn(torch.autograd.Function):
     def forward(ctx, model: "MoCoDiffLossTwoFc", x_q: Tensor, keys, *params):
         be = _ops.backend()
         with torch.no_grad():
-            q_A, q_M, ectx = model.encoder_q.forward_ndhwc(x_q, keep=True)
+            pre, model._q_pre = model._q_pre, None
+            q_A, q_M, ectx = pre if pre is not None else model.encoder_q.forward_ndhwc(x_q, keep=True)
             k_A, k_M, kneg_A, kneg_M = keys
             queue = model.queue
             l1, l2, lp, ln = be.logits_fwd(q_A, q_M, k_A, k_M, kneg_A, kneg_M, queue, 1.0 / model.T)
@@ -158,6 +160,9 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._q_params: List[nn.Parameter] = []
         self._ptr_host: Optional[int] = None
         self._ptr_on_device = False           # True: queue_ptr lives on the device only (graph-captured steps)
+        self.overlap_query = not os.environ.get("RSP_NO_QOVERLAP")     # (switch for A/B runs of tools/)
+        self._query_stream = None
+        self._q_pre = None
         self._cpu_group = None
         self._last_q = None
         self._last_k = []
@@ -486,12 +491,24 @@ class MoCoDiffLossTwoFc(nn.Module):
             ex_k = self._shuffle_exchange(im_k, step_q, T_real, plan2, src2, loc2)
             src = torch.arange(B, dtype=torch.int32, device=dev)
             x_q = be.clip_gather(im_q, src, step_q, T_real, max(C, INPUT_CHANNEL_PAD))
+            self._nbt_q += 1
+            # The query encoder's forward does not depend on the key passes (other weights, other BatchNorm buffers) before the
+            # logits.  Inside a captured HIP graph (rspnet_amd/graph_step.py) it is forked onto its own stream and runs beside them:
+            # the small late layers of either pass leave most of the machine idle on their own.
+            side = None
+            if self.overlap_query and dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                main = torch.cuda.current_stream(dev)
+                side = self._query_stream = self._query_stream or torch.cuda.Stream(device=dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._q_pre = self.encoder_q.forward_ndhwc(x_q, keep=True)
             kneg_mine, kneg_all, dim = self._key_pass(ex_neg, "kneg")
             k_mine, _, _ = self._key_pass(ex_k, "k")
             del ex_neg, ex_k
             k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
             kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
-            self._nbt_q += 1
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
 
         l1, l2, lp, ln = _PretextFn.apply(self, x_q, (k_A, k_M, kneg_A, kneg_M), *self._q_params)
 
