@@ -15,6 +15,7 @@ Activations are (N, D, H, W, C) tensors.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
