@@ -15,7 +15,6 @@ Activations are (N, D, H, W, C) tensors.
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -218,25 +217,22 @@ class BranchStreams:
     block).  Issued eagerly the same forks gain nothing (x1.0: the host feeds one kernel at a time), so outside a capture
     every node stays on the caller's stream.
 
+    Forks are FLAT: only the stream the capture began on (`origin`) forks, and everything joins back into it.  ROCm 7.2's
+    hipStreamEndCapture dies with a segmentation fault on a stream forked from a forked stream (tools/graph_nest_probe.py), so a
+    pass that itself runs on a side stream (the query forward beside the key passes) keeps its branches in line.
+
     Ordering: a side stream first waits for the trunk (its inputs — and every earlier reader of memory its allocator pool may
     recycle — are complete), the trunk waits for all side streams when the next trunk node comes up; a tensor produced on a
     side stream is consumed there or, after that join, on the trunk."""
     _streams: Dict[Tuple, "torch.cuda.Stream"] = {}
-    SMALL_WGRAD_FLOPS = 50e9      # weight gradients below this size run beside the input gradient (see side_task)
+    origin = None          # raw handle of the capturing stream, set by GraphedPretextStep around the capture
 
     def __init__(self, x: torch.Tensor):
         self.dev = x.device
-        self.on = bool(x.is_cuda and _ops.backend().name == "hip" and torch.cuda.is_current_stream_capturing())
+        self.on = bool(x.is_cuda and _ops.backend().name == "hip" and BranchStreams.origin is not None
+                       and torch.cuda.is_current_stream_capturing()
+                       and torch.cuda.current_stream(self.dev).cuda_stream == BranchStreams.origin)
         self.active: Dict[int, "torch.cuda.Stream"] = {}
-        self.pending: Dict[int, Tuple] = {}          # raw handle of a stream -> (its task stream, tensors the task still reads)
-        self.tasks_on = self.on and not os.environ.get("RSP_NO_WFORK")
-
-    def _stream(self, *key):
-        key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(),) + key
-        st = BranchStreams._streams.get(key)
-        if st is None:
-            st = BranchStreams._streams[key] = torch.cuda.Stream(device=self.dev)
-        return st
 
     def run(self, node, fn):
         br = getattr(node, "branch", 0) if self.on else 0
@@ -245,44 +241,23 @@ class BranchStreams:
             return fn()
         st = self.active.get(br)
         if st is None:
-            trunk = torch.cuda.current_stream(self.dev)
-            st = self._stream(trunk.cuda_stream, br)
-            st.wait_stream(trunk)
+            key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(), br)
+            st = BranchStreams._streams.get(key)
+            if st is None:
+                st = BranchStreams._streams[key] = torch.cuda.Stream(device=self.dev)
+            st.wait_stream(torch.cuda.current_stream(self.dev))
             self.active[br] = st
         with torch.cuda.stream(st):
             return fn()
-
-    def side_task(self, fn, keepalive):
-        """Run `fn` (a kernel sequence whose results nobody reads before the end of the pass: a small weight gradient) on a task
-        stream beside the current one; at most one task per stream is outstanding, the previous one is joined first.
-        `keepalive`: the tensors it reads — held until the join so that their memory is not handed out again underneath it."""
-        if not self.tasks_on:
-            return fn()
-        cur = torch.cuda.current_stream(self.dev)
-        self._join_task(cur)
-        ts = self._stream(cur.cuda_stream, "task")
-        ts.wait_stream(cur)
-        with torch.cuda.stream(ts):
-            fn()
-        self.pending[cur.cuda_stream] = (ts, keepalive)
-
-    def _join_task(self, cur):
-        t = self.pending.pop(cur.cuda_stream, None)
-        if t is not None:
-            cur.wait_stream(t[0])
 
     def join(self):
         if self.active:
             main = torch.cuda.current_stream(self.dev)
             for st in self.active.values():
-                self._join_task(st)
                 main.wait_stream(st)
             self.active = {}
 
-    def finish(self):
-        if self.on:
-            self.join()
-            self._join_task(torch.cuda.current_stream(self.dev))
+    finish = join
 
 
 def _slice_of(slots, into, lead_shape, device):
@@ -471,13 +446,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 # batch mean); the reference's autograd produces ~1e-8 rounding noise there.
                 gb.zero_()
         # (a channel-padded geometry writes only the parameter's own channels: the reduce drops the padding's gradients)
-        gw = grad_of(node.conv.weight)
-        if sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS:
-            # a small weight gradient leaves most of the machine idle and nothing reads it before the optimizer: inside a captured
-            # graph it runs beside this unit's input gradient and the next unit's BatchNorm backward
-            branches.side_task(lambda: be.conv_wgrad(sv.cg, sv.x, dy, gw), (sv.x, dy))
-        else:
-            be.conv_wgrad(sv.cg, sv.x, dy, gw)
+        be.conv_wgrad(sv.cg, sv.x, dy, grad_of(node.conv.weight))
         if after_param_grads is not None:
             after_param_grads(ni)
         if node.src != plan.input_slot or want_input_grad:

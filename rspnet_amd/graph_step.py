@@ -114,9 +114,14 @@ class GraphedPretextStep:
             return None                                  # per-launch timing events cannot be recorded inside a capture
         try:
             torch.cuda.synchronize()
+            from .engine import BranchStreams
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                loss, loss_A, loss_M, out, rl, _, _ = self._eager(st["im_q"], st["im_k"], host)
+            try:
+                with torch.cuda.graph(g):
+                    BranchStreams.origin = torch.cuda.current_stream(st["dev"].device).cuda_stream
+                    loss, loss_A, loss_M, out, rl, _, _ = self._eager(st["im_q"], st["im_k"], host)
+            finally:
+                BranchStreams.origin = None
             outs = (loss, loss_A, loss_M, out, rl)
             self.graphs[key] = (g, outs)
             log.info("rspnet_amd: pretext step captured as a HIP graph (speed %s, clips %s)", key[0], key[1])
