@@ -489,7 +489,8 @@ def run_rank(args):
                        "global_batch": B * ws, "parallelism": f"dp{ws}"},
             "final_loss": round(m["final_loss"], 5),
         }
-        for k in ("steps_ms", "comm_ms", "roofline"):
+        res["config"]["step_issue"] = "one replayed HIP graph (rspnet_amd/graph_step.py)" if m["graph"] else "eager launches"
+        for k in ("steps_ms", "comm_ms", "roofline", "graph_fallback"):
             if k in m:
                 res[k] = m[k]
     # BASELINE.json configs 3-5 on the same box (N=1, default run only): the other three backbones at their own batch / clip
@@ -508,7 +509,9 @@ def run_rank(args):
                             "conv_launches_frac": rf["all_conv_launches"]["frac"],
                             "conv_ms_per_step": rf["all_conv_launches"]["ms_per_step"],
                             "dominant_kernel": rf["kernel"], "dominant_kernel_frac": rf["frac"],
-                            "dominant_kernel_share_of_step": rf["share_of_step"], "final_loss": round(om["final_loss"], 5)}
+                            "dominant_kernel_share_of_step": rf["share_of_step"], "final_loss": round(om["final_loss"], 5),
+                            "step_issue": "one replayed HIP graph; roofline numbers from an eager pass of the same step" if om["graph"]
+                            else "eager launches" + (f" (graph capture fell back: {om['graph_fallback']})" if "graph_fallback" in om else "")}
         res["other_workloads"] = others
     if rank == 0:
         if want_cpu:

@@ -105,6 +105,7 @@ class SyntheticVideoClips:
 class Engine:
     def __init__(self, args, cfg: dict, local_rank: int, train_loader=None):
         self.args, self.cfg, self.local_rank = args, cfg, local_rank
+        self._stepper, self._first_epoch = None, 0
         self.device = torch.device("cuda", local_rank)
         self.model = ModelFactory(cfg).build_moco_diffloss(device=self.device)
         self.criterion = Loss(margin=2.0, A=float(cfg["loss_lambda"]["A"]), M=float(cfg["loss_lambda"]["M"]))
@@ -157,6 +158,10 @@ class Engine:
         sums = torch.zeros(4, device=self.device)
         n = 0
         t0 = time.perf_counter()
+        if self._stepper is None and self.args.world_size <= 1 and not getattr(self.args, "no_graph", False):
+            # one rank: the five statements below run as ONE replayed HIP graph per (speed, learning rate) — rspnet_amd/graph_step.py
+            from .graph_step import GraphedPretextStep
+            self._stepper = GraphedPretextStep(self.model, self.criterion, self.optimizer)
         for it, (clip_q, clip_k) in enumerate(self.train_loader):
             if it == 2 and self.current_epoch == self._first_epoch:
                 # modules, layer plans and descriptor caches are long-lived: park them in the permanent generation so a full
@@ -164,11 +169,15 @@ class Engine:
                 import gc
                 gc.collect()
                 gc.freeze()
-            output, target, ranking_logits, ranking_target = self.model(clip_q, clip_k)
-            loss, loss_A, loss_M = self.criterion(output, target, ranking_logits, ranking_target)
-            self.optimizer.zero_grad()
-            loss.backward()
-            self.optimizer.step()
+            if self._stepper is not None:
+                loss, loss_A, loss_M, output, ranking_logits = self._stepper(clip_q, clip_k)
+                target = torch.zeros(output[0].shape[0], dtype=torch.long, device=output[0].device)   # labels_A (:540)
+            else:
+                output, target, ranking_logits, ranking_target = self.model(clip_q, clip_k)
+                loss, loss_A, loss_M = self.criterion(output, target, ranking_logits, ranking_target)
+                self.optimizer.zero_grad()
+                loss.backward()
+                self.optimizer.step()
             acc1_A, acc5_A = accuracy(output[0], target, topk=(1, 5))
             acc1_M, = accuracy(torch.cat(ranking_logits, dim=1), target, topk=(1,))
             sums += torch.stack([loss.detach(), loss_A, loss_M, acc1_A])
@@ -324,6 +333,7 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-scale-lr", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=100, help="synthetic loader length")
+    ap.add_argument("--no-graph", action="store_true", help="one rank: issue the step eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--loader", choices=("tensor", "uint8"), default="tensor",
                     help="tensor: fixed N(0,1) device clips; uint8: synthetic uint8 videos -> CPU random crop -> fused GPU augmentation")
     ap.add_argument("--run-dir", default=None, help="default: EXP/run_{id}_{timestamp}")

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _build(arch, K):
+def _build(arch, K, speeds=(2,)):
     from rspnet_amd.moco import Loss, ModelFactory
     from rspnet_amd.optim import SGD
-    wrapped = ModelFactory(make_cfg(arch, K)).build_moco_diffloss(device=DEV)
+    wrapped = ModelFactory(make_cfg(arch, K, speeds=speeds)).build_moco_diffloss(device=DEV)
     spec = dict(load_spec(arch))
     spec["queue"] = ((128, K), "float32")
     state = P.fill_state(spec, 3)
@@ -61,3 +61,44 @@ def test_graphed_step_equals_eager_step(arch, B, HW):
     assert int(sg["queue_ptr"]) == int(se["queue_ptr"]) == (steps * B) % K
     for k in se:
         assert torch.equal(se[k], sg[k]), (arch, k)
+
+
+def test_one_graph_per_speed_and_learning_rate():
+    """diff_speed = [2, 1] (random.choice per step, builder_diffspeed_diffloss.py:430) changes T_real, i.e. every shape of the step;
+    the scheduler changes the learning rate once per epoch (pretrain.py:75-79).  Each (speed, lr) configuration gets its own
+    captured graph after its own eager warm-up steps; the trajectory stays bit-identical to the eager loop."""
+    from rspnet_amd.graph_step import GraphedPretextStep
+    arch, B, HW, K, steps = "c3d", 4, 32, 64, 14
+    clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(30 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
+    results = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        random.seed(11)
+        wrapped, crit, opt = _build(arch, K, speeds=(2, 1))
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=1) if mode == "graph" else None
+        losses, speeds = [], []
+        for i, (im_q, im_k) in enumerate(clips):
+            if i == 9:
+                for gr in opt.param_groups:
+                    gr["lr"] = 0.01
+            if stepper is None:
+                out, tgt, rl, rt = wrapped(im_q, im_k)
+                loss, la, lm = crit(out, tgt, rl, rt)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            else:
+                loss = stepper(im_q, im_k)[0]
+            losses.append(loss.detach().clone())
+            speeds.append(wrapped.module._last_speed)
+        torch.cuda.synchronize()
+        if stepper is not None:
+            assert not stepper.disabled, stepper.fallback_reason
+            assert len(stepper.graphs) >= 2 and {k[0] for k in stepper.graphs} <= {1, 2}
+        results.append((losses, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
+    (le, se), (lg, sg) = results
+    for i, (a, b) in enumerate(zip(le, lg)):
+        assert torch.equal(a, b), (i, float(a), float(b))
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
