@@ -40,7 +40,9 @@ class GraphedPretextStep:
         self.wrapped = model
         self.model = getattr(model, "module", model)
         self.criterion, self.optimizer = criterion, optimizer
-        self.warmup = max(1, int(warmup))
+        # at least two eager steps: the packed-weight sets an encoder builds during its first step are merged into one batched
+        # set (a host-to-device copy of the job table) when its second step re-packs them
+        self.warmup = max(2, int(warmup))
         self.graphs: Dict[Tuple, Tuple] = {}
         self.eager_steps: Dict[Tuple, int] = {}
         self.static = None
