@@ -104,9 +104,8 @@ class GraphedPretextStep:
             entry = self._capture(key, host)
             if entry is None:
                 return self._eager(st["im_q"], st["im_k"], host)[:5]
-        graph, outs = entry
-        graph.replay()
-        return outs
+        entry[0].replay()
+        return entry[1]
 
     def _capture(self, key, host):
         from . import ops as _ops
@@ -125,7 +124,13 @@ class GraphedPretextStep:
             finally:
                 BranchStreams.origin = None
             outs = (loss, loss_A, loss_M, out, rl)
-            self.graphs[key] = (g, outs)
+            # Everything the graph's kernels address that was allocated OUTSIDE the capture must outlive the graph: a later
+            # configuration (another speed: longer clips) may grow the library's scratch buffers or rebuild a packed-weight set,
+            # and the superseded buffer — still baked into this graph's kernel arguments — would be freed.
+            m = self.model
+            keep = [list(be._ws.values()), list(m.encoder_q._packed._sets), list(m.encoder_k._packed._sets), m._flat,
+                    getattr(m._flat, "m_flat", None), getattr(m, "_nbt_q", None), getattr(m, "_nbt_k", None), st]
+            self.graphs[key] = (g, outs, keep)
             log.info("rspnet_amd: pretext step captured as a HIP graph (speed %s, clips %s)", key[0], key[1])
             # the capture itself executed nothing: run the step it stands for
             return self.graphs[key]
