@@ -125,10 +125,10 @@ class GraphedPretextStep:
                 BranchStreams.origin = None
             outs = (loss, loss_A, loss_M, out, rl)
             # Everything the graph's kernels address that was allocated OUTSIDE the capture must outlive the graph: a later
-            # configuration (another speed: longer clips) may grow the library's scratch buffers or rebuild a packed-weight set,
-            # and the superseded buffer — still baked into this graph's kernel arguments — would be freed.
+            # configuration may rebuild a packed-weight set, and the superseded buffers — still baked into this graph's kernel
+            # arguments — would be freed.  (The library's scratch buffers come from the graph's own pool: ops.HipOps._workspace.)
             m = self.model
-            keep = [list(be._ws.values()), list(m.encoder_q._packed._sets), list(m.encoder_k._packed._sets), m._flat,
+            keep = [list(m.encoder_q._packed._sets), list(m.encoder_k._packed._sets), m._flat,
                     getattr(m._flat, "m_flat", None), getattr(m, "_nbt_q", None), getattr(m, "_nbt_k", None), st]
             self.graphs[key] = (g, outs, keep)
             log.info("rspnet_amd: pretext step captured as a HIP graph (speed %s, clips %s)", key[0], key[1])

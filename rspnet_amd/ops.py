@@ -189,6 +189,11 @@ class HipOps:
     # one grow-only scratch buffer per (device, stream): kernels on one stream are serialised, so they can share it; work issued
     # on different streams (independent branches of a layer graph) must not
     def _workspace(self, dev, nbytes: int) -> torch.Tensor:
+        if torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture the scratch comes from the graph's own memory pool, per call: it lives exactly as long as
+            # the graph (a cached buffer would outlive a destroyed graph's pool, or be freed under a live graph when it grows),
+            # and the pool's stream-aware reuse keeps kernels on forked streams apart
+            return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
         key = (dev, _stream().value)
         buf = self._ws.get(key)
         if buf is None or buf.numel() < nbytes:
