@@ -108,11 +108,17 @@ def run_two_ranks(arch, seed, dev):
         return call
 
     def randperm(n, *a, **k):
+        # perms = [the _diff_speed permutation (drawn with device=...), shuffle #1, shuffle #2 (host draws, in call order)]: the
+        # product draws its host-side decisions first (MoCoDiffLossTwoFc._host_part), so the kinds are told apart by `device`
         if not getattr(tls, "perms", None):
             return rp(n, *a, **k)
-        p = tls.perms.pop(0)
+        if k.get("device") is not None:
+            p = tls.perms[0]
+            assert p.numel() == n
+            return p.clone().to(k["device"])
+        p = tls.perms.pop(1)
         assert p.numel() == n
-        return p.clone().to(k["device"]) if k.get("device") is not None else p.clone()
+        return p.clone()
 
     def no_gloo(*a, **k):
         raise RuntimeError("no side group in the threaded world")
