@@ -226,6 +226,7 @@ class BranchStreams:
     side stream is consumed there or, after that join, on the trunk."""
     _streams: Dict[Tuple, "torch.cuda.Stream"] = {}
     origin = None          # raw handle of the capturing stream, set by GraphedPretextStep around the capture
+    SMALL_WGRAD_FLOPS = 50e9      # weight gradients below this size run beside the input gradient (side_task)
 
     def __init__(self, x: torch.Tensor):
         self.dev = x.device
@@ -233,6 +234,34 @@ class BranchStreams:
                        and torch.cuda.is_current_stream_capturing()
                        and torch.cuda.current_stream(self.dev).cuda_stream == BranchStreams.origin)
         self.active: Dict[int, "torch.cuda.Stream"] = {}
+        self.task = None       # (task stream, tensors its kernels still read) of the outstanding side task
+
+    def _get(self, key):
+        key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(), key)
+        st = BranchStreams._streams.get(key)
+        if st is None:
+            st = BranchStreams._streams[key] = torch.cuda.Stream(device=self.dev)
+        return st
+
+    def side_task(self, fn, keepalive):
+        """Run `fn` — a kernel sequence whose results nobody reads before the end of the pass: a SMALL weight gradient, which on
+        its own leaves most of the machine idle — on a task stream beside the trunk (R3D-18 +1.2 %, R(2+1)D +1.1 %).  Only from
+        the trunk (flat forks); one task outstanding, the previous one is joined first.  `keepalive`: the tensors it reads,
+        held until the join so that the graph's memory pool does not hand their blocks out again underneath it."""
+        cur = torch.cuda.current_stream(self.dev) if self.on else None
+        if cur is None or cur.cuda_stream != BranchStreams.origin:
+            return fn()
+        self.join_task()
+        ts = self._get("task")
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            fn()
+        self.task = (ts, keepalive)
+
+    def join_task(self):
+        if self.task is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.task[0])
+            self.task = None
 
     def run(self, node, fn):
         br = getattr(node, "branch", 0) if self.on else 0
@@ -241,10 +270,7 @@ class BranchStreams:
             return fn()
         st = self.active.get(br)
         if st is None:
-            key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(), br)
-            st = BranchStreams._streams.get(key)
-            if st is None:
-                st = BranchStreams._streams[key] = torch.cuda.Stream(device=self.dev)
+            st = self._get(br)
             st.wait_stream(torch.cuda.current_stream(self.dev))
             self.active[br] = st
         with torch.cuda.stream(st):
@@ -257,7 +283,10 @@ class BranchStreams:
                 main.wait_stream(st)
             self.active = {}
 
-    finish = join
+    def finish(self):
+        self.join()
+        if self.on:
+            self.join_task()
 
 
 def _slice_of(slots, into, lead_shape, device):
@@ -446,7 +475,11 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 # batch mean); the reference's autograd produces ~1e-8 rounding noise there.
                 gb.zero_()
         # (a channel-padded geometry writes only the parameter's own channels: the reduce drops the padding's gradients)
-        be.conv_wgrad(sv.cg, sv.x, dy, grad_of(node.conv.weight))
+        gw = grad_of(node.conv.weight)
+        if sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS:      # (a no-op outside a single-rank graph capture)
+            branches.side_task(lambda: be.conv_wgrad(sv.cg, sv.x, dy, gw), (sv.x, dy))
+        else:
+            be.conv_wgrad(sv.cg, sv.x, dy, gw)
         if after_param_grads is not None:
             after_param_grads(ni)
         if node.src != plan.input_slot or want_input_grad:

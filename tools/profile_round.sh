@@ -11,14 +11,16 @@ OUT="$R/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for a in "${ARCHS[@]}"; do
-  python3 "$R/bench.py" --arch "$a" --no-cpu-baseline > "$OUT/bench_${TAG}_$a.json" 2> "$OUT/bench_${TAG}_$a.err"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 10 --warmup 3 --no-cpu-baseline \
+  # the bench line as the driver runs it for this backbone (step issue: bench.py --graph auto), then the profiled passes with the
+  # step issued EAGERLY (--graph off): per-dispatch rows in launch order, one counter pass each
+  python3 "$R/bench.py" --arch "$a" --no-cpu-baseline --no-other-workloads > "$OUT/bench_${TAG}_$a.json" 2> "$OUT/bench_${TAG}_$a.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --graph off \
     > "$OUT/bench_under_rocprof_${TAG}_$a.json" 2> "$OUT/prof_${TAG}_$a.err"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline \
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --graph off \
     > /dev/null 2> "$OUT/pmc_fetch_${TAG}_$a.err"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline \
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --graph off \
     > /dev/null 2> "$OUT/pmc_write_${TAG}_$a.err"
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline \
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --graph off \
     > /dev/null 2> "$OUT/pmc_mfma_${TAG}_$a.err"
   # keep only the small summaries of the raw traces (the per-dispatch kernel trace of 10 steps is tens of MB)
   find "$OUT/prof_${TAG}_$a" -name '*_kernel_trace.csv' -delete
