@@ -226,7 +226,8 @@ class BranchStreams:
     side stream is consumed there or, after that join, on the trunk."""
     _streams: Dict[Tuple, "torch.cuda.Stream"] = {}
     origin = None          # raw handle of the capturing stream, set by GraphedPretextStep around the capture
-    SMALL_WGRAD_FLOPS = 50e9      # weight gradients below this size run beside the input gradient (side_task)
+    SMALL_WGRAD_FLOPS = 50e9      # weight gradients below this size run beside the input gradient (side_task); swept 50 / 120 /
+    #   300 / 1000 GFLOP: larger ones compete with the input gradient for the matrix pipe (R(2+1)D 77.9 -> 80.2 ms at 300)
 
     def __init__(self, x: torch.Tensor):
         self.dev = x.device
