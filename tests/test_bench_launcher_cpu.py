@@ -59,7 +59,7 @@ def test_launcher_deadline_kills_a_hung_job():
     the node (the driver's first multi-GPU run is the first execution of the RCCL path: a hang must be diagnosable)."""
     import time
     t0 = time.monotonic()
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-hang-rank", "1", "--deadline", "20",
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-hang-rank", "1", "--deadline", "12",
                         "--collective-timeout", "600"] + TINY, capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env())
     assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
     assert "deadline" in r.stderr and time.monotonic() - t0 < 120
@@ -71,7 +71,7 @@ def test_collective_timeout_fails_the_job():
     import time
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-hang-rank", "1", "--deadline", "600",
-                        "--collective-timeout", "10"] + TINY, capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env())
+                        "--collective-timeout", "6"] + TINY, capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env())
     assert r.returncode not in (0, 124), (r.returncode, r.stderr[-2000:])
     assert time.monotonic() - t0 < 200
 
