@@ -141,6 +141,25 @@ int rsp_bn_finalize_v(const float* stat_partials, int32_t tiles, int32_t C, int3
                       float* running_var, float* mean_invstd /*[2][C]*/, float* scale_shift /*[2][C]*/, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Deferred running statistics.  With batch_stats_out != NULL rsp_bn_finalize_x does NOT move running_mean / running_var (both
+ * ignored) but writes this pass's batch moments — [2][c_valid]: mean (conv bias included), unbiased variance; rsp_bn_running_update
+ * later applies  r = (1 - momentum) r + momentum * moment  for a whole list of layers in one launch (jobs in device memory), the
+ * update nn.BatchNorm3d does inside forward.  The two key-encoder passes of a step (builder_diffspeed_diffloss.py:445,512) go through
+ * the SAME BatchNorm buffers; deferring the second pass's update lets the passes run side by side in a captured graph and still
+ * leaves the buffers as two consecutive forwards would. */
+typedef struct rsp_bn_ema_job {
+  float* running_mean;
+  float* running_var;
+  const float* batch_stats; /* [2][C] */
+  int32_t C;
+  float momentum;
+} rsp_bn_ema_job;
+int rsp_bn_finalize_x(const float* stat_partials, int32_t tiles, int32_t C, int32_t c_valid, int32_t stat_ld, int64_t count,
+                      const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* batch_stats_out, float* mean_invstd, float* scale_shift, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int rsp_bn_running_update(const rsp_bn_ema_job* jobs_device, int32_t n_jobs, int32_t max_c, void* stream);
+
 /* Standalone per-channel statistics of y (for convs whose epilogue did not produce partials): writes
  * [tiles][C][2] partials with tiles = rsp_bn_stat_tiles(rows). */
 int32_t rsp_bn_stat_tiles(int64_t rows);

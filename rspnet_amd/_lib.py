@@ -40,6 +40,12 @@ class PackJob(C.Structure):
         "kstepd", "ksteph", "kstepw", "ntaps", "blocks", "reserved")]
 
 
+class BnEmaJob(C.Structure):
+    """rsp_bn_ema_job (32 bytes)"""
+    _fields_ = [("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("batch_stats", C.c_void_p), ("C", C.c_int32),
+                ("momentum", C.c_float)]
+
+
 class AugmentClipDesc(C.Structure):
     """rsp_augment_clip_desc (88 bytes)"""
     _fields_ = [("src", C.c_void_p), ("frame_pitch", C.c_int64), ("row_pitch", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
@@ -80,6 +86,8 @@ SIGNATURES = {
     "rsp_bn_finalize_workspace": (_sz, [_i32, _i32]),
     "rsp_bn_finalize": (C.c_int, [_p, _i32, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_bn_finalize_v": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_bn_finalize_x": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "rsp_bn_running_update": (C.c_int, [_p, _i32, _i32, _p]),
     "rsp_bn_stat_tiles": (_i32, [_i64]),
     "rsp_bn_stats": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "rsp_bn_act_pool_fwd": (C.c_int, [_PP, _p, _p, _p, C.c_int, _p, _p]),

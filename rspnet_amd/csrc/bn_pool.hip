@@ -45,7 +45,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_stage2(const double* __restr
                                                            const float* __restrict__ conv_bias, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                           float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+                                                           float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                           float* __restrict__ bstat) {
   __shared__ double red[16][64][2];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -82,11 +83,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_stage2(const double* __restr
   scale_shift[c] = sc;
   scale_shift[C + c] = b - (float)mean * sc;
   if (!valid) return;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-  if (running_var) {
-    const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+  if (bstat) {
+    // deferred running-statistics update (rsp_bn_running_update): this pass only reports its batch moments — two passes through
+    // the same BatchNorm can then run side by side and have their moving averages applied afterwards, in order
+    bstat[c] = (float)mean;
+    bstat[Cv + c] = (float)unbiased;
+    return;
   }
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
 }
 
 // Single-launch variant for up to a few thousand tiles: one workgroup of 1024 threads per 64 channels — 16 tile-lanes per channel
@@ -97,7 +103,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __re
                                                                const float* __restrict__ conv_bias, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float momentum,
                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                               float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+                                                               float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                               float* __restrict__ bstat) {
   __shared__ double red[16][64][2];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -135,11 +142,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __re
   scale_shift[c] = sc;
   scale_shift[C + c] = b - (float)mean * sc;
   if (!valid) return;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-  if (running_var) {
-    const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+  if (bstat) {
+    // deferred running-statistics update (rsp_bn_running_update): this pass only reports its batch moments — two passes through
+    // the same BatchNorm can then run side by side and have their moving averages applied afterwards, in order
+    bstat[c] = (float)mean;
+    bstat[Cv + c] = (float)unbiased;
+    return;
   }
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
 }
 
 // standalone stats over 128-row tiles (same partial layout as the conv epilogue)
@@ -657,6 +669,30 @@ int rsp_bn_finalize_v(const float* stat_partials, int32_t tiles, int32_t C, int3
                       const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* mean_invstd, float* scale_shift, void* workspace,
                       size_t workspace_bytes, void* stream) {
+  return rsp_bn_finalize_x(stat_partials, tiles, C, c_valid, stat_ld, count, conv_bias, gamma, beta, eps, momentum, running_mean,
+                           running_var, nullptr, mean_invstd, scale_shift, workspace, workspace_bytes, stream);
+}
+
+// EMA of the running statistics for a list of BatchNorm layers in one launch (jobs in device memory): what rsp_bn_finalize does
+// per layer when it is not told to defer (batch_stats_out).  grid = (channel blocks of the widest layer, jobs).
+__global__ __launch_bounds__(256) void bn_ema_kernel(const rsp_bn_ema_job* __restrict__ jobs) {
+  const rsp_bn_ema_job j = jobs[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= j.C) return;
+  j.running_mean[c] = (1.f - j.momentum) * j.running_mean[c] + j.momentum * j.batch_stats[c];
+  j.running_var[c] = (1.f - j.momentum) * j.running_var[c] + j.momentum * j.batch_stats[j.C + c];
+}
+
+int rsp_bn_running_update(const rsp_bn_ema_job* jobs_device, int32_t n_jobs, int32_t max_c, void* stream) {
+  RSP_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_c > 0, "rsp_bn_running_update: bad argument");
+  hipLaunchKernelGGL(bn_ema_kernel, dim3(rsp_cdiv(max_c, 256), n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
+  return rsp_check_launch("bn_ema_kernel");
+}
+
+int rsp_bn_finalize_x(const float* stat_partials, int32_t tiles, int32_t C, int32_t c_valid, int32_t stat_ld, int64_t count,
+                      const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* batch_stats_out, float* mean_invstd, float* scale_shift, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(stat_partials && mean_invstd && scale_shift && workspace, "rsp_bn_finalize: null pointer");
   RSP_REQUIRE(tiles > 0 && C > 0 && count > 0 && stat_ld >= C && c_valid > 0 && c_valid <= C, "rsp_bn_finalize: bad size");
   const int S = finalize_slices(tiles);
@@ -667,7 +703,7 @@ int rsp_bn_finalize_v(const float* stat_partials, int32_t tiles, int32_t C, int3
   hipStream_t s = (hipStream_t)stream;
   if (tiles <= 2048) {
     hipLaunchKernelGGL(bn_finalize_one_kernel, dim3(rsp_cdiv(C, 64)), dim3(1024), 0, s, stat_partials, tiles, C, c_valid, stat_ld, (long long)count,
-                       conv_bias, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
+                       conv_bias, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift, batch_stats_out);
     return rsp_check_launch("bn_finalize_one_kernel");
   }
   double* part = reinterpret_cast<double*>(workspace);
@@ -675,7 +711,7 @@ int rsp_bn_finalize_v(const float* stat_partials, int32_t tiles, int32_t C, int3
   int rc = rsp_check_launch("bn_finalize_stage1");
   if (rc != RSP_OK) return rc;
   hipLaunchKernelGGL(bn_finalize_stage2, dim3(rsp_cdiv(C, 64)), dim3(1024), 0, s, part, S, C, c_valid, (long long)count, conv_bias,
-                     gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
+                     gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift, batch_stats_out);
   return rsp_check_launch("bn_finalize_stage2");
 }
 

@@ -312,13 +312,24 @@ def _eval_scale_shift(bn, bias) -> torch.Tensor:
     return torch.stack([scale, shift]).contiguous()
 
 
-def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, training: bool = True
-                ) -> Tuple[torch.Tensor, Optional[ForwardCtx]]:
+def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, training: bool = True,
+                deferred: Optional[Dict[int, torch.Tensor]] = None) -> Tuple[torch.Tensor, Optional[ForwardCtx]]:
     """Execute `plan` on x (N,D,H,W,C).  keep=True records what backward needs.  training=True: batch-statistics BN (the
     pretext step never runs anything else: pretrain.py:225); training=False: running-statistics BN for the fine-tune /
     validation forward (finetune.py:333-345), no backward."""
     be = _ops.backend()
     assert training or not keep, "eval-mode forward keeps nothing for backward"
+
+    def finalize(bn, stats, rows, bias_d):
+        # deferred: {id(BatchNorm module): [2][C] buffer} — this pass reports its batch moments there and leaves the running
+        # statistics to a later rsp_bn_running_update (ops.BnEmaSet); otherwise bn_finalize moves them itself
+        bso = deferred.get(id(bn)) if deferred is not None else None
+        if bso is not None:
+            return be.bn_finalize(stats, rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), None, None,
+                                  batch_stats_out=bso)
+        return be.bn_finalize(stats, rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum),
+                              bn.running_mean, bn.running_var)
+
     slots: Dict[int, torch.Tensor] = {plan.input_slot: x}
     ctx = ForwardCtx(packed=packed) if keep else None
     def bn_apply(node, y, ss, cg_cout, N, do, ho, wo, xin):
@@ -349,8 +360,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_conv, True)
             # (zero-padded output channels, Cp > Cout: the BatchNorm vectors keep their Cout entries, the kernels treat the rest
             #  as gamma = beta = 0 and leave the running statistics of the real channels alone)
-            mi, ss = be.bn_finalize(stats, cg.rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps),
-                                    float(bn.momentum), bn.running_mean, bn.running_var)
+            mi, ss = finalize(bn, stats, cg.rows, bias_d)
         else:
             y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), None, False)     # bias folded into the shift
             ss = _eval_scale_shift(bn, bias)
@@ -382,8 +392,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         for m in ms:
             C = m.conv.weight.shape[0]
             bn = m.bn
-            mi, ss = be.bn_finalize(stats[:, off:off + C], cg.rows, None, bn.weight.data, bn.bias.data, float(bn.eps),
-                                    float(bn.momentum), bn.running_mean, bn.running_var)
+            mi, ss = finalize(bn, stats[:, off:off + C], cg.rows, None)
             pg, _ = bn_apply(m, y[..., off:off + C], ss, C, N, do, ho, wo, xin)
             per.append((off, C, mi, ss, pg))
             off += C

@@ -160,8 +160,10 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._q_params: List[nn.Parameter] = []
         self._ptr_host: Optional[int] = None
         self._ptr_on_device = False           # True: queue_ptr lives on the device only (graph-captured steps)
-        self.overlap_query = not os.environ.get("RSP_NO_QOVERLAP")     # (switch for A/B runs of tools/)
-        self._query_stream = None
+        self.overlap_query = not os.environ.get("RSP_NO_QOVERLAP")     # (switches for A/B runs of tools/)
+        self.overlap_keys = not os.environ.get("RSP_NO_KOVERLAP")
+        self._query_stream = self._key_stream = None
+        self._ema_k = self._ema_map = None
         self._q_pre = None
         self._cpu_group = None
         self._last_q = None
@@ -345,7 +347,19 @@ class MoCoDiffLossTwoFc(nn.Module):
         return x, handle, loc_t, arrival
 
     @torch.no_grad()
-    def _key_pass(self, exchange, tag: str):
+    def _deferred_k(self):
+        """{id(BatchNorm of encoder_k): its [2][C] batch-moment buffer} + the set that applies the deferred updates.  The second
+        key pass of a step reports its batch moments there instead of moving the running statistics itself: the two passes go
+        through the same BatchNorm buffers, and with the second one's update applied afterwards (`BnEmaSet.run`, one launch)
+        they can run side by side inside a captured graph and still leave the buffers as two consecutive forwards do."""
+        bns = [m for m in self.encoder_k.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        ptrs = [(b.running_mean.data_ptr(), b.running_var.data_ptr()) for b in bns]
+        if self._ema_k is None or self._ema_k.ptrs != ptrs:
+            self._ema_k = _ops.backend().bn_ema_set([(b.running_mean, b.running_var, float(b.momentum)) for b in bns])
+            self._ema_map = {id(b): self._ema_k.stats[i] for i, b in enumerate(bns)}
+        return self._ema_map
+
+    def _key_pass(self, exchange, tag: str, deferred=None, bump: bool = True):
         """Second half (:408-419): encoder_k on the exchanged clips, then ONE all-gather of the fused (A | M) features that
         serves both the un-shuffle (:389-406) and the queue's key all-gather (:348).  Returns (features [A | M] of my samples
         in my order, features of ALL samples in global order (B*ws rows), width of the A part)."""
@@ -356,12 +370,13 @@ class MoCoDiffLossTwoFc(nn.Module):
         if handle is not None:
             with self._comm("all_to_all_" + tag):
                 handle.wait()
-        self._nbt_k += 1
-        a, m, _ = self.encoder_k.forward_ndhwc(x, keep=False)
+        if bump:
+            self._nbt_k += 1
+        a, m, _ = self.encoder_k.forward_ndhwc(x, keep=False, deferred=deferred)
         feats = torch.cat([a, m], dim=1)
         # introspection only (tests compare with the reference's encoder_k outputs): this rank's key features in arrival
         # order + the position each arrival has in the reference's shuffled batch G[rank]
-        self._last_k.append((feats, arrival))
+        self._last_k[0 if tag == "kneg" else 1] = (feats, arrival)
         if ws > 1:
             gathered = torch.empty((B * ws, feats.shape[1]), dtype=feats.dtype, device=feats.device)
             with self._comm("all_gather_" + tag):
@@ -469,7 +484,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         dev = im_q.device
         B, C, T, H, W = im_q.shape
         im_q, im_k = im_q.contiguous(), im_k.contiguous()
-        self._last_k = []
+        self._last_k = [None, None]          # (k_negative pass, k pass)
         with torch.no_grad():
             self._momentum_update_key_encoder()
             # _diff_speed (:421-447)
@@ -502,8 +517,24 @@ class MoCoDiffLossTwoFc(nn.Module):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self._q_pre = self.encoder_q.forward_ndhwc(x_q, keep=True)
-            kneg_mine, kneg_all, dim = self._key_pass(ex_neg, "kneg")
-            k_mine, _, _ = self._key_pass(ex_k, "k")
+            # The two key passes (k_negative first, :445; then k, :512) go through the same encoder_k.  The second one defers its
+            # running-statistics update (_deferred_k), so under capture it is forked onto its own stream beside the first (and
+            # beside the query forward); the deferred update is applied after both, in the reference's order.
+            deferred = self._deferred_k()
+            self._nbt_k += 2
+            side_k = None
+            if side is not None and self.overlap_keys:
+                main = torch.cuda.current_stream(dev)
+                side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
+                side_k.wait_stream(main)
+                with torch.cuda.stream(side_k):
+                    k_mine, _, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
+            kneg_mine, kneg_all, dim = self._key_pass(ex_neg, "kneg", bump=False)
+            if side_k is None:
+                k_mine, _, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
+            else:
+                torch.cuda.current_stream(dev).wait_stream(side_k)
+            self._ema_k.run()
             del ex_neg, ex_k
             k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
             kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()

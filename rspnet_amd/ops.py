@@ -284,7 +284,9 @@ class HipOps:
 
     # ---- batch norm -------------------------------------------------------------------------------------------
     def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,
-                    running_var):
+                    running_var, batch_stats_out=None):
+        """batch_stats_out ([2][c_valid] view of a BnEmaSet): report this pass's batch moments there instead of moving the
+        running statistics (deferred update, rsp_bn_running_update)."""
         tiles, Cc, _ = stats.shape
         if stats.is_contiguous():
             _chk(stats, "stats")
@@ -299,10 +301,15 @@ class HipOps:
         ws = self._workspace(stats.device, wsb)
         # the parameter vectors may be shorter than the convolution's (zero-padded) channel count: gamma's length says how many
         c_valid = Cc if gamma is None else int(gamma.shape[0])
-        _lib.check(self.lib.rsp_bn_finalize_v(_ptr(stats), tiles, Cc, c_valid, stat_ld, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta),
-                                              eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(mi), _ptr(ss), _ptr(ws),
-                                              wsb, _stream()), "rsp_bn_finalize")
+        _lib.check(self.lib.rsp_bn_finalize_x(_ptr(stats), tiles, Cc, c_valid, stat_ld, count, _ptr(conv_bias), _ptr(gamma), _ptr(beta),
+                                              eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(batch_stats_out), _ptr(mi),
+                                              _ptr(ss), _ptr(ws), wsb, _stream()), "rsp_bn_finalize")
         return mi, ss
+
+    def bn_ema_set(self, entries):
+        """entries: list of (running_mean, running_var, momentum) of BatchNorm layers whose running-statistics update is deferred;
+        returns a BnEmaSet: `.stats[i]` is the [2][C] buffer layer i's bn_finalize reports into, `.run()` applies all updates."""
+        return BnEmaSet(self, entries)
 
     def bn_act_pool_fwd(self, pg: PoolGeom, y, scale_shift, residual, relu: bool, out=None):
         in_ld = _rows_ld(y, "y")             # y may be a channel slice of a wider conv output
@@ -561,6 +568,32 @@ class HipOps:
         _lib.check(self.lib.rsp_augment_batch(_ptr(descs), n_clips, T, size, m3, s3, b9, _ptr(out), 3 * T * size * size, _ptr(ws),
                                               ws.numel(), _stream()), "rsp_augment_batch")
         return out
+
+
+class BnEmaSet:
+    """Batch moments of a list of BatchNorm layers (one flat buffer) + the device-resident job table of their deferred
+    running-statistics update (rsp_bn_running_update: one launch for all layers)."""
+
+    def __init__(self, be: "HipOps", entries):
+        self.be = be
+        dev = entries[0][0].device
+        sizes = [int(rm.shape[0]) for rm, _, _ in entries]
+        self.flat = torch.zeros(2 * sum(sizes), dtype=torch.float32, device=dev)
+        self.stats, self.ptrs, jobs, off = [], [], [], 0
+        for (rm, rv, mom), c in zip(entries, sizes):
+            _chk(rm, "running_mean")
+            _chk(rv, "running_var")
+            v = self.flat[off:off + 2 * c].view(2, c)
+            self.stats.append(v)
+            self.ptrs.append((rm.data_ptr(), rv.data_ptr()))
+            jobs.append(bytes(_lib.BnEmaJob(rm.data_ptr(), rv.data_ptr(), v.data_ptr(), c, float(mom))))
+            off += 2 * c
+        self.keep = [e[:2] for e in entries]
+        self.max_c, self.n = max(sizes), len(sizes)
+        self.table = torch.frombuffer(bytearray(b"".join(jobs)), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        _lib.check(self.be.lib.rsp_bn_running_update(_ptr(self.table), self.n, self.max_c, _stream()), "rsp_bn_running_update")
 
 
 class PackSet:

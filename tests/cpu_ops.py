@@ -50,8 +50,19 @@ class CpuOps:
         if dbias_out is not None:
             dbias_out.copy_(dy.sum(dim=(0, 1, 2, 3)))
 
-    def bn_finalize(self, stats, count, conv_bias, gamma, beta, eps, momentum, running_mean, running_var):
+    def bn_ema_set(self, entries):
+        return _CpuEmaSet(entries)
+
+    def bn_finalize(self, stats, count, conv_bias, gamma, beta, eps, momentum, running_mean, running_var, batch_stats_out=None):
         C, Cv = stats.shape[1], gamma.shape[0]
+        if batch_stats_out is not None:
+            # deferred running-statistics update: report the batch moments (mean incl. conv bias, unbiased variance) instead
+            s = stats.double().sum(dim=0)[:Cv]
+            mean0 = s[:, 0] / count
+            var = (s[:, 1] / count - mean0 * mean0).clamp_min(0)
+            batch_stats_out[0].copy_((mean0 + (conv_bias.double() if conv_bias is not None else 0)).float())
+            batch_stats_out[1].copy_((var * count / (count - 1) if count > 1 else var).float())
+            running_mean = running_var = None
         if Cv < C:        # zero-padded output channels: parameters hold Cv entries, the padding gets gamma = beta = 0
             pad = lambda v, fill=0.0: None if v is None else torch.cat([v, torch.full((C - Cv,), fill, dtype=v.dtype)])
             rm = None if running_mean is None else pad(running_mean)
@@ -289,6 +300,20 @@ class CpuOps:
     def pack_signature(self, g, which, w_ref):
         # checker "layout" = zero-padded reference layout: depends on the channel counts and the kernel only
         return (which, g.Cin, g.Cout, tuple(g.k), tuple(w_ref.shape))
+
+
+class _CpuEmaSet:
+    """Checker twin of rspnet_amd.ops.BnEmaSet."""
+
+    def __init__(self, entries):
+        self.entries = entries
+        self.stats = [torch.zeros(2, rm.shape[0]) for rm, _, _ in entries]
+        self.ptrs = [(rm.data_ptr(), rv.data_ptr()) for rm, rv, _ in entries]
+
+    def run(self):
+        for (rm, rv, mom), st in zip(self.entries, self.stats):
+            rm.mul_(1 - mom).add_(mom * st[0])
+            rv.mul_(1 - mom).add_(mom * st[1])
 
 
 class _CpuPackSet:

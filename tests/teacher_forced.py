@@ -106,7 +106,7 @@ class Recorder:
 
     def __getattr__(self, name):
         fn = getattr(self.inner, name)
-        if not callable(fn) or name == "pack_signature":      # (a pure host query: nothing to replay)
+        if not callable(fn) or name in ("pack_signature", "bn_ema_set"):      # (host queries / set builders: nothing to replay)
             return fn
 
         def wrapped(*args, **kwargs):

@@ -592,3 +592,31 @@ def test_channel_padded_unit_uses_the_parameters_own_lengths(hip):
     dw2 = torch.empty(64, Cv, 3, 1, 1, device=DEV)
     hip.conv_wgrad(g2, out, dy2.to(DEV), dw2)
     close(dw2, dw2_ref, 2e-5, "dw (input channels padded)")
+
+
+@pytest.mark.parametrize("C,Cv,tiles", [(64, 64, 5), (84, 83, 3), (1152, 1152, 2), (128, 128, 3000)])
+def test_deferred_running_statistics_update(hip, C, Cv, tiles):
+    """rsp_bn_finalize_x with batch_stats_out reports the pass's batch moments and leaves the running statistics alone;
+    rsp_bn_running_update (one launch for a list of layers) then moves them exactly as the in-place finalize does."""
+    rows = tiles * 128 - 17
+    part = (torch.rand(tiles, C, 2) + 0.5) * 100
+    part[:, :, 1] = part[:, :, 0] ** 2 / 128 * 1.3 + 5.0
+    if Cv < C:
+        part[:, Cv:] = 0
+    gamma, beta = rnd(Cv, seed=3) + 1.5, rnd(Cv, seed=4)
+    rm, rv = rnd(Cv, seed=5), rnd(Cv, seed=6) + 1.5
+    other_rm, other_rv = rnd(40, seed=7), rnd(40, seed=8) + 1.5                 # a second layer in the same set
+    d = lambda t: t.to(DEV)
+    rm_a, rv_a = d(rm), d(rv)
+    mi_a, ss_a = hip.bn_finalize(d(part), rows, None, d(gamma), d(beta), 1e-5, 0.1, rm_a, rv_a)
+    rm_b, rv_b, orm, orv = d(rm), d(rv), d(other_rm), d(other_rv)
+    ema = hip.bn_ema_set([(rm_b, rv_b, 0.1), (orm, orv, 0.25)])
+    ema.stats[1].copy_(torch.stack([torch.full((40,), 2.0), torch.full((40,), 3.0)]))
+    mi_b, ss_b = hip.bn_finalize(d(part), rows, None, d(gamma), d(beta), 1e-5, 0.1, None, None, batch_stats_out=ema.stats[0])
+    assert torch.equal(rm_b.cpu(), rm) and torch.equal(rv_b.cpu(), rv)              # untouched so far
+    assert torch.equal(mi_a, mi_b) and torch.equal(ss_a, ss_b)
+    ema.run()
+    close(rm_b, rm_a, 1e-6, "running_mean after the deferred update")
+    close(rv_b, rv_a, 1e-6, "running_var after the deferred update")
+    close(orm, 0.75 * other_rm + 0.25 * 2.0, 1e-6, "second layer mean")
+    close(orv, 0.75 * other_rv + 0.25 * 3.0, 1e-6, "second layer var")
