@@ -145,6 +145,12 @@ class PackedWeights:
     def invalidate(self):
         self._dirty = True
 
+    def refresh_now(self):
+        """Re-pack on the CURRENT stream if the weights changed: for callers that are about to use the copies from several
+        streams (two passes through one encoder side by side) and need the re-pack ordered before the fork."""
+        if self._dirty and self._entries:
+            self._refresh()
+
     def _refresh(self):
         be = _ops.backend()
         ptrs = [c.weight.data_ptr() for _, _, c in self._entries]

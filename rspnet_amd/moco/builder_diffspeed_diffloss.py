@@ -522,6 +522,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             # beside the query forward); the deferred update is applied after both, in the reference's order.
             deferred = self._deferred_k()
             self._nbt_k += 2
+            self.encoder_k._packed.refresh_now()      # (re-pack of the momentum-updated weights: before the passes fork)
             side_k = None
             if side is not None and self.overlap_keys:
                 main = torch.cuda.current_stream(dev)
