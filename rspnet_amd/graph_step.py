@@ -35,6 +35,7 @@ log = logging.getLogger(__name__)
 
 class GraphedPretextStep:
     RING = 8
+    MAX_GRAPHS = 4      # configurations kept (diff_speed has at most three entries; a new learning rate retires the old graphs)
 
     def __init__(self, model, criterion, optimizer, warmup: int = 2):
         self.wrapped = model
@@ -43,9 +44,10 @@ class GraphedPretextStep:
         # at least two eager steps: the packed-weight sets an encoder builds during its first step are merged into one batched
         # set (a host-to-device copy of the job table) when its second step re-packs them
         self.warmup = max(2, int(warmup))
-        self.graphs: Dict[Tuple, Tuple] = {}
+        self.graphs: Dict[Tuple, Tuple] = {}      # insertion order = least recently used first
         self.eager_steps: Dict[Tuple, int] = {}
         self.static = None
+        self.pool = None                          # one memory pool for all graphs of this stepper: only one replays at a time
         self.disabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.fallback_reason = "more than one rank" if self.disabled else None
 
@@ -104,6 +106,7 @@ class GraphedPretextStep:
             entry = self._capture(key, host)
             if entry is None:
                 return self._eager(st["im_q"], st["im_k"], host)[:5]
+        self.graphs[key] = self.graphs.pop(key)         # most recently used last
         entry[0].replay()
         return entry[1]
 
@@ -116,9 +119,13 @@ class GraphedPretextStep:
         try:
             torch.cuda.synchronize()
             from .engine import BranchStreams
+            while len(self.graphs) >= self.MAX_GRAPHS:      # (the scheduler changes the learning rate every epoch: old graphs go)
+                self.graphs.pop(next(iter(self.graphs)))
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, pool=self.pool):
                     BranchStreams.origin = torch.cuda.current_stream(st["dev"].device).cuda_stream
                     loss, loss_A, loss_M, out, rl, _, _ = self._eager(st["im_q"], st["im_k"], host)
             finally:

@@ -68,7 +68,7 @@ def test_one_graph_per_speed_and_learning_rate():
     the scheduler changes the learning rate once per epoch (pretrain.py:75-79).  Each (speed, lr) configuration gets its own
     captured graph after its own eager warm-up steps; the trajectory stays bit-identical to the eager loop."""
     from rspnet_amd.graph_step import GraphedPretextStep
-    arch, B, HW, K, steps = "c3d", 4, 32, 64, 14
+    arch, B, HW, K, steps = "c3d", 4, 32, 64, 26
     clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(30 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
     results = []
     for mode in ("eager", "graph"):
@@ -77,9 +77,11 @@ def test_one_graph_per_speed_and_learning_rate():
         random.seed(11)
         wrapped, crit, opt = _build(arch, K, speeds=(2, 1))
         stepper = GraphedPretextStep(wrapped, crit, opt, warmup=1) if mode == "graph" else None
+        if stepper is not None:
+            stepper.MAX_GRAPHS = 3               # 2 speeds x 2 learning rates = 4 configurations: one graph must be retired
         losses, speeds = [], []
         for i, (im_q, im_k) in enumerate(clips):
-            if i == 9:
+            if i == 12:
                 for gr in opt.param_groups:
                     gr["lr"] = 0.01
             if stepper is None:
@@ -95,7 +97,7 @@ def test_one_graph_per_speed_and_learning_rate():
         torch.cuda.synchronize()
         if stepper is not None:
             assert not stepper.disabled, stepper.fallback_reason
-            assert len(stepper.graphs) >= 2 and {k[0] for k in stepper.graphs} <= {1, 2}
+            assert 2 <= len(stepper.graphs) <= stepper.MAX_GRAPHS and {k[0] for k in stepper.graphs} <= {1, 2}
         results.append((losses, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
     (le, se), (lg, sg) = results
     for i, (a, b) in enumerate(zip(le, lg)):
