@@ -38,3 +38,42 @@ def test_step_matches_golden_ws1(cpu_backend, arch, seed, optimizer):
     compare_to_golden(z, 0, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=grad_tol(arch))
     wkey, worst = worst_grad_err(z, 0, grads)
     assert worst <= grad_tol(arch), (wkey, worst)
+
+
+def test_graphed_step_wrapper_falls_back_to_the_eager_statements(cpu_backend):
+    """rspnet_amd.graph_step.GraphedPretextStep off the GPU (or with more than one rank) issues the reference's five statements
+    eagerly, split as host part / device part — same results as calling the model directly, same golden."""
+    import random
+    from model_util import ReplayRNG, make_cfg
+    from rspnet_amd.graph_step import GraphedPretextStep
+    from rspnet_amd.moco import Loss, ModelFactory
+    from rspnet_amd.optim import SGD
+    arch, _, seed = _C3D[0]
+    z, meta = load_case(arch, 1, seed)
+    spec, (state, mom, clips, perms_B, sh) = build_inputs(arch, meta)
+    outs = []
+    for use_wrapper in (False, True):
+        random.seed(3)
+        wrapped = ModelFactory(make_cfg(arch, meta["K"], m=meta["m"], T=meta["T"])).build_moco_diffloss(device=torch.device("cpu"))
+        wrapped.module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+        wrapped.train()
+        opt = SGD(wrapped.parameters(), lr=meta["lr"], momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=False)
+        crit = Loss(margin=meta["margin"], A=meta["A"], M=meta["M"])
+        im_q, im_k = torch.from_numpy(clips[0][0]), torch.from_numpy(clips[0][1])
+        stepper = GraphedPretextStep(wrapped, crit, opt)
+        for _ in range(2):
+            with ReplayRNG([perms_B[0], sh[0], sh[1]], meta["speed"]):
+                if use_wrapper:
+                    loss, loss_A, loss_M, out, rl = stepper(im_q, im_k)
+                else:
+                    out, tgt, rl, rt = wrapped(im_q, im_k)
+                    loss, loss_A, loss_M = crit(out, tgt, rl, rt)
+                    opt.zero_grad()
+                    loss.backward()
+                    opt.step()
+        assert not stepper.graphs                                   # nothing to capture on the CPU
+        outs.append((loss.detach().clone(), out[0].detach().clone(), {k: v.clone() for k, v in wrapped.module.state_dict().items()}))
+    (l0, o0, s0), (l1, o1, s1) = outs
+    assert torch.equal(l0, l1) and torch.equal(o0, o1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
