@@ -108,3 +108,62 @@ def test_speed_draw_is_shared_across_ranks():
         s0, s1 = np.load(os.path.join(tmp, "speeds0.npy")), np.load(os.path.join(tmp, "speeds1.npy"))
     assert (s0[0] == s1[0]).all() and (s0[0] == s0[1]).all()          # both ran what rank 0 drew
     assert (s1[1] != s1[0]).any(), "the ranks' own draws never differed: the test would not notice independent speeds"
+
+
+def _worker_vs_oracle(rank, ws, arch, B, HW, K, seed, port, tmp):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from cpu_ops import CpuOps
+    from full_size_util import full_size_meta, rel_l2
+    from golden_util import load_spec, rel_err, run_restatement
+    from model_util import run_model_step
+    from oracle.gen_golden import case_inputs
+    from rspnet_amd import ops
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    ops.set_backend(CpuOps())
+    meta = dict(full_size_meta(arch, B, HW, K, seed), ws=ws)
+    spec = dict(load_spec(arch))
+    spec["queue"] = ((128, K), "float32")
+    inputs = case_inputs(spec, arch, B, HW, K, ws, seed)
+    res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, torch.device("cpu"), "fused")
+    ref = os.path.join(tmp, "oracle.pt")
+    if rank == 0:                                                     # the same step on the oracle, ws simulated ranks (once)
+        outs, states, moms = run_restatement(arch, meta, inputs)
+        keep = ("loss", "loss_A", "loss_M", "logits1", "logits2", "l_pos_M", "l_neg_M", "q_A", "q_M", "k_A_shuf", "k_M_shuf",
+                "kneg_A_shuf", "kneg_M_shuf", "grads")
+        # (post-step parameters and the queue are rank-identical: averaged gradients, all-gathered keys)
+        shared = {k: v for k, v in states[0].items() if k in ("queue", "queue_ptr") or k in outs[0]["grads"]}
+        torch.save(([{k: (o_[k] if k != "grads" or r_ == 0 else None) for k in keep} for r_, o_ in enumerate(outs)], shared), ref)
+    dist.barrier()
+    outs, st = torch.load(ref, weights_only=False)
+    o = outs[rank]
+    o["grads"] = outs[0]["grads"]
+    for k in ("loss", "loss_A", "loss_M", "logits1", "logits2", "l_pos_M", "l_neg_M", "q_A", "q_M", "k_A_shuf", "k_M_shuf",
+              "kneg_A_shuf", "kneg_M_shuf"):
+        assert rel_err(res[k], o[k].numpy()) <= 2e-4, (rank, k, rel_err(res[k], o[k].numpy()))
+    assert rel_err(post["queue"], st["queue"].numpy()) <= 2e-4                    # global queue: every rank's keys, rank order
+    assert int(np.asarray(post["queue_ptr"]).reshape(-1)[0]) == int(st["queue_ptr"][0])
+    worst = 0.0
+    for k, g in o["grads"].items():                                               # DDP-averaged gradients
+        if g is not None and float((g.double() ** 2).sum()) > 1e-8:
+            worst = max(worst, rel_l2(grads[k], g.numpy()))
+    assert worst <= 2e-2, (rank, worst)
+    for k in o["grads"]:
+        assert rel_l2(post[k], st[k].numpy()) <= 2e-3, (rank, k)
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([worst]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_step_matches_oracle():
+    """world_size 4 over gloo against the oracle restatement run with 4 simulated ranks (the fixtures stop at 2 ranks): uneven
+    all-to-all splits with up to four peers, the key all-gather / un-shuffle map, the global queue order and the bucketed
+    gradient all-reduce at the next world size on the way to the driver's 8."""
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_vs_oracle, args=(4, "c3d", 2, 16, 64, 3, _free_port(), tmp), nprocs=4, join=True)
+        assert all(os.path.exists(os.path.join(tmp, f"ok{r}.npy")) for r in range(4))
