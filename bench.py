@@ -494,32 +494,47 @@ def run_rank(args):
             if k in m:
                 res[k] = m[k]
     # BASELINE.json configs 3-5 on the same box (N=1, default run only): the other three backbones at their own batch / clip
-    # size, a shorter run each — whole-step and dominant-kernel roofline fractions next to the headline
+    # size, a shorter run each — whole-step and dominant-kernel roofline fractions next to the headline.  Each runs in a CHILD
+    # interpreter of this file (fresh process, started and waited for — never exec'ed into): whatever happens there — an
+    # out-of-memory kill, a runtime crash inside a graph capture — cannot take the headline line down with it.
     if ws == 1 and not cpu_selftest and args.other_workloads and args.arch == "c3d" and not args.batch and not args.hw:
         others = {}
         for arch in ("resnet18", "r2plus1d-vcop", "s3dg"):
-            oB, ohw, olr = ARCHS[arch]
-            om, _ = measure(args, arch, oB, ohw, olr, args.other_steps, args.other_warmup, dev, rank, ws)
-            rf = om["roofline"]
-            others[arch] = {"workload": f"{arch} pretext step, {oB} clips/GPU, encoder 3x16x{ohw}x{ohw}, K={om['K']}",
-                            "clips_per_s": round(om["clips_per_s"], 2), "ms_per_step": round(om["ms_per_step"], 3),
-                            "steps": args.other_steps, "warmup": args.other_warmup, "steps_ms": om.get("steps_ms"),
-                            "whole_step_frac": rf["whole_step"]["frac"],
-                            "algorithmic_conv_gflop_per_clip": rf["whole_step"]["algorithmic_conv_gflop_per_clip"],
-                            "conv_launches_frac": rf["all_conv_launches"]["frac"],
-                            "conv_ms_per_step": rf["all_conv_launches"]["ms_per_step"],
-                            "dominant_kernel": rf["kernel"], "dominant_kernel_frac": rf["frac"],
-                            "dominant_kernel_share_of_step": rf["share_of_step"], "final_loss": round(om["final_loss"], 5),
-                            "step_issue": "one replayed HIP graph; roofline numbers from an eager pass of the same step" if om["graph"]
-                            else "eager launches" + (f" (graph capture fell back: {om['graph_fallback']})" if "graph_fallback" in om else "")}
+            oB, ohw, _ = ARCHS[arch]
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--arch", arch, "--steps", str(args.other_steps),
+                   "--warmup", str(args.other_warmup), "--queue", str(args.queue), "--graph", args.graph, "--no-cpu-baseline",
+                   "--no-other-workloads"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+                if r.returncode != 0 or not lines:
+                    raise RuntimeError(f"rc {r.returncode}: {r.stderr.strip()[-300:]}")
+                od = json.loads(lines[-1])
+                rf = od["roofline"]
+                others[arch] = {"workload": od["config"]["workload"], "clips_per_s": round(od["value"], 2),
+                                "ms_per_step": od["ms_per_step"], "steps": od["steps"], "warmup": od["warmup"],
+                                "steps_ms": od.get("steps_ms"), "whole_step_frac": rf["whole_step"]["frac"],
+                                "algorithmic_conv_gflop_per_clip": rf["whole_step"]["algorithmic_conv_gflop_per_clip"],
+                                "conv_launches_frac": rf["all_conv_launches"]["frac"],
+                                "conv_ms_per_step": rf["all_conv_launches"]["ms_per_step"], "dominant_kernel": rf["kernel"],
+                                "dominant_kernel_frac": rf["frac"], "dominant_kernel_share_of_step": rf["share_of_step"],
+                                "final_loss": od["final_loss"],
+                                "step_issue": od["config"]["step_issue"] + ("; roofline numbers from an eager pass of the same step"
+                                                                            if od["config"]["step_issue"].startswith("one replayed") else "")
+                                + (f" (graph capture fell back: {od['graph_fallback']})" if "graph_fallback" in od else "")}
+            except Exception as e:      # noqa: BLE001 - reported in the line, never fatal for the headline
+                others[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}
         res["other_workloads"] = others
     if rank == 0:
         if want_cpu:
-            cb, par = cpu_baseline(args.arch, hw, args.cpu_sample, args.cpu_steps, m["K"], m["lr"], parity=capture)
-            res["cpu_baseline"] = cb
-            res["vs_cpu_baseline"] = round(res["value"] / cb["value"], 1) if cb["value"] > 0 else None
-            if par is not None:
-                res["parity"] = par
+            try:
+                cb, par = cpu_baseline(args.arch, hw, args.cpu_sample, args.cpu_steps, m["K"], m["lr"], parity=capture)
+                res["cpu_baseline"] = cb
+                res["vs_cpu_baseline"] = round(res["value"] / cb["value"], 1) if cb["value"] > 0 else None
+                if par is not None:
+                    res["parity"] = par
+            except Exception as e:      # noqa: BLE001 - the measured line still goes out
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         print(json.dumps(res), flush=True)
     if ws > 1:
         dist.barrier()
