@@ -93,3 +93,22 @@ def test_parity_leg_replays_the_first_step():
     assert p["ok"] is True and p["loss_rel"] <= 1e-4 and p["logits_rel"] <= 1e-4 and p["features_rel"] <= 1e-4
     assert p["queue_slab_rel"] <= 1e-4 and p["grad_rel_l2"] <= 1e-2
     assert d["cpu_baseline"]["value"] > 0 and d["vs_cpu_baseline"] > 0
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's multi-GPU command line, verbatim, with the CPU self-test standing in for the GPUs:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...
+    Every rank is started by torchrun (WORLD_SIZE set): bench.py must not spawn a second level, rank 0 prints the one line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2"] + TINY, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and "comm_ms" in d
