@@ -15,6 +15,7 @@ Activations are (N, D, H, W, C) tensors.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -41,6 +42,7 @@ class ConvBN:
     residual: Optional[int] = None                 # slot added before the ReLU
     into: Optional[Tuple[int, int, int]] = None    # (concat slot, channel offset, total channels): write a slice
     branch: int = 0                                # > 0: node of a side branch that may run beside its siblings (BranchStreams)
+    virtual_w: bool = False                        # 3-channel stem with W stride 2: run on "virtual pixels" (VirtualStem)
     cout_pad: int = 0                              # run with Cout zero-padded to this many channels (0: as is).  R(2+1)D's
     #   mid-channel counts (83, 230, 921 ...) are not multiples of 4; padded, this conv's output and the next conv's input are
     #   16-byte rows and both take the LDS-DMA kernels instead of the scalar gather.  Pad channels carry zero weights and
@@ -141,6 +143,7 @@ class PackedWeights:
         self._sets = []
         self._ptrs = []
         self._dirty = True
+        self._virtual = {}        # id(conv) -> VirtualStem: derived filters that are re-gathered before every re-pack
 
     def invalidate(self):
         self._dirty = True
@@ -153,6 +156,8 @@ class PackedWeights:
 
     def _refresh(self):
         be = _ops.backend()
+        for vs in self._virtual.values():
+            vs.refresh()
         ptrs = [c.weight.data_ptr() for _, _, c in self._entries]
         if len(self._sets) > 1 or ptrs != self._ptrs:      # new members since the last rebuild, or the parameters moved
             self._sets = [be.pack_set([(g, which, c.weight.data) for g, which, c in self._entries])] if self._entries else []
@@ -214,6 +219,75 @@ def _pad_vec(v: torch.Tensor, n: int, fill: float = 0.0) -> torch.Tensor:
 
 
 INPUT_CHANNEL_PAD = 4
+
+
+class VirtualStem:
+    """A 3-channel stem convolution with kernel width 7 and stride 2 along W (R3D-18's 7x7x7 conv1, models/resnet.py:124; the
+    (1,7,7) spatial half of R(2+1)D's conv1, models/r2plus1d_vcop.py:57) without the zero fourth channel.
+
+    The implicit-GEMM kernel wants 16-byte pixels, so the clip is gathered with its 3 channels padded to 4 and a quarter of the
+    matrix work multiplies zeros.  But an output column wo reads 7 pixels = 21 CONTIGUOUS floats of a packed 3-channel row, starting
+    at float 6 wo - 9; seen as 16-byte "virtual pixels" (4 floats, 84 per 112-pixel row) that window starts 3 floats into virtual
+    pixel 3g - 3 for wo = 2g and 1 float into virtual pixel 3g - 1 for wo = 2g + 1.  Each parity of wo is therefore an ORDINARY
+    convolution over the virtual row — kernel width 6, stride 3, 4 "channels", its own weight tensor with the 21 real values shifted
+    by 3 (even) or 1 (odd) floats inside the 24 — and writes every second output column (channel pitch 2 Cout).  K per output drops
+    from 7 * 4 = 28 to 24 floats per kernel row: 14 % less matrix work on the layer that is a third of R3D-18's step.
+    The packed row carries 3 zero virtual pixels on the left and 2 on the right, so both parities run without padding along W
+    (the odd one from a base address 2 virtual pixels in) and the output-size formula gives exactly Wo / 2 columns."""
+
+    def __init__(self, node):
+        self.conv = node.conv
+        w = node.conv.weight
+        Cout, cin, kT, kH, kW = w.shape
+        assert cin == 3 and kW == 7 and node.s[2] == 2 and node.p[2] == 3
+        self.holders, self.idx, self.src, self.dst = [], [], [], []
+        co = torch.arange(Cout).view(Cout, 1, 1, 1, 1)
+        c4 = torch.arange(4).view(1, 4, 1, 1, 1)
+        kt = torch.arange(kT).view(1, 1, kT, 1, 1)
+        kh = torch.arange(kH).view(1, 1, 1, kH, 1)
+        j = torch.arange(6).view(1, 1, 1, 1, 6)
+        for off in (3, 1):                               # even wo, odd wo
+            r = 4 * j + c4 - off                         # float inside the 21-float window
+            valid = ((r >= 0) & (r < 21)).expand(Cout, 4, kT, kH, 6)
+            real = ((((co * 3 + r % 3) * kT + kt) * kH + kh) * 7 + torch.div(r, 3, rounding_mode="floor")).expand(Cout, 4, kT, kH, 6)
+            idx = torch.where(valid, real, torch.full_like(real, w.numel())).reshape(-1)      # sentinel -> the appended zero
+            flat_valid = valid.reshape(-1).nonzero().view(-1)
+            self.idx.append(idx.to(w.device))
+            self.src.append(flat_valid.to(w.device))
+            self.dst.append(real.reshape(-1)[flat_valid].to(w.device))
+            h = _CatConv()
+            h.weight = torch.zeros((Cout, 4, kT, kH, 6), dtype=w.dtype, device=w.device)
+            self.holders.append(_CatHolder(h))
+        self.device = w.device
+        self.refresh()
+
+    enabled = not os.environ.get("RSP_NO_VIRTUAL_STEM")      # (A/B switch for measurements)
+
+    @staticmethod
+    def applies(node, xin) -> bool:
+        w = node.conv.weight
+        W = xin.shape[3]
+        return (VirtualStem.enabled and node.virtual_w and w.shape[1] == 3 and xin.shape[4] == 4 and w.shape[4] == 7 and node.s[2] == 2 and node.p[2] == 3
+                and (3 * W) % 4 == 0 and W % 2 == 0 and getattr(node.conv, "bias", None) is None and node.residual is None
+                and node.into is None)
+
+    def refresh(self):
+        """class weights <- current parameter values (two gathers of 8/7 the filter size), called by PackedWeights ahead of every
+        re-pack: the pack set then lays them out with the rest"""
+        w = self.conv.weight
+        ext = torch.cat([w.data.reshape(-1), w.data.new_zeros(1)])
+        for h, idx in zip(self.holders, self.idx):
+            torch.index_select(ext, 0, idx, out=h.conv.weight.view(-1))
+
+    def pack_rows(self, xin):
+        """(N,D,H,W,4) clip with a zero 4th channel -> packed 3-channel rows as virtual pixels: (N,D,H,Wv+5,4) for the even outputs and
+        the same memory from 2 virtual pixels in for the odd ones."""
+        N, D, H, W, _ = xin.shape
+        Wp = 3 * W // 4 + 5
+        flat = torch.zeros(N * D * H * Wp * 4 + 8, dtype=xin.dtype, device=xin.device)
+        xv = flat[:N * D * H * Wp * 4].view(N, D, H, Wp, 4)
+        xv.view(N, D, H, Wp * 4)[..., 12:12 + 3 * W].view(N, D, H, W, 3).copy_(xin[..., :3])
+        return xv, torch.as_strided(flat, (N, D, H, Wp, 4), xv.stride(), 8)
 
 
 class BranchStreams:
@@ -350,8 +424,36 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             slots[node.dst] = be.bn_act_pool_fwd(pg, y, ss, res, node.relu)
         return pg, res
 
+    def convbn_virtual(node, key):
+        """ConvBN of a 3-channel stride-2 stem as two ordinary convolutions over virtual pixels (see VirtualStem)."""
+        xin = slots[node.src]
+        N, D, H, W, _ = xin.shape
+        w = node.conv.weight
+        Cout = w.shape[0]
+        Cp = node.cout_pad if node.cout_pad > Cout else Cout
+        vs = packed._virtual.get(id(node.conv))
+        if vs is None or vs.device != w.device:
+            vs = packed._virtual[id(node.conv)] = VirtualStem(node)
+        x_e, x_o = vs.pack_rows(xin)
+        (kT, kH, _), (sT, sH, _), (pT, pH, _) = node.k, node.s, node.p
+        cg = ConvGeom(N, D, H, x_e.shape[3], 4, Cp, (kT, kH, 6), (sT, sH, 3), (pT, pH, 0), Cin_alg=3 * 7 / 6)
+        do, ho, g = cg.out_dims
+        y = torch.empty((N, do, ho, 2 * g, Cp), dtype=torch.float32, device=xin.device)
+        yv = y.view(N, do, ho, g, 2 * Cp)
+        parts = []
+        for c, xc in enumerate((x_e, x_o)):
+            _, st = be.conv_fwd(cg, xc, packed.get(vs.holders[c], cg), None, True, out=yv[..., c * Cp:(c + 1) * Cp], out_ld=2 * Cp)
+            parts.append(st)
+        rows = N * do * ho * 2 * g
+        mi, ss = finalize(node.bn, torch.cat(parts), rows, None)
+        pg, res, = bn_apply(node, y, ss, Cp, N, do, ho, 2 * g, xin)
+        if keep:
+            ctx.saved[key] = ("vstem", x_e, x_o, y, mi, ss, cg, pg, vs)
+
     def convbn(node, key):
         xin = slots[node.src]
+        if training and node.virtual_w and VirtualStem.applies(node, xin):
+            return convbn_virtual(node, key)
         N, D, H, W, Cin = xin.shape
         w = node.conv.weight
         Cout = w.shape[0]
@@ -472,8 +574,30 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
         else:
             dslots[slot] = g
 
+    def convbn_virtual_bwd(node, sv, ni):
+        _, x_e, x_o, y, mi, ss, cg, pg, vs = sv
+        assert node.src == plan.input_slot and not want_input_grad, "a virtual-pixel stem reads the clip: no input gradient"
+        dout = dslots.pop(node.dst)
+        bn = node.bn
+        dy, _ = be.bn_act_pool_bwd(pg, y, None, dout, bn.weight.data, mi, ss, node.relu, False, grad_of(bn.weight), grad_of(bn.bias))
+        gw = grad_of(node.conv.weight)
+        if gw is not None:
+            N, do, ho, Wo, Cp = dy.shape
+            dyv = dy.view(N, do, ho, Wo // 2, 2 * Cp)
+            gflat = gw.view(-1)
+            gflat.zero_()
+            for c, xc in enumerate((x_e, x_o)):
+                gv = torch.empty_like(vs.holders[c].conv.weight)
+                be.conv_wgrad(cg, xc, dyv[..., c * Cp:(c + 1) * Cp], gv)
+                # every real filter element appears once in a class's virtual filter: unique indices, order-independent
+                gflat.index_add_(0, vs.dst[c], gv.view(-1).index_select(0, vs.src[c]))
+        if after_param_grads is not None:
+            after_param_grads(ni)
+
     def convbn_bwd(node, key, ni):
         sv = ctx.saved.pop(key)
+        if isinstance(sv, tuple) and sv[0] == "vstem":
+            return convbn_virtual_bwd(node, sv, ni)
         if node.into is not None:
             dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout)
         else:

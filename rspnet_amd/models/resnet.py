@@ -76,7 +76,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def plan(self) -> Plan:
-        nodes = [ConvBN(self.conv1, self.bn1, 0, 1, (7, 7, 7), (1, 2, 2), (3, 3, 3), relu=True),
+        nodes = [ConvBN(self.conv1, self.bn1, 0, 1, (7, 7, 7), (1, 2, 2), (3, 3, 3), relu=True, virtual_w=True),
                  Pool(1, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1))]
         cur, nxt = 2, 3
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

@@ -29,7 +29,7 @@ class ConvGeom:
     k: Tuple[int, int, int]
     s: Tuple[int, int, int]
     p: Tuple[int, int, int]
-    Cin_alg: int = 0    # algorithmic input channels when Cin includes zero padding (FLOP accounting only)
+    Cin_alg: float = 0  # algorithmic input channels when Cin includes zero padding (FLOP / byte accounting only; may be fractional)
 
     @property
     def out_dims(self):
@@ -43,7 +43,7 @@ class ConvGeom:
     @property
     def flops(self):
         """Algorithmic FLOPs of one pass (2*MACs, padded taps included — SURVEY.md §8d)."""
-        return 2 * self.rows * self.Cout * (self.Cin_alg or self.Cin) * self.k[0] * self.k[1] * self.k[2]
+        return int(2 * self.rows * self.Cout * (self.Cin_alg or self.Cin) * self.k[0] * self.k[1] * self.k[2])
 
     @property
     def bytes(self):
@@ -51,7 +51,7 @@ class ConvGeom:
         once — what a launch must touch at least; the measured L2-miss traffic is priced against it."""
         taps = self.k[0] * self.k[1] * self.k[2]
         cin = self.Cin_alg or self.Cin
-        return 4 * (self.N * self.Di * self.Hi * self.Wi * cin + self.rows * self.Cout + self.Cout * cin * taps)
+        return int(4 * (self.N * self.Di * self.Hi * self.Wi * cin + self.rows * self.Cout + self.Cout * cin * taps))
 
     def desc(self, in_ld=None, out_ld=None) -> _lib.ConvDesc:
         do, ho, wo = self.out_dims
@@ -266,9 +266,9 @@ class HipOps:
     def conv_wgrad(self, g: ConvGeom, x, dy, dw_out: torch.Tensor, dbias_out: Optional[torch.Tensor] = None):
         """dw_out (Cout,Cin,kT,kH,kW) and dbias_out are written in place (they are views of the flat grad buffer)."""
         _chk(x, "x")
-        _chk(dy, "dy")
         _chk(dw_out, "dw_out")
-        d, dref, _, _, _, wsb, _, names = _conv_plan(0, g, None, None)
+        dy_ld = _rows_ld(dy, "dy")                # dy may be a channel slice of a wider gradient tensor
+        d, dref, _, _, _, wsb, _, names = _conv_plan(0, g, None, None if dy_ld == g.Cout else dy_ld)
         ws = self._workspace(x.device, wsb)
         e0 = self._ev()
         if dw_out.shape[0] != g.Cout or dw_out.shape[1] != g.Cin:

@@ -35,6 +35,9 @@ class CpuOps:
             stats = stats.double()  # keep precision of the single tile
         if bias is not None:
             y0 = y0 + bias.view(1, -1, 1, 1, 1)
+        if out is not None:                      # a channel-slice view of a wider tensor (pitch out_ld)
+            out.copy_(_ndhwc(y0))
+            return out, stats
         return _ndhwc(y0), stats
 
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):

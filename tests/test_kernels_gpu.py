@@ -620,3 +620,12 @@ def test_deferred_running_statistics_update(hip, C, Cv, tiles):
     close(rv_b, rv_a, 1e-6, "running_var after the deferred update")
     close(orm, 0.75 * other_rm + 0.25 * 2.0, 1e-6, "second layer mean")
     close(orv, 0.75 * other_rv + 0.25 * 3.0, 1e-6, "second layer var")
+
+
+def test_virtual_pixel_stem_equals_padded_stem(hip):
+    """R3D-18's and R(2+1)D's 3-channel stride-2 stems on virtual pixels (engine.VirtualStem: two kernel-width-6 stride-3
+    convolutions over the packed 3-channel row) against the same unit as a 4-channel-padded convolution, forward, backward and
+    after a weight update."""
+    from virtual_stem_util import CASES, check_case
+    for case in CASES + [(64, 0, (7, 7, 7), (1, 2, 2), (3, 3, 3), (2, 8, 56, 56))]:
+        check_case(DEV, case, 3e-5)
