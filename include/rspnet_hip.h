@@ -175,6 +175,9 @@ typedef struct rsp_pool3d_desc {
 /* out = maxpool(act(scale*y + shift (+ residual))) ; act = ReLU if relu!=0.  residual (nullable) has y's shape. */
 int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
                         int relu, float* out, void* stream);
+/* ... with per-sample channel gates ([N][C], nullable) multiplied in after the activation and before the max (see rsp_bn_gate_sums) */
+int rsp_bn_act_pool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
+                             int relu, const float* gate, float* out, void* stream);
 
 /* Backward of the fused block, two launches:
  *  reduce: per-channel partial sums of dz and dz*xhat (dz = grad at the BN output after pool routing + ReLU mask)
@@ -203,6 +206,17 @@ size_t rsp_gate_fwd_workspace(int32_t N, int32_t P, int32_t C);
 int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* w, const float* b,
                  float* out, int32_t out_ld, float* mean, float* gate, void* workspace, size_t workspace_bytes,
                  void* stream);
+/* The same unit with the gate's spatial mean taken by the kernel that applies the BatchNorm in front of it
+ * (sep_conv = ... BasicConv3d -> excitation, models/s3dg.py:52-72): rsp_bn_gate_sums computes a = relu(y*scale + shift), its
+ * per-(sample, channel) mean and the gate in one pass over y — storing a ([N][P][C], pitch act_ld) only when `act` is given (a
+ * backward will read it) — and the gated output is then either rsp_gate_apply(a) or, without the stored activation,
+ * rsp_bn_act_pool_gate_fwd straight from y (optionally through the max-pool that follows the front-end units, s3dg.py:105-109).
+ * Bit-identical to rsp_bn_act_pool_fwd + rsp_gate_fwd (+ rsp_maxpool3d_fwd).  Workspace: rsp_gate_fwd_workspace(N, P, C). */
+int rsp_bn_gate_sums(const float* y, int32_t N, int32_t P, int32_t C, int32_t y_ld, const float* scale_shift, int relu,
+                     float* act, int32_t act_ld, const float* w, const float* b, float* mean, float* gate, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int rsp_gate_apply(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* gate, float* out, int32_t out_ld,
+                   void* stream);
 size_t rsp_gate_bwd_workspace(int32_t N, int32_t P, int32_t C);
 int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_t C, int32_t x_ld, int32_t dout_ld,
                  const float* w, const float* mean, const float* gate, float* dx, int32_t dx_ld, float* dw, float* db,

@@ -188,6 +188,7 @@ struct PoolParams {
   const float* __restrict__ y;
   const float* __restrict__ ss;   // [2][C] scale, shift
   const float* __restrict__ res;  // nullable
+  const float* __restrict__ gate; // nullable: [N][C] per-sample channel gates applied after the activation (S3D-G self-gating)
   float* __restrict__ out;
   int relu;
   int cg;  // channel groups = C / VEC
@@ -262,11 +263,20 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p
         if (p.res) z += r[e];
         best[e] = p.relu ? fmaxf(z, 0.f) : z;
       }
+      if (p.gate) {
+        const int n = fastdiv(fastdiv(fastdiv((int)o, p.dWo), p.dHo), p.dDo);
+        float g[VEC];
+        load_vec<VEC>(p.gate + (long long)n * d.C + c, g);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) best[e] *= g[e];
+      }
     } else {
       const int op = (int)o;
       const int q1 = fastdiv(op, p.dWo), ow = op - q1 * d.Wo;
       const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
       const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
+      float g[VEC];
+      if (p.gate) load_vec<VEC>(p.gate + (long long)n * d.C + c, g);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) best[e] = -INFINITY;
       for (int kt = 0; kt < d.kT; ++kt) {
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p
               float z = fmaf(v[e], sc[e], sh[e]);
               if (p.res) z += r[e];
               if (p.relu) z = fmaxf(z, 0.f);
+              if (p.gate) z *= g[e];      // (the gated activation is what the reference pools: models/s3dg.py:105-108)
               best[e] = fmaxf(best[e], z);
             }
           }
@@ -717,12 +728,18 @@ int rsp_bn_finalize_x(const float* stat_partials, int32_t tiles, int32_t C, int3
 
 int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
                         int relu, float* out, void* stream) {
+  return rsp_bn_act_pool_gate_fwd(d, y, scale_shift, residual, relu, nullptr, out, stream);
+}
+
+int rsp_bn_act_pool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
+                             int relu, const float* gate, float* out, void* stream) {
   RSP_REQUIRE(pool_ok(d, false), "rsp_bn_act_pool_fwd: bad descriptor");
   RSP_REQUIRE(y && scale_shift && out, "rsp_bn_act_pool_fwd: null pointer");
   PoolParams p;
-  p.d = *d; p.y = y; p.ss = scale_shift; p.res = residual; p.out = out; p.relu = relu;
+  p.d = *d; p.y = y; p.ss = scale_shift; p.res = residual; p.gate = gate; p.out = out; p.relu = relu;
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(out) &&
-                   rsp_aligned16(scale_shift) && (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual)));
+                   rsp_aligned16(scale_shift) && (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual))) &&
+                   (!gate || rsp_aligned16(gate));
   p.cg = vec ? d->C / 4 : d->C;
   const Layout L = make_layout(d, p.cg, 4);
   RSP_REQUIRE(L.npos < (1ll << 31), "rsp_bn_act_pool_fwd: more than 2^31 - 1 output positions");

@@ -255,6 +255,72 @@ static void launch_spatial_sum(const float* x, const float* x2, int N, int P, in
   else hipLaunchKernelGGL(spatial_sum_kernel, dim3(N * S, rsp_cdiv(C, 64)), dim3(256), 0, s, x, x2, P, C, ld, ld2, S, part);
 }
 
+// The gate's spatial sums taken where its input is PRODUCED: a = relu(y*scale + shift) (the BatchNorm-apply in front of every
+// self-gating unit, models/s3dg.py:52-72), summed per (sample, channel) over the same slices, lanes and LDS tree as
+// spatial_sum_kernel / spatial_sum_vec_kernel — bit-identical partials — and stored to `act` only when a backward will need it.
+// Saves the reduction's own read of the activation; with act == null (key passes) also its write.
+__global__ __launch_bounds__(256) void bn_act_sum_kernel(const float* __restrict__ y, const float* __restrict__ ss, int relu,
+                                                         float* __restrict__ act, int P, int C, int ld, int act_ld, int S,
+                                                         float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x / S, sl = blockIdx.x % S;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int per = (P + S - 1) / S;
+  const int p0 = sl * per, p1 = min(P, p0 + per);
+  float s = 0.f;
+  if (c < C) {
+    const float sc = ss[c], sh = ss[C + c];
+    for (int pp = p0 + pl; pp < p1; pp += 4) {
+      const long long row = (long long)n * P + pp;
+      float z = fmaf(y[row * ld + c], sc, sh);
+      if (relu) z = fmaxf(z, 0.f);
+      if (act) act[row * act_ld + c] = z;
+      s += z;
+    }
+  }
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x;
+    part[((long long)n * S + sl) * C + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
+}
+__global__ __launch_bounds__(256) void bn_act_sum_vec_kernel(const float* __restrict__ y, const float* __restrict__ ss, int relu,
+                                                             float* __restrict__ act, int P, int C, int ld, int act_ld, int S,
+                                                             float* __restrict__ part) {
+  __shared__ floatx4 red[16][16];
+  const int n = blockIdx.x / S, sl = blockIdx.x - n * S;
+  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + q * 4;
+  const int per = (P + S - 1) / S;
+  const int p0 = sl * per, p1 = min(P, p0 + per);
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const floatx4 sc = *reinterpret_cast<const floatx4*>(ss + c), sh = *reinterpret_cast<const floatx4*>(ss + C + c);
+    const float* yp = y + ((long long)n * P) * ld + c;
+    float* ap = act ? act + ((long long)n * P) * act_ld + c : nullptr;
+    for (int pp = p0 + pl; pp < p1; pp += 16) {
+      const floatx4 v = *reinterpret_cast<const floatx4*>(yp + (long long)pp * ld);
+      floatx4 z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        z[e] = fmaf(v[e], sc[e], sh[e]);
+        if (relu) z[e] = fmaxf(z[e], 0.f);
+      }
+      if (ap) *reinterpret_cast<floatx4*>(ap + (long long)pp * act_ld) = z;
+      s += z;
+    }
+  }
+  red[pl][q] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    floatx4 a = red[0][q];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) a += red[l][q];
+    *reinterpret_cast<floatx4*>(part + ((long long)n * S + sl) * C + c) = a;
+  }
+}
+
 // out[n][c] = scale * sum_s part[n][s][c]  (* g*(1-g) when gate != null: the sigmoid derivative of the gating backward)
 __global__ void spatial_sum_final_kernel(const float* __restrict__ part, int N, int C, int S, float scale,
                                          const float* __restrict__ gate, float* __restrict__ out) {
@@ -466,6 +532,50 @@ int rsp_gate_fwd(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld,
   hipLaunchKernelGGL(gate_fc_kernel, dim3(rsp_cdiv((long long)N * C, 4)), dim3(256), 0, s, mean, w, b, N, C, gate);
   rc = rsp_check_launch("gate_fc_kernel");
   if (rc != RSP_OK) return rc;
+  const long long total = (long long)N * P * C;
+  if (gate_vec_ok(P, C, in_ld, out_ld, x, out, gate, nullptr))
+    hipLaunchKernelGGL(gate_apply_vec_kernel, dim3(gate_vec_blocks(P, C, N), N), dim3(256), 0, s, x, gate, (const float*)nullptr, P, C,
+                       in_ld, out_ld, out);
+  else
+    hipLaunchKernelGGL(gate_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, gate, P, C, in_ld, out_ld, total, out);
+  return rsp_check_launch("gate_apply_kernel");
+}
+
+int rsp_bn_gate_sums(const float* y, int32_t N, int32_t P, int32_t C, int32_t y_ld, const float* scale_shift, int relu,
+                     float* act, int32_t act_ld, const float* w, const float* b, float* mean, float* gate, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(y && scale_shift && w && b && mean && gate && workspace, "rsp_bn_gate_sums: null pointer");
+  RSP_REQUIRE(N > 0 && P > 0 && C > 0 && y_ld >= C && (!act || act_ld >= C), "rsp_bn_gate_sums: bad size");
+  if (workspace_bytes < rsp_gate_fwd_workspace(N, P, C)) {
+    rsp_set_error("rsp_bn_gate_sums: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int S = gate_splits(P);
+  float* part = reinterpret_cast<float*>(workspace);
+  const bool vec = C % 4 == 0 && y_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(part) && rsp_aligned16(scale_shift) &&
+                   (!act || (act_ld % 4 == 0 && rsp_aligned16(act)));
+  if (vec)
+    hipLaunchKernelGGL(bn_act_sum_vec_kernel, dim3(N * S, rsp_cdiv(C, 64)), dim3(256), 0, s, y, scale_shift, relu, act, P, C, y_ld, act_ld,
+                       S, part);
+  else
+    hipLaunchKernelGGL(bn_act_sum_kernel, dim3(N * S, rsp_cdiv(C, 64)), dim3(256), 0, s, y, scale_shift, relu, act, P, C, y_ld, act_ld, S,
+                       part);
+  int rc = rsp_check_launch("bn_act_sum_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(spatial_sum_final_kernel, dim3(rsp_cdiv((long long)N * C, 256)), dim3(256), 0, s, part, N, C, S, 1.f / (float)P,
+                     (const float*)nullptr, mean);
+  rc = rsp_check_launch("spatial_sum_final_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(gate_fc_kernel, dim3(rsp_cdiv((long long)N * C, 4)), dim3(256), 0, s, mean, w, b, N, C, gate);
+  return rsp_check_launch("gate_fc_kernel");
+}
+
+int rsp_gate_apply(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* gate, float* out, int32_t out_ld,
+                   void* stream) {
+  RSP_REQUIRE(x && gate && out, "rsp_gate_apply: null pointer");
+  RSP_REQUIRE(N > 0 && P > 0 && C > 0 && in_ld >= C && out_ld >= C, "rsp_gate_apply: bad size");
+  hipStream_t s = (hipStream_t)stream;
   const long long total = (long long)N * P * C;
   if (gate_vec_ok(P, C, in_ld, out_ld, x, out, gate, nullptr))
     hipLaunchKernelGGL(gate_apply_vec_kernel, dim3(gate_vec_blocks(P, C, N), N), dim3(256), 0, s, x, gate, (const float*)nullptr, P, C,

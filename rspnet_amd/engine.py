@@ -370,6 +370,40 @@ class BranchStreams:
             self.join_task()
 
 
+def _gate_fusion(plan: "Plan"):
+    """{index of a ConvBN: (index of the Gate that is the only reader of its output, index of the Pool that is the only reader of
+    the gate's output | None)} — S3D-G's sep_conv units (models/s3dg.py:36-72) and, for the two front-end ones, the max-pool
+    behind them (:105-109).  The three run as one op (ops.bn_act_gate_fwd)."""
+    cached = getattr(plan, "_gate_fusion", None)
+    if cached is not None:
+        return cached
+    readers: Dict[int, List[int]] = {}
+    for i, n in enumerate(plan.nodes):
+        for m in (n.members if isinstance(n, ConvBNGroup) else [n]):
+            for slot in (getattr(m, "src", None), getattr(m, "residual", None)):
+                if slot is not None:
+                    readers.setdefault(slot, []).append(i)
+    table = {}
+    if not os.environ.get("RSP_NO_GATE_FUSION"):
+        for i, n in enumerate(plan.nodes[:-1]):
+            g = plan.nodes[i + 1]
+            if not (isinstance(n, ConvBN) and isinstance(g, Gate) and g.src == n.dst and g.branch == n.branch):
+                continue
+            if n.residual is not None or n.pool or n.into is not None or n.cout_pad or n.virtual_w or n.dst == plan.output_slot:
+                continue
+            if readers.get(n.dst) != [i + 1]:
+                continue
+            pi = None
+            if i + 2 < len(plan.nodes):
+                q = plan.nodes[i + 2]
+                if (isinstance(q, Pool) and g.into is None and q.src == g.dst and q.branch == n.branch and readers.get(g.dst) == [i + 2]
+                        and g.dst != plan.output_slot):
+                    pi = i + 2
+            table[i] = (i + 1, pi)
+    plan._gate_fusion = table
+    return table
+
+
 def _slice_of(slots, into, lead_shape, device):
     """Channel-slice view of a concat tensor, allocating the tensor on first use."""
     slot, off, total = into
@@ -450,7 +484,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         if keep:
             ctx.saved[key] = ("vstem", x_e, x_o, y, mi, ss, cg, pg, vs)
 
-    def convbn(node, key):
+    def convbn(node, key, gated=None):
         xin = slots[node.src]
         if training and node.virtual_w and VirtualStem.applies(node, xin):
             return convbn_virtual(node, key)
@@ -476,6 +510,29 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             if Cp != Cout:
                 ss = torch.cat([ss, torch.zeros((2, Cp - Cout), dtype=ss.dtype, device=ss.device)], dim=1).contiguous()
         do, ho, wo = cg.out_dims
+        if gated is not None:
+            # BatchNorm-apply + self-gating (+ the max-pool behind a front-end unit, when nothing is kept for a backward) in two
+            # passes over y: see _gate_fusion
+            gi, pi = gated
+            gnode = plan.nodes[gi]
+            pnode = plan.nodes[pi] if (pi is not None and not keep) else None
+            pg = PoolGeom(N, do, ho, wo, cg.Cout)
+            out = None
+            if gnode.into is not None:
+                out = _view(_slice_of(slots, gnode.into, (N, do, ho, wo), xin.device), gnode.into, cg.Cout)
+            pool = PoolGeom(N, do, ho, wo, cg.Cout, pnode.k, pnode.s, pnode.p) if pnode is not None else None
+            o, a, mean, gate = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, keep, pool=pool,
+                                                  out=out)
+            if pnode is not None:
+                slots[pnode.dst] = o
+                skipped.add(pi)
+            elif gnode.into is None:
+                slots[gnode.dst] = o
+            skipped.add(gi)
+            if keep:
+                ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, None)
+                ctx.saved[gi] = (a, mean, gate)
+            return
         pg, res = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin)
         if keep:
             ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, res)
@@ -507,9 +564,14 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         if keep:
             ctx.saved[ni] = ("group", xin, y, cg, per)
 
+    fusion = _gate_fusion(plan) if training else {}
+    skipped = set()
+
     def run_node(ni, node):
+        if ni in skipped:
+            return
         if isinstance(node, ConvBN):
-            convbn(node, ni)
+            convbn(node, ni, fusion.get(ni))
         elif isinstance(node, ConvBNGroup):
             convbn_group(node, ni)
         elif isinstance(node, ConvBias):

@@ -373,6 +373,36 @@ class HipOps:
                    "rsp_gate_fwd")
         return out, mean, gate
 
+    def bn_act_gate_fwd(self, pg: PoolGeom, y, scale_shift, relu: bool, w, b, keep_act: bool, pool: Optional[PoolGeom] = None,
+                        out=None):
+        """BatchNorm-apply (+ReLU) and the self-gating unit behind it as one op (models/s3dg.py:52-72; pg: the unit-window
+        geometry of y).  a = act(y*scale + shift); gate = sigmoid(W mean(a) + b); out = a * gate — through `pool` (a max-pool
+        geometry over a's dims, models/s3dg.py:105-109) when given.  keep_act: also materialise a for the backward (then no pool).
+        Returns (out, a | None, mean, gate).  Two passes over y instead of the five tensor passes of bn_act_pool_fwd + gate_fwd."""
+        N, P, Cc = pg.N, pg.Di * pg.Hi * pg.Wi, pg.C
+        y_ld = _rows_ld(y, "y")
+        if keep_act and pool is not None:
+            raise _lib.RspError("bn_act_gate_fwd: the pooled form keeps no activation")
+        a = torch.empty((N, pg.Di, pg.Hi, pg.Wi, Cc), dtype=torch.float32, device=y.device) if keep_act else None
+        mean = torch.empty((N, Cc), dtype=torch.float32, device=y.device)
+        gate = torch.empty((N, Cc), dtype=torch.float32, device=y.device)
+        wsb = self.lib.rsp_gate_fwd_workspace(N, P, Cc)
+        ws = self._workspace(y.device, wsb)
+        _lib.check(self.lib.rsp_bn_gate_sums(_ptr(y), N, P, Cc, y_ld, _ptr(scale_shift), int(relu), _ptr(a), Cc, _ptr(_chk(w, "w")),
+                                             _ptr(_chk(b, "b")), _ptr(mean), _ptr(gate), _ptr(ws), wsb, _stream()), "rsp_bn_gate_sums")
+        og = pool if pool is not None else pg
+        if out is None:
+            do, ho, wo = og.out_dims
+            out = torch.empty((N, do, ho, wo, Cc), dtype=torch.float32, device=y.device)
+        if keep_act:
+            _lib.check(self.lib.rsp_gate_apply(_ptr(a), N, P, Cc, Cc, _ptr(gate), _ptr(out), _rows_ld(out, "out"), _stream()),
+                       "rsp_gate_apply")
+        else:
+            d, dref, _, _ = _pool_plan(0, og, y_ld, _rows_ld(out, "out"), None)
+            _lib.check(self.lib.rsp_bn_act_pool_gate_fwd(dref, _ptr(y), _ptr(scale_shift), None, int(relu), _ptr(gate), _ptr(out),
+                                                         _stream()), "rsp_bn_act_pool_gate_fwd")
+        return out, a, mean, gate
+
     def gate_bwd(self, x, dout, w, mean, gate, dw_out, db_out):
         _chk(x, "x")
         N, D, H, W, Cc = x.shape

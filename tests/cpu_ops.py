@@ -127,6 +127,17 @@ class CpuOps:
             return out, mean, gate
         return o, mean, gate
 
+    def bn_act_gate_fwd(self, pg: PoolGeom, y, scale_shift, relu, w, b, keep_act, pool=None, out=None):
+        a = self.bn_act_pool_fwd(pg, y, scale_shift, None, relu)
+        o, mean, gate = self.gate_fwd(a, w, b)
+        if pool is not None:
+            assert not keep_act
+            o = _ndhwc(F.max_pool3d(_ncdhw(o), pool.k, pool.s, pool.p)).contiguous()
+        if out is not None:
+            out.copy_(o)
+            o = out
+        return o, (a if keep_act else None), mean, gate
+
     @torch.enable_grad()
     def gate_bwd(self, x, dout, w, mean, gate, dw_out, db_out):
         xx = x.detach().requires_grad_(True)

@@ -629,3 +629,35 @@ def test_virtual_pixel_stem_equals_padded_stem(hip):
     from virtual_stem_util import CASES, check_case
     for case in CASES + [(64, 0, (7, 7, 7), (1, 2, 2), (3, 3, 3), (2, 8, 56, 56))]:
         check_case(DEV, case, 3e-5)
+
+
+@pytest.mark.parametrize("N,D,H,W,C,pool", [(2, 4, 12, 12, 64, None), (3, 2, 7, 7, 48, None), (2, 3, 9, 10, 6, None),
+                                              (2, 4, 14, 14, 64, ((1, 3, 3), (1, 2, 2), (0, 1, 1))),
+                                              (2, 4, 9, 9, 10, ((1, 3, 3), (1, 2, 2), (0, 1, 1)))])
+def test_bn_act_gate_fused_is_bit_identical_to_the_three_ops(hip, N, D, H, W, C, pool):
+    """ops.bn_act_gate_fwd (BatchNorm-apply + ReLU + S3D-G self-gating, optionally through the max-pool behind it) against
+    bn_act_pool_fwd -> gate_fwd (-> maxpool_fwd): same bits, with and without the activation kept, into a channel slice too."""
+    y = rnd(N, D, H, W, C, seed=11).to(DEV)
+    ss = torch.stack([rnd(C, seed=12).abs() + 0.5, rnd(C, seed=13) * 0.3]).contiguous().to(DEV)
+    w, b = (rnd(C, C, 1, 1, 1, seed=14) * 0.2).to(DEV), (rnd(C, seed=15) * 0.1).to(DEV)
+    pg = PoolGeom(N, D, H, W, C)
+    a_ref = hip.bn_act_pool_fwd(pg, y, ss, None, True)
+    o_ref, mean_ref, gate_ref = hip.gate_fwd(a_ref, w, b)
+    o, a, mean, gate = hip.bn_act_gate_fwd(pg, y, ss, True, w, b, True)
+    assert torch.equal(a, a_ref) and torch.equal(mean, mean_ref) and torch.equal(gate, gate_ref) and torch.equal(o, o_ref)
+    o2, a2, mean2, gate2 = hip.bn_act_gate_fwd(pg, y, ss, True, w, b, False)
+    assert a2 is None and torch.equal(mean2, mean_ref) and torch.equal(gate2, gate_ref) and torch.equal(o2, o_ref)
+    # into a channel slice of a wider (concat) tensor
+    if C % 2 == 0:
+        cat = torch.zeros(N, D, H, W, C + 8, device=DEV)
+        hip.bn_act_gate_fwd(pg, y, ss, True, w, b, False, out=cat[..., 8:])
+        assert torch.equal(cat[..., 8:], o_ref) and float(cat[..., :8].abs().max()) == 0.0
+    if pool is not None:
+        pp = PoolGeom(N, D, H, W, C, *pool)
+        p_ref, _ = hip.maxpool_fwd(pp, o_ref, False)
+        p3, _, _, _ = hip.bn_act_gate_fwd(pg, y, ss, True, w, b, False, pool=pp)
+        assert torch.equal(p3, p_ref)
+    # and the checker agrees to rounding
+    oc, ac, mc, gc = CPU.bn_act_gate_fwd(pg, y.cpu(), ss.cpu(), True, w.cpu(), b.cpu(), True)
+    close(o, oc, 2e-5, "gated output")
+    close(gate, gc, 2e-5, "gate")

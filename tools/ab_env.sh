@@ -5,9 +5,10 @@ OUT="gpurun_out/$1"; VAR="$2"; shift 2
 mkdir -p "$OUT"
 for spec in "$@"; do
   a="${spec%%:*}"; extra=""; [ "$spec" != "$a" ] && extra="${spec#*:}"
+  tag="$a$(echo "$extra" | tr -d ' -')"
   for rep in 1 2; do
-    python bench.py --arch $a --no-cpu-baseline --no-other-workloads $extra > "$OUT/off_${a}_$rep.json" 2> "$OUT/off_${a}_$rep.err"
-    env $VAR=1 python bench.py --arch $a --no-cpu-baseline --no-other-workloads $extra > "$OUT/on_${a}_$rep.json" 2> "$OUT/on_${a}_$rep.err"
+    python bench.py --arch $a --no-cpu-baseline --no-other-workloads $extra > "$OUT/off_${tag}_$rep.json" 2> "$OUT/off_${tag}_$rep.err"
+    env $VAR=1 python bench.py --arch $a --no-cpu-baseline --no-other-workloads $extra > "$OUT/on_${tag}_$rep.json" 2> "$OUT/on_${tag}_$rep.err"
   done
 done
 python - "$OUT" <<'PY'
