@@ -184,6 +184,166 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const MPParams p) 
   }
 }
 
+// ---- 3x3x3 / stride 1 / pad 1 ("same") pooling: S3D-G's inception branch 3 (models/s3dg.py:90) -----------------------------
+// The generic kernels above load all 27 taps per output (forward) and 27 arg-max + 27 gradient quads per input (backward): at
+// 1.0-1.5 TB/s algorithmic they are bound by L1 traffic, not HBM.  Here a thread owns a run of `seg` positions along W of one
+// (sample, t, h, channel quad) row and slides along it: per step it loads ONE new column — the 9 (kt, kh) rows at w + 1 — and
+// keeps the previous two, so every input quad is loaded 9 times instead of 27.
+struct ColMax {
+  floatx4 v;
+  intx4 r;      // (kt * 3 + kh) of the first maximum in scan order, -1: none (KEEP only)
+};
+
+template <bool KEEP>
+__device__ __forceinline__ ColMax mp333_column(const float* __restrict__ xn, const int (&rowoff)[9], unsigned rowmask, int w, int ld) {
+  ColMax m;
+  m.v = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  m.r = intx4{-1, -1, -1, -1};
+  floatx4 v[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) v[r] = *reinterpret_cast<const floatx4*>(xn + (long long)(rowoff[r] + w) * ld);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    if (!((rowmask >> r) & 1u)) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (KEEP) {
+        if (v[r][e] > m.v[e] || m.r[e] < 0) { m.v[e] = v[r][e]; m.r[e] = r; }
+      } else {
+        m.v[e] = fmaxf(m.v[e], v[r][e]);
+      }
+    }
+  }
+  return m;
+}
+
+template <bool KEEP>
+__global__ __launch_bounds__(256) void maxpool333_fwd_kernel(const MPParams p, int seg, int nseg) {
+  const rsp_pool3d_desc& d = p.d;
+  const int C4 = d.C >> 2;
+  const long long total = (long long)d.N * d.Di * d.Hi * nseg * C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % C4) * 4;
+    int q = (int)(i / C4);
+    const int sg = q % nseg; q /= nseg;
+    const int h = q % d.Hi; q /= d.Hi;
+    const int t = q % d.Di;
+    const int n = q / d.Di;
+    const float* xn = p.x + (long long)n * d.Di * d.Hi * d.Wi * d.in_ld + c;
+    int rowoff[9];
+    unsigned rowmask = 0;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int id = t - 1 + kt, ih = h - 1 + kh;
+        const bool ok = (unsigned)id < (unsigned)d.Di && (unsigned)ih < (unsigned)d.Hi;
+        rowoff[kt * 3 + kh] = (min(max(id, 0), d.Di - 1) * d.Hi + min(max(ih, 0), d.Hi - 1)) * d.Wi;
+        rowmask |= (ok ? 1u : 0u) << (kt * 3 + kh);
+      }
+    const int w0 = sg * seg, w1 = min(d.Wi, w0 + seg);
+    ColMax none;
+    none.v = floatx4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    none.r = intx4{-1, -1, -1, -1};
+    ColMax prev = w0 > 0 ? mp333_column<KEEP>(xn, rowoff, rowmask, w0 - 1, d.in_ld) : none;
+    ColMax cur = mp333_column<KEEP>(xn, rowoff, rowmask, w0, d.in_ld);
+    const long long orow = (((long long)n * d.Do + t) * d.Ho + h) * d.Wo;
+    for (int w = w0; w < w1; ++w) {
+      const ColMax next = w + 1 < d.Wi ? mp333_column<KEEP>(xn, rowoff, rowmask, w + 1, d.in_ld) : none;
+      floatx4 best;
+      if (KEEP) {
+        // first maximum in (kt, kh, kw) scan order, like max_pool3d: among equal values the smaller (kt, kh), then the smaller kw
+        intx4 bi;
+        const ColMax* col[3] = {&prev, &cur, &next};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float bv = -INFINITY;
+          int br = -1, bk = 0;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float v = col[kw]->v[e];
+            const int r = col[kw]->r[e];
+            if (r >= 0 && (br < 0 || v > bv || (v == bv && r < br))) { bv = v; br = r; bk = kw; }
+          }
+          best[e] = bv;
+          const int kt = br / 3, kh = br - kt * 3;
+          bi[e] = ((t - 1 + kt) * d.Hi + (h - 1 + kh)) * d.Wi + (w - 1 + bk);
+        }
+        *reinterpret_cast<intx4*>(p.idx + (orow + w) * d.C + c) = bi;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) best[e] = fmaxf(fmaxf(prev.v[e], cur.v[e]), next.v[e]);
+      }
+      *reinterpret_cast<floatx4*>(p.out + (orow + w) * d.out_ld + c) = best;
+      prev = cur;
+      cur = next;
+    }
+  }
+}
+
+// Backward of the same pooling, input-centric and sliding the same way: a thread owns a run of input positions of one row; per
+// step it loads the arg-max and gradient quads of ONE output column (the 9 (od, oh) rows at ow) and adds them into the three
+// inputs iw = ow - 1 .. ow + 1 of its row they may point at.  Fixed order (ow ascending, then od, oh) -> deterministic.
+__global__ __launch_bounds__(256) void maxpool333_bwd_kernel(const MPParams p, int seg, int nseg) {
+  const rsp_pool3d_desc& d = p.d;
+  const int C4 = d.C >> 2;
+  const long long total = (long long)d.N * d.Di * d.Hi * nseg * C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const int c = (int)(i % C4) * 4;
+    int q = (int)(i / C4);
+    const int sg = q % nseg; q /= nseg;
+    const int h = q % d.Hi; q /= d.Hi;
+    const int t = q % d.Di;
+    const int n = q / d.Di;
+    int rowoff[9];
+    unsigned rowmask = 0;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int od = t - 1 + kt, oh = h - 1 + kh;
+        const bool ok = (unsigned)od < (unsigned)d.Do && (unsigned)oh < (unsigned)d.Ho;
+        rowoff[kt * 3 + kh] = (min(max(od, 0), d.Do - 1) * d.Ho + min(max(oh, 0), d.Ho - 1)) * d.Wo;
+        rowmask |= (ok ? 1u : 0u) << (kt * 3 + kh);
+      }
+    const long long obase = (long long)n * d.Do * d.Ho * d.Wo;
+    const int lin0 = (t * d.Hi + h) * d.Wi;
+    const int w0 = sg * seg, w1 = min(d.Wi, w0 + seg);
+    floatx4 acc[3];      // gradients of iw = ow - 1, ow, ow + 1 while column ow is being added
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int ow = max(w0 - 1, 0); ow <= min(w1, d.Wo - 1); ++ow) {
+      intx4 a[9];
+      floatx4 g[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        a[r] = *reinterpret_cast<const intx4*>(p.idx + (obase + rowoff[r] + ow) * d.C + c);
+        g[r] = *reinterpret_cast<const floatx4*>(p.dout + (obase + rowoff[r] + ow) * d.out_ld + c);
+      }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        if (!((rowmask >> r) & 1u)) continue;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int lin = lin0 + ow - 1 + k;
+          const bool inrow = (unsigned)(ow - 1 + k) < (unsigned)d.Wi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (inrow && a[r][e] == lin) acc[k][e] += g[r][e];
+        }
+      }
+      // input ow - 1 has now seen its last window (ow): store it if it belongs to this thread's run
+      const int done = ow - 1;
+      if (done >= w0 && done < w1) *reinterpret_cast<floatx4*>(p.dx + ((long long)n * d.Di * d.Hi * d.Wi + lin0 + done) * d.in_ld + c) = acc[0];
+      acc[0] = acc[1];
+      acc[1] = acc[2];
+      acc[2] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the run's last input when the row ends with it (no window ow = Wi)
+    if (w1 == d.Wi) *reinterpret_cast<floatx4*>(p.dx + ((long long)n * d.Di * d.Hi * d.Wi + lin0 + w1 - 1) * d.in_ld + c) = acc[0];
+  }
+}
+
 // ---- S3D-G gating ---------------------------------------------------------------------------------------------------
 // sum over a slice of positions per (sample, channel): block = (sample*S + slice, 64-channel group), 4 position lanes.
 // Two deterministic stages so that a (16, 8x112x112, 64) tensor is reduced by thousands of workgroups, not sixteen.
@@ -454,6 +614,23 @@ int gate_splits(int P) {
   const int s = (P + 255) / 256;
   return s > 64 ? 64 : (s < 1 ? 1 : s);
 }
+bool mp_same333(const rsp_pool3d_desc* d) {
+#ifdef RSP_TUNE
+  if (getenv("RSP_NO_POOL333")) return false;
+#endif
+  return d->kT == 3 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 1 && d->pH == 1 && d->pW == 1;
+}
+
+// positions along W per thread: whole rows.  Shorter runs (more threads, one re-read column on either side of each run) were swept
+// on S3D-G's nine branch pools — 1 / 2 / 3 / 4 / 7 / 14 / 28 — and lose everywhere: the kernels are bound by L1 traffic, not by
+// occupancy (28x28x192 forward 106 / 145 / 125 / 113 / 99 / 72 / 56 us; 14x14x480: 38 / 40 / 38 / 32 / 33 / 20 / 20 us).
+int mp333_seg(const rsp_pool3d_desc* d) {
+#ifdef RSP_TUNE
+  if (const char* e = getenv("RSP_POOL_SEG")) return atoi(e) < d->Wi ? atoi(e) : d->Wi;
+#endif
+  return d->Wi;
+}
+
 int grid_for(long long total) {
   long long b = (total + 255) / 256;
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -475,7 +652,12 @@ int rsp_maxpool3d_fwd(const rsp_pool3d_desc* d, const float* x, float* out, int3
     const dim3 grid(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4)));
     hipStream_t st = (hipStream_t)stream;
     const int kkk = d->kT * 100 + d->kH * 10 + d->kW;
-    if (kkk == 333) {
+    if (mp_same333(d)) {
+      const int seg = mp333_seg(d), nseg = rsp_cdiv(d->Wi, seg);
+      const dim3 g3(grid_for((long long)d->N * d->Di * d->Hi * nseg * (d->C / 4)));
+      if (argmax) hipLaunchKernelGGL((maxpool333_fwd_kernel<true>), g3, dim3(256), 0, st, p, seg, nseg);
+      else hipLaunchKernelGGL((maxpool333_fwd_kernel<false>), g3, dim3(256), 0, st, p, seg, nseg);
+    } else if (kkk == 333) {
       if (argmax) hipLaunchKernelGGL((maxpool_fwd_vec_kernel<true, 3, 3, 3>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((maxpool_fwd_vec_kernel<false, 3, 3, 3>), grid, dim3(256), 0, st, p);
     } else if (kkk == 133) {
@@ -499,7 +681,11 @@ int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t
   p.d = *d; p.dout = dout; p.idx = const_cast<int*>(argmax); p.dx = dx;
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(dout) && rsp_aligned16(dx) &&
                    rsp_aligned16(argmax) && (long long)d->N * d->Di * d->Hi * d->Wi * (d->C / 4) < (1ll << 31);
-  if (vec)
+  if (vec && mp_same333(d)) {
+    const int seg = mp333_seg(d), nseg = rsp_cdiv(d->Wi, seg);
+    hipLaunchKernelGGL(maxpool333_bwd_kernel, dim3(grid_for((long long)d->N * d->Di * d->Hi * nseg * (d->C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, p, seg, nseg);
+  } else if (vec)
     hipLaunchKernelGGL(maxpool_bwd_vec_kernel, dim3(grid_for((long long)d->N * d->Di * d->Hi * d->Wi * (d->C / 4))), dim3(256), 0,
                        (hipStream_t)stream, p);
   else

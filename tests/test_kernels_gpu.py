@@ -371,6 +371,14 @@ MAXPOOL_CASES = [
     (2, 2, 5, 9, 8, (1, 3, 3), (1, 2, 1), (0, 0, 0)),
     (1, 2, 4, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (2, 5, 9, 6, 192, (2, 1, 3), (2, 1, 1), (0, 0, 1)),
+    # the sliding 3x3x3 / stride 1 / pad 1 kernels (maxpool333_*): whole-row runs, split runs (14 = 2 x 7, 28 = 4 x 7, 9 = 5 + 4),
+    # single-column and single-plane inputs
+    (16, 2, 7, 7, 832, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 4, 14, 14, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 2, 5, 28, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 3, 4, 9, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 1, 1, 1, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 1, 6, 2, 12, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 ]
 
 
