@@ -95,22 +95,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_stage2(const double* __restr
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
 }
 
-// Single-launch variant for up to a few thousand tiles: one workgroup of 1024 threads per 64 channels — 16 tile-lanes per channel
-// reduce the [tiles][C][2] partials in fp64 (fixed order: lane-strided, then a 16-way LDS tree read in index order), then the
-// first 64 threads finalize their channel exactly as bn_finalize_stage2 does.  Replaces two ~6 us launches per BatchNorm by one
-// (S3D-G runs 231 BatchNorm forwards per step).
-__global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __restrict__ part, int tiles, int C, int Cv, int ld, long long count,
-                                                               const float* __restrict__ conv_bias, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float eps, float momentum,
-                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                               float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
-                                                               float* __restrict__ bstat) {
-  __shared__ double red[16][64][2];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  double s = 0.0, ss = 0.0;
+// Single-launch variant for up to a few thousand tiles: one workgroup of 1024 threads per FIN_CH = 16 channels — 64 tile-lanes per
+// channel reduce the [tiles][C][2] partials in fp64 (fixed order: lane-strided, then an 8 x 8 LDS tree read in index order), then
+// the first 16 threads finalize their channel exactly as bn_finalize_stage2 does.  Replaces two ~6 us launches per BatchNorm by
+// one (S3D-G runs 231 BatchNorm forwards per step).  (A first version gave a workgroup 64 channels x 16 lanes: a 64-channel layer
+// with 2 048 tiles was then read by ONE compute unit — 17-29 us per BatchNorm on C3D / R(2+1)D, forward and backward.)
+constexpr int FIN_CH = 16, FIN_LANES = 1024 / FIN_CH;
+
+// Sum of the [n][C][2] fp32 partials (row pitch ld channels) of channel blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), in double.
+// Returns true in the ONE thread per channel that holds the totals.
+__device__ __forceinline__ bool fin_sum_partials(const float* __restrict__ part, int n, int C, int ld, double& s, double& ss) {
+  __shared__ double red[FIN_LANES][FIN_CH][2];
+  const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  s = 0.0;
+  ss = 0.0;
   if (c < C)
-    for (int t = rl; t < tiles; t += 16) {
+    for (int t = rl; t < n; t += FIN_LANES) {
       const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * ld + c) * 2);
       s += (double)v.x;
       ss += (double)v.y;
@@ -118,14 +119,41 @@ __global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __re
   red[rl][cl][0] = s;
   red[rl][cl][1] = ss;
   __syncthreads();
-  if (rl != 0 || c >= C) return;
+  if (rl < 8) {
+    s = 0.0;
+    ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < FIN_LANES / 8; ++i) {
+      s += red[rl * (FIN_LANES / 8) + i][cl][0];
+      ss += red[rl * (FIN_LANES / 8) + i][cl][1];
+    }
+  }
+  __syncthreads();
+  if (rl < 8) {
+    red[rl][cl][0] = s;
+    red[rl][cl][1] = ss;
+  }
+  __syncthreads();
+  if (rl != 0 || c >= C) return false;
   s = 0.0;
   ss = 0.0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 8; ++i) {
     s += red[i][cl][0];
     ss += red[i][cl][1];
   }
+  return true;
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_one_kernel(const float* __restrict__ part, int tiles, int C, int Cv, int ld, long long count,
+                                                               const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                               float* __restrict__ bstat) {
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+  double s, ss;
+  if (!fin_sum_partials(part, tiles, C, ld, s, ss)) return;
   const double n = (double)count;
   const double mean0 = s / n;                   // mean of the bias-free conv output
   double var = ss / n - mean0 * mean0;          // biased
@@ -435,31 +463,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
   }
 }
 
-// sums[c] = (sum dz, sum dz*xhat) in double; also dgamma / dbeta.  Block = 64 channels x 16 partial-row lanes.
+// sums[c] = (sum dz, sum dz*xhat) in double; also dgamma / dbeta.  Block = FIN_CH channels x 64 partial-row lanes.
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int Cv,
                                                                double* __restrict__ sums, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta) {
-  __shared__ double red[16][64][2];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int i = rl; i < nblocks; i += 16) {
-      const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)i * C + c) * 2);
-      a += (double)v.x;
-      b += (double)v.y;
-    }
-  red[rl][cl][0] = a;
-  red[rl][cl][1] = b;
-  __syncthreads();
-  if (rl == 0 && c < C) {
-    a = 0.0; b = 0.0;
-    for (int l = 0; l < 16; ++l) { a += red[l][cl][0]; b += red[l][cl][1]; }
-    sums[2 * c] = a;
-    sums[2 * c + 1] = b;
-    if (dbeta && c < Cv) dbeta[c] = (float)a;
-    if (dgamma && c < Cv) dgamma[c] = (float)b;
-  }
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+  double a, b;
+  if (!fin_sum_partials(partial, nblocks, C, C, a, b)) return;
+  sums[2 * c] = a;
+  sums[2 * c + 1] = b;
+  if (dbeta && c < Cv) dbeta[c] = (float)a;
+  if (dgamma && c < Cv) dgamma[c] = (float)b;
 }
 
 // pass 2: input-centric.  dy = gamma*invstd*(dz_in - mean(dz) - xhat*mean(dz*xhat)); dz_in = dout*mask if this position
@@ -713,7 +727,7 @@ int rsp_bn_finalize_x(const float* stat_partials, int32_t tiles, int32_t C, int3
   }
   hipStream_t s = (hipStream_t)stream;
   if (tiles <= 2048) {
-    hipLaunchKernelGGL(bn_finalize_one_kernel, dim3(rsp_cdiv(C, 64)), dim3(1024), 0, s, stat_partials, tiles, C, c_valid, stat_ld, (long long)count,
+    hipLaunchKernelGGL(bn_finalize_one_kernel, dim3(rsp_cdiv(C, FIN_CH)), dim3(1024), 0, s, stat_partials, tiles, C, c_valid, stat_ld, (long long)count,
                        conv_bias, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift, batch_stats_out);
     return rsp_check_launch("bn_finalize_one_kernel");
   }
@@ -798,7 +812,7 @@ int rsp_bn_act_pool_bwd_v(const rsp_pool3d_desc* d, const float* y, const float*
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, rgrid, dim3(256), 0, s, p);
   int rc = rsp_check_launch("bn_bwd_reduce_kernel");
   if (rc != RSP_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, 64)), dim3(1024), 0, s, p.partial, p.nblocks, d->C, c_valid, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, FIN_CH)), dim3(1024), 0, s, p.partial, p.nblocks, d->C, c_valid, sums,
                      dgamma, dbeta);
   rc = rsp_check_launch("bn_bwd_finalize_kernel");
   if (rc != RSP_OK) return rc;
