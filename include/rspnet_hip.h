@@ -195,6 +195,13 @@ int rsp_bn_act_pool_bwd_v(const rsp_pool3d_desc* d, const float* y, const float*
                           float* dres, float* dgamma, float* dbeta, int32_t c_valid, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* ... behind an S3D-G self-gating unit whose forward kept no activation (rsp_bn_gate_sums, act == NULL): dout is the gradient of
+ * the GATED output; gate [N][C] from the forward, dmean [N][C] from rsp_gate_bwd_params.  Unit windows, no residual. */
+int rsp_bn_act_pool_bwd_g(const rsp_pool3d_desc* d, const float* y, const float* residual, const float* dout,
+                          const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
+                          float* dres, float* dgamma, float* dbeta, int32_t c_valid, const float* gate, const float* dmean,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Stand-alone MaxPool3d, any window/stride/padding (models/resnet.py:139, models/s3dg.py:90,107-119).
  * argmax (nullable in forward when no backward is needed): [N,Do,Ho,Wo,C] int32, linear input position per sample. */
 int rsp_maxpool3d_fwd(const rsp_pool3d_desc* d, const float* x, float* out, int32_t* argmax, void* stream);
@@ -217,6 +224,11 @@ int rsp_bn_gate_sums(const float* y, int32_t N, int32_t P, int32_t C, int32_t y_
                      size_t workspace_bytes, void* stream);
 int rsp_gate_apply(const float* x, int32_t N, int32_t P, int32_t C, int32_t in_ld, const float* gate, float* out, int32_t out_ld,
                    void* stream);
+/* Parameter half of the gating backward with the activation recomputed from y: dw (C,C), db (C) and dmean [N][C] (the data half
+ * runs inside rsp_bn_act_pool_bwd_g).  Workspace: rsp_gate_bwd_workspace(N, P, C). */
+int rsp_gate_bwd_params(const float* y, const float* scale_shift, int relu, const float* dout, int32_t N, int32_t P, int32_t C,
+                        int32_t y_ld, int32_t dout_ld, const float* w, const float* mean, const float* gate, float* dw, float* db,
+                        float* dmean, void* workspace, size_t workspace_bytes, void* stream);
 size_t rsp_gate_bwd_workspace(int32_t N, int32_t P, int32_t C);
 int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_t C, int32_t x_ld, int32_t dout_ld,
                  const float* w, const float* mean, const float* gate, float* dx, int32_t dx_ld, float* dw, float* db,

@@ -95,12 +95,14 @@ SIGNATURES = {
     "rsp_bn_bwd_workspace": (_sz, [_PP]),
     "rsp_bn_act_pool_bwd": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_bn_act_pool_bwd_v": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _i32, _p, _sz, _p]),
+    "rsp_bn_act_pool_bwd_g": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "rsp_maxpool3d_fwd": (C.c_int, [_PP, _p, _p, _p, _p]),
     "rsp_maxpool3d_bwd": (C.c_int, [_PP, _p, _p, _p, _p]),
     "rsp_gate_fwd_workspace": (_sz, [_i32, _i32, _i32]),
     "rsp_gate_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "rsp_bn_gate_sums": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, C.c_int, _p, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_gate_apply": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    "rsp_gate_bwd_params": (C.c_int, [_p, _p, C.c_int, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_gate_bwd_workspace": (_sz, [_i32, _i32, _i32]),
     "rsp_gate_bwd": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "rsp_head_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),

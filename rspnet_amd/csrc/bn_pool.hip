@@ -360,7 +360,21 @@ struct BwdParams {
   long long npos;
   FastDiv dcgc, dWo, dHo, dDo;
   int Cv;           // valid channels: gamma / dgamma / dbeta hold Cv entries, channels [Cv, C) are zero padding (gamma = 0)
+  // S3D-G self-gating behind this BatchNorm (unit windows only): the incoming gradient is that of the GATED output; the gradient
+  // at the activation is dout*gate[n][c] + dmean[n][c]/P (rsp_gate_bwd_params), formed on the fly instead of by a kernel of its own
+  const float* __restrict__ gate;   // nullable [N][C]
+  const float* __restrict__ dmean;  // [N][C]
+  float invP;
 };
+
+template <int VEC>
+__device__ __forceinline__ void gated_grad(const BwdParams& p, int n, int c, float (&g)[VEC]) {
+  float gt[VEC], dm[VEC];
+  load_vec<VEC>(p.gate + (long long)n * p.d.C + c, gt);
+  load_vec<VEC>(p.dmean + (long long)n * p.d.C + c, dm);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) g[e] = fmaf(g[e], gt[e], dm[e] * p.invP);
+}
 
 // gamma of VEC channels starting at c (1 when there is no affine weight, 0 for padding channels)
 template <int VEC>
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
       }
       float g[VEC];
       load_vec<VEC>(p.dout + op * d.out_ld + c, g);
+      if (p.gate) gated_grad<VEC>(p, n, c, g);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float dz = (p.relu && !(best[e] > 0.f)) ? 0.f : g[e];
@@ -577,6 +592,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p
     load_vec<VEC>(p.dout + o * d.out_ld + c, g);
     if (nwin == 1) {
       // no pooling: the position is its own window
+      if (p.gate) gated_grad<VEC>(p, fastdiv(fastdiv(fastdiv((int)o, p.dWo), p.dHo), p.dDo), c, g);
       float yv[VEC], z[VEC], ov[VEC], dz[VEC];
       zval<VEC>(p, o, c, sc, sh, yv, z);
 #pragma unroll
@@ -780,7 +796,17 @@ int rsp_bn_act_pool_bwd_v(const rsp_pool3d_desc* d, const float* y, const float*
                           const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
                           float* dres, float* dgamma, float* dbeta, int32_t c_valid, void* workspace, size_t workspace_bytes,
                           void* stream) {
+  return rsp_bn_act_pool_bwd_g(d, y, residual, dout, gamma, mean_invstd, scale_shift, relu, dy, dres, dgamma, dbeta, c_valid, nullptr,
+                               nullptr, workspace, workspace_bytes, stream);
+}
+
+int rsp_bn_act_pool_bwd_g(const rsp_pool3d_desc* d, const float* y, const float* residual, const float* dout,
+                          const float* gamma, const float* mean_invstd, const float* scale_shift, int relu, float* dy,
+                          float* dres, float* dgamma, float* dbeta, int32_t c_valid, const float* gate, const float* dmean,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   RSP_REQUIRE(pool_ok(d, true), "rsp_bn_act_pool_bwd: needs disjoint windows (kernel == stride, no padding)");
+  RSP_REQUIRE(!gate || (dmean && d->kT * d->kH * d->kW == 1 && d->sT * d->sH * d->sW == 1 && !residual),
+              "rsp_bn_act_pool_bwd: a gated unit has a unit window, no residual, and needs dmean");
   RSP_REQUIRE(c_valid > 0 && c_valid <= d->C, "rsp_bn_act_pool_bwd: bad valid channel count");
   RSP_REQUIRE(y && dout && mean_invstd && scale_shift && dy && workspace, "rsp_bn_act_pool_bwd: null pointer");
   if (workspace_bytes < rsp_bn_bwd_workspace(d)) {
@@ -793,11 +819,14 @@ int rsp_bn_act_pool_bwd_v(const rsp_pool3d_desc* d, const float* y, const float*
   p.d = *d; p.y = y; p.res = residual; p.dout = dout; p.gamma = gamma; p.mi = mean_invstd; p.ss = scale_shift;
   p.dy = dy; p.dres = dres; p.relu = relu;
   p.Cv = c_valid;
+  p.gate = gate; p.dmean = dmean;
+  p.invP = 1.f / (float)((long long)d->Di * d->Hi * d->Wi);
   p.count = (long long)d->N * d->Di * d->Hi * d->Wi;
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(dout) &&
                    rsp_aligned16(dy) && rsp_aligned16(scale_shift) && rsp_aligned16(mean_invstd) &&
                    (!gamma || c_valid != d->C || rsp_aligned16(gamma)) &&
-                   (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual) && (!dres || rsp_aligned16(dres))));
+                   (!residual || (d->res_ld % 4 == 0 && rsp_aligned16(residual) && (!dres || rsp_aligned16(dres)))) &&
+                   (!gate || (rsp_aligned16(gate) && rsp_aligned16(dmean)));
   p.cg = vec ? d->C / 4 : d->C;
   p.partial = reinterpret_cast<float*>(workspace);
   double* sums = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(workspace) +

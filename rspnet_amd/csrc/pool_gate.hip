@@ -481,6 +481,68 @@ __global__ __launch_bounds__(256) void bn_act_sum_vec_kernel(const float* __rest
   }
 }
 
+// Backward twin: sum_p dout * a with a = relu(y*scale + shift) recomputed from y (the forward kept no activation) — the lanes,
+// slices and tree of spatial_sum_kernel / spatial_sum_vec_kernel with x2 = a.
+__global__ __launch_bounds__(256) void dout_act_sum_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                           const float* __restrict__ ss, int relu, int P, int C, int dout_ld, int y_ld,
+                                                           int S, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x / S, sl = blockIdx.x % S;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int per = (P + S - 1) / S;
+  const int p0 = sl * per, p1 = min(P, p0 + per);
+  float s = 0.f;
+  if (c < C) {
+    const float sc = ss[c], sh = ss[C + c];
+    for (int pp = p0 + pl; pp < p1; pp += 4) {
+      const long long row = (long long)n * P + pp;
+      float z = fmaf(y[row * y_ld + c], sc, sh);
+      if (relu) z = fmaxf(z, 0.f);
+      s = fmaf(dout[row * dout_ld + c], z, s);
+    }
+  }
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x;
+    part[((long long)n * S + sl) * C + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
+}
+__global__ __launch_bounds__(256) void dout_act_sum_vec_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                               const float* __restrict__ ss, int relu, int P, int C, int dout_ld,
+                                                               int y_ld, int S, float* __restrict__ part) {
+  __shared__ floatx4 red[16][16];
+  const int n = blockIdx.x / S, sl = blockIdx.x - n * S;
+  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + q * 4;
+  const int per = (P + S - 1) / S;
+  const int p0 = sl * per, p1 = min(P, p0 + per);
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const floatx4 sc = *reinterpret_cast<const floatx4*>(ss + c), sh = *reinterpret_cast<const floatx4*>(ss + C + c);
+    const float* dp = dout + ((long long)n * P) * dout_ld + c;
+    const float* yp = y + ((long long)n * P) * y_ld + c;
+    for (int pp = p0 + pl; pp < p1; pp += 16) {
+      const floatx4 a = *reinterpret_cast<const floatx4*>(dp + (long long)pp * dout_ld);
+      const floatx4 v = *reinterpret_cast<const floatx4*>(yp + (long long)pp * y_ld);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float z = fmaf(v[e], sc[e], sh[e]);
+        if (relu) z = fmaxf(z, 0.f);
+        s[e] = fmaf(a[e], z, s[e]);
+      }
+    }
+  }
+  red[pl][q] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    floatx4 a = red[0][q];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) a += red[l][q];
+    *reinterpret_cast<floatx4*>(part + ((long long)n * S + sl) * C + c) = a;
+  }
+}
+
 // out[n][c] = scale * sum_s part[n][s][c]  (* g*(1-g) when gate != null: the sigmoid derivative of the gating backward)
 __global__ void spatial_sum_final_kernel(const float* __restrict__ part, int N, int C, int S, float scale,
                                          const float* __restrict__ gate, float* __restrict__ out) {
@@ -809,6 +871,42 @@ int rsp_gate_bwd(const float* x, const float* dout, int32_t N, int32_t P, int32_
     hipLaunchKernelGGL(gate_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dout, gate, dmean, P, C, dout_ld, dx_ld,
                        total, dx);
   return rsp_check_launch("gate_bwd_apply_kernel");
+}
+
+// Parameter half of the gating backward for a unit whose forward kept no activation (rsp_bn_gate_sums with act == NULL): the
+// activation is recomputed from y.  Writes dw, db and dmean ([N][C], = d loss / d sum_p a before the 1/P) for
+// rsp_bn_act_pool_bwd_g, which folds the data half (dx = dout*gate + dmean/P) into the BatchNorm backward in front of it.
+int rsp_gate_bwd_params(const float* y, const float* scale_shift, int relu, const float* dout, int32_t N, int32_t P, int32_t C,
+                        int32_t y_ld, int32_t dout_ld, const float* w, const float* mean, const float* gate, float* dw, float* db,
+                        float* dmean, void* workspace, size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(y && scale_shift && dout && w && mean && gate && dw && db && dmean && workspace, "rsp_gate_bwd_params: null pointer");
+  RSP_REQUIRE(N > 0 && P > 0 && C > 0 && y_ld >= C && dout_ld >= C, "rsp_gate_bwd_params: bad size");
+  if (workspace_bytes < rsp_gate_bwd_workspace(N, P, C)) {
+    rsp_set_error("rsp_gate_bwd_params: workspace too small");
+    return RSP_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* dpre = reinterpret_cast<float*>(workspace);
+  const int S = gate_splits(P);
+  float* part = dpre + (size_t)2 * N * C;
+  const bool vec = C % 4 == 0 && y_ld % 4 == 0 && dout_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(dout) && rsp_aligned16(part) &&
+                   rsp_aligned16(scale_shift);
+  if (vec)
+    hipLaunchKernelGGL(dout_act_sum_vec_kernel, dim3(N * S, rsp_cdiv(C, 64)), dim3(256), 0, s, dout, y, scale_shift, relu, P, C, dout_ld,
+                       y_ld, S, part);
+  else
+    hipLaunchKernelGGL(dout_act_sum_kernel, dim3(N * S, rsp_cdiv(C, 64)), dim3(256), 0, s, dout, y, scale_shift, relu, P, C, dout_ld, y_ld,
+                       S, part);
+  int rc = rsp_check_launch("dout_act_sum_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(spatial_sum_final_kernel, dim3(rsp_cdiv((long long)N * C, 256)), dim3(256), 0, s, part, N, C, S, 1.f, gate, dpre);
+  rc = rsp_check_launch("spatial_sum_final_kernel(bwd)");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(gate_bwd_param_kernel, dim3(rsp_cdiv((long long)C * C, 256)), dim3(256), 0, s, dpre, mean, N, C, dw, db);
+  rc = rsp_check_launch("gate_bwd_param_kernel");
+  if (rc != RSP_OK) return rc;
+  hipLaunchKernelGGL(gate_bwd_dmean_kernel, dim3(rsp_cdiv(C, 64), N), dim3(1024), 0, s, dpre, w, N, C, dmean);
+  return rsp_check_launch("gate_bwd_dmean_kernel");
 }
 
 }  // extern "C"

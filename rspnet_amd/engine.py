@@ -219,6 +219,7 @@ def _pad_vec(v: torch.Tensor, n: int, fill: float = 0.0) -> torch.Tensor:
 
 
 INPUT_CHANNEL_PAD = 4
+GATE_BWD_FUSED = not os.environ.get("RSP_NO_GATE_BWD_FUSION")      # (A/B switch for measurements)
 
 
 class VirtualStem:
@@ -521,7 +522,9 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             if gnode.into is not None:
                 out = _view(_slice_of(slots, gnode.into, (N, do, ho, wo), xin.device), gnode.into, cg.Cout)
             pool = PoolGeom(N, do, ho, wo, cg.Cout, pnode.k, pnode.s, pnode.p) if pnode is not None else None
-            o, a, mean, gate = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, keep, pool=pool,
+            # (a backward recomputes the activation from y: nothing but the (sample, channel) means and gates is kept)
+            keep_act = keep and not GATE_BWD_FUSED
+            o, a, mean, gate = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, keep_act, pool=pool,
                                                   out=out)
             if pnode is not None:
                 slots[pnode.dst] = o
@@ -531,7 +534,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             skipped.add(gi)
             if keep:
                 ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, None)
-                ctx.saved[gi] = (a, mean, gate)
+                ctx.saved[gi] = (a, mean, gate) if keep_act else ("fused", key, mean, gate)
             return
         pg, res = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin)
         if keep:
@@ -625,6 +628,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
     packed = packed if packed is not None else ctx.packed
     dslots: Dict[int, torch.Tensor] = {plan.output_slot: dfeat}
     branches = BranchStreams(dfeat)
+    fused_gates: Dict[int, Tuple] = {}      # key of a ConvBN -> (index, means, gates) of the gate fused behind it
 
     def add_grad(slot, g):
         # gradient accumulation at fan-out points; g is always the fresh output of the op that produced it, so the sum is
@@ -660,13 +664,27 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
         sv = ctx.saved.pop(key)
         if isinstance(sv, tuple) and sv[0] == "vstem":
             return convbn_virtual_bwd(node, sv, ni)
-        if node.into is not None:
+        bn = node.bn
+        gated = fused_gates.pop(key, None)
+        if gated is not None:
+            pass
+        elif node.into is not None:
             dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout)
         else:
             dout = dslots.pop(node.dst)
-        bn = node.bn
-        dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
-                                      node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
+        if gated is not None:
+            # the self-gating unit behind this BatchNorm, whose forward kept no activation: both backwards as one op
+            gi, mean, gate = gated
+            gnode = plan.nodes[gi]
+            dout = _view(dslots[gnode.into[0]], gnode.into, sv.cg.Cout) if gnode.into is not None else dslots.pop(gnode.dst)
+            dy = be.bn_act_gate_bwd(sv.pg, sv.y, dout, bn.weight.data, sv.mi, sv.ss, node.relu, gnode.conv.weight.data, mean, gate,
+                                    grad_of(bn.weight), grad_of(bn.bias), grad_of(gnode.conv.weight), grad_of(gnode.conv.bias))
+            dres = None
+            if after_param_grads is not None:
+                after_param_grads(gi)
+        else:
+            dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
+                                          node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
         if node.residual is not None:
             add_grad(node.residual, dres)
         bias = getattr(node.conv, "bias", None)
@@ -736,7 +754,11 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             pg, idx = ctx.saved.pop(ni)
             add_grad(node.src, be.maxpool_bwd(pg, dslots.pop(node.dst), idx))
         elif isinstance(node, Gate):
-            xin, mean, gate = ctx.saved.pop(ni)
+            sv = ctx.saved.pop(ni)
+            if sv[0] == "fused":      # its backward runs with the BatchNorm's in front of it (convbn_bwd)
+                fused_gates[sv[1]] = (ni, sv[2], sv[3])
+                return
+            xin, mean, gate = sv
             dout = (_view(dslots[node.into[0]], node.into, xin.shape[4]) if node.into is not None
                     else dslots.pop(node.dst))
             add_grad(node.src, be.gate_bwd(xin, dout, node.conv.weight.data, mean, gate, grad_of(node.conv.weight),

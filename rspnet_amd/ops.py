@@ -403,6 +403,30 @@ class HipOps:
                                                          _stream()), "rsp_bn_act_pool_gate_fwd")
         return out, a, mean, gate
 
+    def bn_act_gate_bwd(self, pg: PoolGeom, y, dout, gamma, mean_invstd, scale_shift, relu: bool, w, mean, gate,
+                        dgamma_out, dbeta_out, dw_out, db_out):
+        """Backward of bn_act_gate_fwd(keep_act=False): dout is the gradient of the gated output (possibly a channel slice of
+        a concat gradient).  Gate parameter gradients into dw_out / db_out, BatchNorm's into dgamma_out / dbeta_out; returns dy.
+        The activation is recomputed from y, and the gate's data gradient dout*gate + dmean/P is formed inside the BatchNorm
+        backward kernels: seven tensor passes instead of the nine of gate_bwd + bn_act_pool_bwd."""
+        N, P, Cc = pg.N, pg.Di * pg.Hi * pg.Wi, pg.C
+        _chk(y, "y")
+        dout_ld = _rows_ld(dout, "dout")
+        dmean = torch.empty((N, Cc), dtype=torch.float32, device=y.device)
+        wsb = self.lib.rsp_gate_bwd_workspace(N, P, Cc)
+        ws = self._workspace(y.device, wsb)
+        _lib.check(self.lib.rsp_gate_bwd_params(_ptr(y), _ptr(scale_shift), int(relu), _ptr(dout), N, P, Cc, Cc, dout_ld, _ptr(_chk(w, "w")),
+                                                _ptr(mean), _ptr(gate), _ptr(dw_out), _ptr(db_out), _ptr(dmean), _ptr(ws), wsb,
+                                                _stream()), "rsp_gate_bwd_params")
+        d, dref, wsb2, _ = _pool_plan(0, pg, Cc, dout_ld, None)
+        ws2 = self._workspace(y.device, wsb2)
+        dy = torch.empty_like(y)
+        c_valid = pg.C if gamma is None else int(gamma.shape[0])
+        _lib.check(self.lib.rsp_bn_act_pool_bwd_g(dref, _ptr(y), None, _ptr(dout), _ptr(gamma), _ptr(mean_invstd), _ptr(scale_shift),
+                                                  int(relu), _ptr(dy), None, _ptr(dgamma_out), _ptr(dbeta_out), c_valid, _ptr(gate),
+                                                  _ptr(dmean), _ptr(ws2), wsb2, _stream()), "rsp_bn_act_pool_bwd_g")
+        return dy
+
     def gate_bwd(self, x, dout, w, mean, gate, dw_out, db_out):
         _chk(x, "x")
         N, D, H, W, Cc = x.shape

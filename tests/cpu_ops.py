@@ -138,6 +138,13 @@ class CpuOps:
             o = out
         return o, (a if keep_act else None), mean, gate
 
+    def bn_act_gate_bwd(self, pg: PoolGeom, y, dout, gamma, mean_invstd, scale_shift, relu, w, mean, gate, dgamma_out, dbeta_out,
+                        dw_out, db_out):
+        a = self.bn_act_pool_fwd(pg, y, scale_shift, None, relu)
+        dx = self.gate_bwd(a, dout, w, mean, gate, dw_out, db_out)
+        dy, _ = self.bn_act_pool_bwd(pg, y, None, dx, gamma, mean_invstd, scale_shift, relu, False, dgamma_out, dbeta_out)
+        return dy
+
     @torch.enable_grad()
     def gate_bwd(self, x, dout, w, mean, gate, dw_out, db_out):
         xx = x.detach().requires_grad_(True)

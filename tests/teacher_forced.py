@@ -104,6 +104,16 @@ class Recorder:
             args = tuple(args[:3]) + (dout,) + tuple(args[4:])
         return args
 
+    def bn_act_gate_bwd(self, pg, y, dout, gamma, mean_invstd, scale_shift, relu, w, mean, gate, dgamma_out, dbeta_out, dw_out,
+                        db_out):
+        """The fused backward is recorded as the three primitives it stands for (each through this recorder, so the ReLU knife
+        edges of the BatchNorm backward are neutralised as everywhere else); the fused device path itself is pinned to those
+        primitives by tests/test_kernels_gpu.py::test_bn_act_gate_bwd_fused_matches_the_two_ops."""
+        a = self.bn_act_pool_fwd(pg, y, scale_shift, None, relu)
+        dx = self.gate_bwd(a, dout, w, mean, gate, dw_out, db_out)
+        dy, _ = self.bn_act_pool_bwd(pg, y, None, dx, gamma, mean_invstd, scale_shift, relu, False, dgamma_out, dbeta_out)
+        return dy
+
     def __getattr__(self, name):
         fn = getattr(self.inner, name)
         if not callable(fn) or name in ("pack_signature", "bn_ema_set"):      # (host queries / set builders: nothing to replay)

@@ -669,3 +669,36 @@ def test_bn_act_gate_fused_is_bit_identical_to_the_three_ops(hip, N, D, H, W, C,
     oc, ac, mc, gc = CPU.bn_act_gate_fwd(pg, y.cpu(), ss.cpu(), True, w.cpu(), b.cpu(), True)
     close(o, oc, 2e-5, "gated output")
     close(gate, gc, 2e-5, "gate")
+
+
+@pytest.mark.parametrize("N,D,H,W,C,sliced", [(2, 4, 12, 12, 64, False), (3, 2, 7, 7, 48, True), (2, 3, 9, 10, 6, False)])
+def test_bn_act_gate_bwd_fused_matches_the_two_ops(hip, N, D, H, W, C, sliced):
+    """ops.bn_act_gate_bwd (activation recomputed from y, the gate's data gradient formed inside the BatchNorm backward kernels)
+    against gate_bwd on the stored activation followed by bn_act_pool_bwd — on the device and against the checker."""
+    y = rnd(N, D, H, W, C, seed=21).to(DEV)
+    gamma = (rnd(C, seed=22).abs() + 0.5).to(DEV)
+    mean_c, var_c = y.mean(dim=(0, 1, 2, 3)), y.var(dim=(0, 1, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var_c + 1e-3)
+    beta = (rnd(C, seed=23) * 0.3).to(DEV)
+    mi = torch.stack([mean_c, invstd]).contiguous()
+    ss = torch.stack([gamma * invstd, beta - mean_c * gamma * invstd]).contiguous()
+    w, b = (rnd(C, C, 1, 1, 1, seed=24) * 0.2).to(DEV), (rnd(C, seed=25) * 0.1).to(DEV)
+    pg = PoolGeom(N, D, H, W, C)
+    o, a, mean, gate = hip.bn_act_gate_fwd(pg, y, ss, True, w, b, True)
+    if sliced:      # gradient of the gated output as a channel slice of a wider concat gradient
+        wide = rnd(N, D, H, W, C + 16, seed=26).to(DEV)
+        dout = wide[..., 8:8 + C]
+    else:
+        dout = rnd(N, D, H, W, C, seed=26).to(DEV)
+    dw_r, db_r, dg_r, dbt_r = (torch.empty_like(t) for t in (w, b, gamma, beta))
+    dx = hip.gate_bwd(a, dout, w, mean, gate, dw_r, db_r)
+    dy_r, _ = hip.bn_act_pool_bwd(pg, y, None, dx, gamma, mi, ss, True, False, dg_r, dbt_r)
+    dw, db, dg, dbt = (torch.empty_like(t) for t in (w, b, gamma, beta))
+    dy = hip.bn_act_gate_bwd(pg, y, dout, gamma, mi, ss, True, w, mean, gate, dg, dbt, dw, db)
+    for name, got, ref in (("dy", dy, dy_r), ("dw", dw, dw_r), ("db", db, db_r), ("dgamma", dg, dg_r), ("dbeta", dbt, dbt_r)):
+        close(got, ref.cpu(), 1e-6, name)
+    dwc, dbc, dgc, dbtc = (torch.empty(t.shape) for t in (w, b, gamma, beta))
+    dyc = CPU.bn_act_gate_bwd(pg, y.cpu(), dout.cpu(), gamma.cpu(), mi.cpu(), ss.cpu(), True, w.cpu(), mean.cpu(), gate.cpu(), dgc, dbtc,
+                              dwc, dbc)
+    for name, got, ref in (("dy", dy, dyc), ("dw", dw, dwc), ("dgamma", dg, dgc), ("dbeta", dbt, dbtc)):
+        close(got, ref, 5e-5, name + " vs checker")
