@@ -16,7 +16,10 @@ dev = torch.device("cuda", 0)
 SHAPES = [("r2+1d conv2 mid", 32, 16, 56, 56, 144, None), ("r2+1d conv2 out", 32, 16, 56, 56, 64, None),
           ("c3d conv1+pool", 32, 16, 112, 112, 64, ((1, 2, 2), (1, 2, 2))), ("c3d conv2+pool", 32, 16, 56, 56, 128, ((2, 2, 2), (2, 2, 2))),
           ("c3d conv3a", 32, 8, 28, 28, 256, None), ("s3dg conv1 7x1x1", 16, 8, 112, 112, 64, None),
-          ("s3dg 3b in", 16, 8, 28, 28, 192, None), ("r3d stem", 32, 16, 56, 56, 64, None)]
+          ("s3dg 3b in", 16, 8, 28, 28, 192, None), ("r3d stem", 32, 16, 56, 56, 64, None),
+          ("s3dg 28x28x96", 16, 8, 28, 28, 96, None), ("s3dg 14x14x320", 16, 4, 14, 14, 320, None), ("s3dg 14x14x64", 16, 4, 14, 14, 64, None),
+          ("s3dg 7x7x384", 16, 2, 7, 7, 384, None), ("s3dg 7x7x128", 16, 2, 7, 7, 128, None), ("r3d 14x14x128", 32, 4, 14, 14, 128, None),
+          ("r3d 4x4x512", 32, 1, 4, 4, 512, None)]
 scratch = torch.empty(256 << 20, device=dev)
 
 

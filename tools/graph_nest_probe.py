@@ -44,6 +44,23 @@ with torch.cuda.graph(g):
                 x.mul_(1.0)
             x.add_(0)                       # origin-stream work beside A
             main.wait_stream(A)
+    elif topo in ("prejoin", "prejoin2"):   # children join the capture by waiting on the ORIGIN first (flat), then take work from A
+        reps = 1 if topo == "prejoin" else 4
+        for _ in range(reps):
+            for s in (A, B, C):
+                s.wait_stream(main)
+            with torch.cuda.stream(A):
+                x.mul_(1.0)
+                for s in (B, C):
+                    s.wait_stream(A)            # cross edge between two streams that both forked from the origin
+                    with torch.cuda.stream(s):
+                        x.mul_(1.0)
+                for s in (B, C):
+                    A.wait_stream(s)
+                x.mul_(1.0)
+            x.add_(0)
+            for s in (A, B, C):
+                main.wait_stream(s)
     x.add_(1)
 g.replay()
 g.replay()
