@@ -667,12 +667,6 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
         bn = node.bn
         gated = fused_gates.pop(key, None)
         if gated is not None:
-            pass
-        elif node.into is not None:
-            dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout)
-        else:
-            dout = dslots.pop(node.dst)
-        if gated is not None:
             # the self-gating unit behind this BatchNorm, whose forward kept no activation: both backwards as one op
             gi, mean, gate = gated
             gnode = plan.nodes[gi]
@@ -683,6 +677,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             if after_param_grads is not None:
                 after_param_grads(gi)
         else:
+            dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout) if node.into is not None else dslots.pop(node.dst)
             dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
                                           node.residual is not None, grad_of(bn.weight), grad_of(bn.bias))
         if node.residual is not None:
