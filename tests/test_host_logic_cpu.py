@@ -77,3 +77,31 @@ def test_graphed_step_wrapper_falls_back_to_the_eager_statements(cpu_backend):
     assert torch.equal(l0, l1) and torch.equal(o0, o1)
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_gate_fusion_table_and_the_unfused_path(cpu_backend, monkeypatch):
+    """engine._gate_fusion pairs every sep_conv unit of S3D-G (models/s3dg.py:36-72) with its gate — and the two front-end ones
+    with the max-pool behind them — and nothing else; with both fusions switched off (the A/B switches of DESIGN 5c) the step
+    still reproduces the golden fixture, and the parameter gradients of the two ways agree to rounding."""
+    from rspnet_amd import engine
+    from rspnet_amd.models.s3dg import S3D_G
+    plan = S3D_G().plan()
+    table = engine._gate_fusion(plan)
+    assert len(table) == 20 and sum(1 for v in table.values() if v[1] is not None) == 2
+    for ci, (gi, pi) in table.items():
+        conv, gate = plan.nodes[ci], plan.nodes[gi]
+        assert isinstance(conv, engine.ConvBN) and isinstance(gate, engine.Gate) and gate.src == conv.dst and gi == ci + 1
+        if pi is not None:
+            assert isinstance(plan.nodes[pi], engine.Pool) and plan.nodes[pi].src == gate.dst and gate.into is None
+    arch, _, seed = cases_for("s3dg", 1)[0]
+    z, meta = load_case(arch, 1, seed)
+    spec, inputs = build_inputs(arch, meta)
+    _, _, _, grads_fused = run_model_step(arch, meta, inputs, 0, torch.device("cpu"), "fused")
+    monkeypatch.setenv("RSP_NO_GATE_FUSION", "1")        # read when a plan's table is built: every model builds its own plan
+    monkeypatch.setattr(engine, "GATE_BWD_FUSED", False)
+    res, post, mom_post, grads = run_model_step(arch, meta, inputs, 0, torch.device("cpu"), "fused")
+    compare_to_golden(z, 0, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=grad_tol(arch))
+    for k, g in grads.items():
+        if g is not None:
+            ref = grads_fused[k]
+            assert float(np.abs(g - ref).max()) <= 1e-5 * max(float(np.abs(ref).max()), 1e-6), k
