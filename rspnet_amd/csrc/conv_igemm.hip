@@ -84,11 +84,36 @@ struct IgemmParams {
   int adv_tap, adv_ci;                     // BK / Cin, BK % Cin
   int nbuf;                                // LDS tile buffers: 2, or 1 (see igemm_body)
   int kmajor;                              // 1: channel-slice-major K order (k_slice_major)
+  int skip_pad;                            // slice-major walk: skip the chunks of taps that are padding for the whole tile
+  int Nb;                                  // samples (M = Nb * Gd * Gh * Gw)
+  int dmajor;                              // GEMM rows enumerate (part, depth, sample in part, h, w) instead of (sample, depth, h, w): row_decode
+  int Np;                                  // samples per part (dmajor)
+  FastDiv dNp, dGdNp;
   FastDiv dNt;                             // taps per slice (kmajor)
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
 inline void fill_fastdiv(IgemmParams& p);
+
+// GEMM row -> (sample, output-grid depth) from q2 = row / (Gh * Gw).  Depth-major enumeration (slice-major kernels on layers with
+// depth padding): the samples are cut into parts of Np; within a part all its samples' positions of ONE output frame are
+// consecutive rows, so a 128-row tile lies (mostly) in one frame and the depth taps that are padding for that frame are padding
+// for the whole tile (skipped, igemm_body) — n-major tiles straddle frames (C3D conv4: 196 rows per frame and sample, conv5: 49).
+// The frames of a part are walked 1, 2, ..., Gd-1, 0: the frames with fewer taps come last.  Eight parts when the batch allows:
+// rsp_xcd_remap hands each XCD one contiguous eighth of the tiles = one part, so every XCD runs its full-length tiles first and
+// its short ones at the end, where they fill the ragged last round instead of leaving full-length tiles to it.
+__device__ __forceinline__ void row_decode(const IgemmParams& p, bool dmajor, int q2, int& n, int& gd) {
+  if (dmajor) {
+    const int part = fastdiv(q2, p.dGdNp);
+    const int rem = q2 - part * (p.Gd * p.Np);
+    const int g = fastdiv(rem, p.dNp);
+    n = part * p.Np + (rem - g * p.Np);
+    gd = g + 1 == p.Gd ? 0 : g + 1;
+  } else {
+    n = fastdiv(q2, p.dGd);
+    gd = q2 - n * p.Gd;
+  }
+}
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups of ITS problem (blockIdx.x / gridDim.x for a single
 // problem; offsets into a shared grid when several problems run in one launch, igemm_multi_kernel).
@@ -170,7 +195,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     if (r < p.M) {
       const int q1 = fastdiv(r, p.dGw), gw = r - q1 * p.Gw;
       const int q2 = fastdiv(q1, p.dGh), gh = q1 - q2 * p.Gh;
-      const int n = fastdiv(q2, p.dGd), gd = q2 - n * p.Gd;
+      int n, gd;
+      row_decode(p, KS && p.dmajor, q2, n, gd);
       aid[i] = gd * p.sD;
       aih[i] = gh * p.sH;
       aiw[i] = gw * p.sW;
@@ -190,8 +216,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     wok[i] = co < p.Cout;
     wrow[i] = p.w + (long long)(wok[i] ? co : 0) * p.Kld;
   }
-  __syncthreads();  // tap table ready
-
   floatx4 areg[AR], breg[BR];
 
   // (tap, ci) of this thread's k position(s) in the NEXT chunk to load, advanced incrementally (no division in the loop);
@@ -200,19 +224,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   const int adv_tap = p.adv_tap, adv_ci = p.adv_ci;
   int ntap[NE], nci[NE];
   int4 ntt[NE];
-#pragma unroll
-  for (int e = 0; e < NE && !KS; ++e) {
-    const int k = kc_begin * BK + kcol + e;
-    if (p.kmajor) {   // chunk kc = (slice kc / ntaps, tap kc % ntaps); this lane's channel = slice*32 + its offset in the chunk
-      const int sl = fastdiv(kc_begin, p.dNt);
-      ntap[e] = kc_begin - sl * ntaps;
-      nci[e] = sl * BK + kcol + e;
-    } else {
-      ntap[e] = fastdiv(k, p.dCin);
-      nci[e] = k - ntap[e] * p.Cin;
-    }
-    ntt[e] = taptab[min(ntap[e], ntaps - 1)];
-  }
   const float* const zero = p.zero;
   // element offset of the zero page relative to p.x, so an invalid lane only swaps an offset (pure v_cndmask, no branch)
   const long long zoff = (reinterpret_cast<const char*>(p.zero) - reinterpret_cast<const char*>(p.x)) / 4;
@@ -248,6 +259,40 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
 #pragma unroll
   for (int i = 0; i < BR; ++i) wrowoff[i] = (unsigned)(n0 + arow + 32 * i) * (unsigned)p.Kld * 4u;
 
+  // Taps that fall into the zero padding for EVERY row of this tile contribute nothing: the slice-major walk below skips their
+  // chunks outright (no copies, no MFMAs).  With 128 consecutive output positions per tile this is mostly the depth taps of the
+  // first / last frame — a 3x3x3 convolution over T frames spends 2/(3T) of its products there: C3D conv3 8 %, conv4 17 %,
+  // conv5 33 %, R3D-18 layer4 (T = 1) 67 %.  tmask = OR of the rows' validity bits (rbits), through the (still unused) row-address
+  // table and the barrier that publishes the tap table.
+  unsigned tmask = 0x00ffffffu;
+  if (KS) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) m |= rbits[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m |= (unsigned)__shfl_xor((int)m, o);
+    if (lane == 0) reinterpret_cast<unsigned*>(rowaddr)[wave] = m;
+  }
+  __syncthreads();  // tap table (and the waves' masks) ready
+  if (KS) {
+    const unsigned* wmk = reinterpret_cast<const unsigned*>(rowaddr);
+    tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(wmk[0] | wmk[1] | wmk[2] | wmk[3]));
+    if (!p.skip_pad) tmask = 0x00ffffffu;
+  }
+#pragma unroll
+  for (int e = 0; e < NE && !KS; ++e) {
+    const int k = kc_begin * BK + kcol + e;
+    if (p.kmajor) {   // chunk kc = (slice kc / ntaps, tap kc % ntaps); this lane's channel = slice*32 + its offset in the chunk
+      const int sl = fastdiv(kc_begin, p.dNt);
+      ntap[e] = kc_begin - sl * ntaps;
+      nci[e] = sl * BK + kcol + e;
+    } else {
+      ntap[e] = fastdiv(k, p.dCin);
+      nci[e] = k - ntap[e] * p.Cin;
+    }
+    ntt[e] = taptab[min(ntap[e], ntaps - 1)];
+  }
+
   // Channel-slice-major K order on the DMA path: every chunk is ONE tap of ONE 32-channel slice, the same for all lanes, so
   // the walk (kw fastest, then kh, kd, then the next slice) is kept in wave-uniform counters — scalar arithmetic beside the
   // matrix pipe — and a row costs and + compare + add + select per chunk; no tap table, no per-lane tap tracking.
@@ -260,6 +305,30 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     ukd = fastdiv(q, p.dTh);
     ukh = q - ukd * p.nTh;
   }
+
+  // KS cursor: (ckc; ukw, ukh, ukd, uslice) is the next chunk to load.  ks_step() moves it on by one chunk, ks_seek() past the
+  // chunks whose tap is padding for the whole tile (scalar arithmetic only: no LDS access may follow an LDS-DMA issue).
+  int ckc = kc_begin;
+  auto ks_step = [&]() {
+    ++ckc;
+    if (++ukw == p.nTw) {
+      ukw = 0;
+      if (++ukh == p.nTh) {
+        ukh = 0;
+        if (++ukd == p.nTd) {
+          ukd = 0;
+          ++uslice;
+        }
+      }
+    }
+  };
+  auto ks_seek = [&]() {
+    while (ckc < kc_end) {
+      const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
+      if ((tmask & need) == need) break;
+      ks_step();
+    }
+  };
 
   auto load_chunk = [&](int kc, int buf) {
     const int k = kc * BK + kcol;
@@ -279,16 +348,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
         const unsigned off = (rbits[i] & need) == need ? abase32[i] + delta4 : 0xffffffffu;
         float* dst = As + buf * BM * LDR + i * 32 * LDR + wave * 64 * 4;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
-      }
-      if (++ukw == p.nTw) {
-        ukw = 0;
-        if (++ukh == p.nTh) {
-          ukh = 0;
-          if (++ukd == p.nTd) {
-            ukd = 0;
-            ++uslice;
-          }
-        }
       }
       return;
     }
@@ -389,15 +448,24 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     for (int i = 0; i < (reps ? reps : 4); ++i) __builtin_amdgcn_s_sleep(16);
   }
 #endif
-  if (kc_begin < kc_end) {
+  bool have = kc_begin < kc_end;
+  if (KS) {
+    ks_seek();
+    have = ckc < kc_end;
+    if (have) {
+      load_chunk(ckc, 0);
+      ks_step();
+      ks_seek();
+    }
+  } else if (have) {
     load_chunk(kc_begin, 0);
     store_chunk(0);
   }
   __syncthreads();   // (with DMA in flight hipcc emits s_waitcnt vmcnt(0) before the barrier: the tile has landed)
 
   int buf = 0;
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const bool more = kc + 1 < kc_end;
+  for (int kc = kc_begin; KS ? have : kc < kc_end; ++kc) {
+    const bool more = KS ? ckc < kc_end : kc + 1 < kc_end;
     // 1. this chunk's operand fragments -> registers.  They are read BEFORE the next chunk's LDS-DMA is issued: hipcc
     //    orders every ds_read behind all pending LDS-DMA (s_waitcnt vmcnt(0)), so a read issued after the DMA would
     //    serialise the copy with the MFMAs instead of overlapping it.
@@ -416,10 +484,15 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     // 2. next chunk: LDS-DMA (or global loads into registers) in flight under this chunk's MFMAs
     if (nbuf == 1) __syncthreads();   // every wave holds its fragments: the buffer may be overwritten
 #ifdef RSP_TUNE
-    if (more && !(p.tune & 1)) load_chunk(kc + 1, nbuf == 1 ? 0 : buf ^ 1);
+    if (more && !(p.tune & 1)) load_chunk(KS ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
 #else
-    if (more) load_chunk(kc + 1, nbuf == 1 ? 0 : buf ^ 1);
+    if (more) load_chunk(KS ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
 #endif
+    if (KS && more) {
+      ks_step();
+      ks_seek();
+    }
+    if (KS) have = more;
     // 3. 16 k-steps x TM x TN MFMAs
 #ifdef RSP_TUNE
     if (p.tune & 32) __builtin_amdgcn_s_setprio(1);
@@ -461,7 +534,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       if (r < p.M) {
         const int q1 = fastdiv(r, p.dGw), gw = r - q1 * p.Gw;
         const int q2 = fastdiv(q1, p.dGh), gh = q1 - q2 * p.Gh;
-        const int n = fastdiv(q2, p.dGd), gd = q2 - n * p.Gd;
+        int n, gd;
+        row_decode(p, KS && p.dmajor, q2, n, gd);
         addr = ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw +
                 p.oOw) * p.out_ld;
       }
@@ -591,7 +665,26 @@ struct ReduceParams {
   int M, Cout, splitk, stat_ld;
   int row0;   // first row covered by the partials ([splitk][M - row0][Cout]); a multiple of 128
   int Gd, Gh, Gw, oDm, oHm, oWm, oSd, oSh, oSw, oOd, oOh, oOw, out_ld;
+  int Nb, dmajor, Np;   // depth-major row enumeration (row_decode)
 };
+
+__device__ __forceinline__ long long reduce_row_addr(const ReduceParams& p, int r) {
+  const int gw = r % p.Gw;
+  int q = r / p.Gw;
+  const int gh = q % p.Gh;
+  q /= p.Gh;
+  int gd, n;
+  if (p.dmajor) {
+    const int part = q / (p.Gd * p.Np), rem = q - part * (p.Gd * p.Np);
+    const int g = rem / p.Np;
+    n = part * p.Np + (rem - g * p.Np);
+    gd = g + 1 == p.Gd ? 0 : g + 1;
+  } else {
+    gd = q % p.Gd;
+    n = q / p.Gd;
+  }
+  return ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw + p.oOw) * p.out_ld;
+}
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
   // block = one 128-row tile x 64 channels; thread = (row group of 4 lanes.., channel)
@@ -607,15 +700,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
       if (r >= p.M) break;
       float v = 0.f;
       for (int z = 0; z < p.splitk; ++z) v += p.partial[((long long)z * (p.M - p.row0) + (r - p.row0)) * p.Cout + c];
-      const int gw = r % p.Gw;
-      int q = r / p.Gw;
-      const int gh = q % p.Gh;
-      q /= p.Gh;
-      const int gd = q % p.Gd;
-      const int n = q / p.Gd;
-      const long long addr =
-          ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw + p.oOw) *
-          p.out_ld;
+      const long long addr = reduce_row_addr(p, r);
       p.y[addr + c] = v + bv;
       s += v;
       ss = fmaf(v, v, ss);
@@ -653,16 +738,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const ReducePara
     const int r = m_tile * 128 + rl + 16 * i;
     v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     addr[i] = -1;
-    if (r < p.M && cok) {
-      const int gw = r % p.Gw;
-      int q = r / p.Gw;
-      const int gh = q % p.Gh;
-      q /= p.Gh;
-      const int gd = q % p.Gd;
-      const int n = q / p.Gd;
-      addr[i] = ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw + p.oOw) *
-                p.out_ld;
-    }
+    if (r < p.M && cok) addr[i] = reduce_row_addr(p, r);
   }
   // K-slices are summed four at a time, ((z0 + z1) + (z2 + z3)) onto the running sum: 32 independent 16-byte loads in flight per
   // thread instead of 8 (the small late layers run S = 8..16 slices on a few dozen workgroups, where each dependent round of
@@ -877,15 +953,33 @@ int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
   return rsp_check_launch("igemm_multi_kernel");
 }
 
+inline void fill_fastdiv_linear(IgemmParams& p) {
+  p.linear_out = p.oSd == 1 && p.oSh == 1 && p.oSw == 1 && p.oOd == 0 && p.oOh == 0 && p.oOw == 0 && p.oDm == p.Gd &&
+                 p.oHm == p.Gh && p.oWm == p.Gw && !p.dmajor;
+}
+
 inline void fill_fastdiv(IgemmParams& p) {
   p.dGw = fastdiv_make(p.Gw); p.dGh = fastdiv_make(p.Gh); p.dGd = fastdiv_make(p.Gd);
   p.dCin = fastdiv_make(p.Cin); p.dTw = fastdiv_make(p.nTw); p.dTh = fastdiv_make(p.nTh);
   p.adv_tap = BK / p.Cin;
   p.adv_ci = BK % p.Cin;
   p.kmajor = k_slice_major(p.Cin, p.nTd * p.nTh * p.nTw) ? 1 : 0;
+  static const bool no_skip = getenv("RSP_NO_PAD_SKIP") != nullptr;      // (A/B switches for measurements, read once)
+  static const bool no_dmajor = getenv("RSP_NO_DMAJOR") != nullptr;
+  p.skip_pad = no_skip ? 0 : 1;
+  // parts: eight (one per XCD) when each part's frame still spans several tiles, else one
+  p.Np = (p.Nb % 8 == 0 && (long long)(p.Nb / 8) * p.Gh * p.Gw >= 4 * 128) ? p.Nb / 8 : (p.Nb > 0 ? p.Nb : 1);
+#ifdef RSP_TUNE
+  if (const char* e = getenv("RSP_DMAJOR_PARTS")) { const int parts = atoi(e); if (parts > 0 && p.Nb % parts == 0) p.Np = p.Nb / parts; }
+#endif
+  p.dNp = fastdiv_make(p.Np);
+  p.dGdNp = fastdiv_make(p.Gd * p.Np);
+  // depth-major rows: slice-major kernels whose depth taps reach into the padding for some output frame
+  const int dlo = p.offstep > 0 ? p.off0d : p.off0d - (p.nTd - 1);
+  const int dhi = (p.Gd - 1) * p.sD + (p.offstep > 0 ? p.off0d + p.nTd - 1 : p.off0d);
+  p.dmajor = (p.skip_pad && !no_dmajor && p.kmajor && p.nTd > 1 && p.Gd > 1 && p.Nb > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
   p.dNt = fastdiv_make(p.nTd * p.nTh * p.nTw);
-  p.linear_out = p.oSd == 1 && p.oSh == 1 && p.oSw == 1 && p.oOd == 0 && p.oOh == 0 && p.oOw == 0 && p.oDm == p.Gd &&
-                 p.oHm == p.Gh && p.oWm == p.Gw;
+  fill_fastdiv_linear(p);
 }
 
 int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
@@ -1002,6 +1096,9 @@ void fill_reduce(ReduceParams& r, const IgemmParams& p) {
   r.oSd = p.oSd; r.oSh = p.oSh; r.oSw = p.oSw;
   r.oOd = p.oOd; r.oOh = p.oOh; r.oOw = p.oOw;
   r.out_ld = p.out_ld;
+  r.Nb = p.Nb;
+  r.dmajor = p.dmajor;
+  r.Np = p.Np;
 }
 
 
@@ -1026,6 +1123,10 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
 #endif
   p.nchunks = rsp_cdiv(p.K, BK);
   fill_fastdiv(p);
+  if (!vec4 && p.dmajor) {      // only the slice-major DMA kernel (igemm_ks_kernel) knows the depth-major enumeration
+    p.dmajor = 0;
+    fill_fastdiv_linear(p);
+  }
   int bn = tile_bn(p.Cout);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
@@ -1217,6 +1318,7 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   memset(&p, 0, sizeof p);
   p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.stat = stat_partials;
   p.M = d->N * d->Do * d->Ho * d->Wo;
+  p.Nb = d->N;
   p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
   p.oDm = d->Do; p.oHm = d->Ho; p.oWm = d->Wo;
   p.oSd = p.oSh = p.oSw = 1;
@@ -1366,6 +1468,7 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
     memset(&p, 0, sizeof p);
     p.x = dy; p.w = wpk + woff; p.bias = nullptr; p.y = dx; p.stat = nullptr;
     p.M = d->N * g.Gd * g.Gh * g.Gw;
+    p.Nb = d->N;
     p.Gd = g.Gd; p.Gh = g.Gh; p.Gw = g.Gw;
     p.oDm = d->Di; p.oHm = d->Hi; p.oWm = d->Wi;
     p.oSd = d->sT; p.oSh = d->sH; p.oSw = d->sW;

@@ -69,6 +69,16 @@ CONV_CASES = [
     (1, 2, 6, 6, 128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 2, 6, 6, 128, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 4, 8, 8, 32, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1)),        # dgrad C = 512: the 8-tap class is slice-major, the others tap-major
+    # depth-major row enumeration + skipped padding taps (slice-major kernel, N > 1, depth padding): frames of 147 / 49 / 16 rows per
+    # sample (tiles straddle samples, ragged last tile, K-split tails), T = 1 (two of three depth taps are padding everywhere),
+    # a strided layer (dgrad classes), a (3,1,1) temporal convolution, no depth padding at all (stays n-major)
+    (3, 4, 7, 7, 128, 96, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (5, 2, 7, 7, 128, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (6, 1, 4, 4, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 5, 9, 9, 128, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (3, 6, 5, 5, 1024, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (2, 6, 6, 6, 128, 64, (3, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (2, 8, 40, 40, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # 200 tiles x 1: whole frames per tile group, K-split tail
     # wgrad output-channel segments on the 32-wide tile
     (1, 3, 20, 20, 8, 20, (1, 3, 3), (1, 1, 1), (0, 1, 1)),        # 20 channels: one 32-wide tile
     (1, 3, 20, 20, 16, 272, (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # 272 = 256 + 16; K = 16 (64-wide k tile: the 16 ride on the 64-row tile)
