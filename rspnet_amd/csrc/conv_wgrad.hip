@@ -33,6 +33,10 @@ struct WgradParams {
   const float* __restrict__ zero;  // >= 64 B of zeros
   unsigned x_bytes, dy_bytes;      // extents for the buffer descriptors of the DMA variant
   const uint2* __restrict__ rowgeom;  // [M] row geometry (DMA variant)
+  int skip_pad;                       // DMA variant: skip the row chunks whose frames make this k tile's depth taps padding
+  FastDiv dP, dGd;                    // rows per frame (Gh * Gw), frames per sample
+  int kh0, kh1;                       // k tiles [kh0, kh1) never skip ("full"); the others skip some frames ("short"): wgrad_unit_lpt
+  int lpt;                            // full units first (launches of two or more rounds; a single round gains nothing and loses L2 locality)
   int tune;
 };
 
@@ -55,6 +59,39 @@ __device__ __forceinline__ WUnit wgrad_unit(int L, int nwg, int tiles, int tune)
   WUnit w;
   w.z = u / tiles;
   w.tile = u - w.z * tiles;
+  return w;
+}
+
+// With skipped frames the units are no longer equally long: the k tiles of the kernel's edge depths run 1 - 1/T of the row
+// chunks.  A launch is only ~4 units deep per workgroup slot, so dealt in list order the slots that happen to draw four full
+// units set the finish time and the skipped work buys nothing (measured: C3D conv3b 5.29 -> 5.27 ms).  Every XCD therefore walks
+// its contiguous share of the FULL units first and its contiguous share of the SHORT ones after it (both slab-major, so the
+// L2 argument above still holds within each phase): the short units fill the ragged end of the launch.
+__device__ __forceinline__ WUnit wgrad_unit_lpt(int L, int nwg, int slabs, int co_tiles, int k_tiles, int kh0, int kh1) {
+  const int Hk = kh1 - kh0, Lk = k_tiles - Hk;
+  const int UH = slabs * co_tiles * Hk;
+  const int x = L & 7, j = L >> 3;
+  const int q = nwg >> 3, r = nwg & 7, qh = UH >> 3, rh = UH & 7;
+  const int hq = qh + (x < rh ? 1 : 0);
+  const int base_h = x * qh + min(x, rh);
+  const int base_l = x * q + min(x, r) - base_h;
+  WUnit w;
+  int co, k;
+  if (j < hq) {
+    const int i = base_h + j, per = co_tiles * Hk;
+    w.z = i / per;
+    const int rem = i - w.z * per;
+    co = rem / Hk;
+    k = kh0 + (rem - co * Hk);
+  } else {
+    const int i = base_l + (j - hq), per = co_tiles * Lk;
+    w.z = i / per;
+    const int rem = i - w.z * per;
+    co = rem / Lk;
+    const int kk = rem - co * Lk;
+    k = kk < kh0 ? kk : kk + Hk;
+  }
+  w.tile = co * k_tiles + k;
   return w;
 }
 
@@ -346,7 +383,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const WUnit unit = wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles, p.tune);
+  const WUnit unit = (p.lpt && p.kh1 > p.kh0 && p.kh1 - p.kh0 < p.k_tiles)
+                         ? wgrad_unit_lpt(blockIdx.x, gridDim.x, p.splitm, p.co_tiles, p.k_tiles, p.kh0, p.kh1)
+                         : wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles, p.tune);
   const int tile = unit.tile;
   const int co_tile = tile / p.k_tiles, k_tile = tile - co_tile * p.k_tiles;
   const int co0 = co_tile * BM, k0 = k_tile * BN;
@@ -361,10 +400,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   // A side (dy)
   const int acol = (t % ACOLS) * 4, arow = t / ACOLS;
   const bool acol_ok = co0 + acol < p.Cout;
-  unsigned aoff[AR];
+  unsigned aoff0[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i)
-    aoff[i] = ((unsigned)(row_begin + arow + i * ARP) * (unsigned)p.dy_ld + (unsigned)(co0 + acol)) * 4u;
+    aoff0[i] = ((unsigned)(row_begin + arow + i * ARP) * (unsigned)p.dy_ld + (unsigned)(co0 + acol)) * 4u;
   const unsigned astep = (unsigned)RK * (unsigned)p.dy_ld * 4u;
   // B side (im2col x): this thread's k -> the three validity bits it needs and the byte delta of its (tap, ci)
   const int bcol = (t % BCOLS) * 4, brow = t / BCOLS;
@@ -399,8 +438,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = acol_ok & (rbase + arow + i * ARP < row_end);
-      const unsigned off = ok ? aoff[i] : 0xffffffffu;
-      aoff[i] += astep;
+      const unsigned off = ok ? aoff0[i] + (unsigned)chunk * astep : 0xffffffffu;
       float* dst = At + buf * RK * BM + i * ARP * BM + wave * 256;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (lptr_t)dst, 16, off, 0, 0, 0);
     }
@@ -422,21 +460,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nchunk = (row_end - row_begin + RK - 1) / RK;
-  fetch_rows(0, 0);
-  fetch_rows(1, 1);
+  // Row chunks that cannot contribute to THIS k tile are skipped: the tile's taps span the kernel depths [kt_lo, kt_hi]; a chunk of
+  // 32 consecutive rows lies in one or two output frames, and for a frame at the volume's edge those depths may all fall into
+  // the zero padding (3x3x3 over T frames: a third of the k tiles skip 1/T of the rows each — C3D conv3 8 %, conv4 17 %, conv5 33 %
+  // of the launch).  Scalar arithmetic per chunk; the walk below goes from live chunk to live chunk.
+  const int khw = p.kH * p.kW;
+  const int kt_lo = (k0 / p.Cin) / khw, kt_hi = ((min(k0 + BN, p.K) - 1) / p.Cin) / khw;
+  auto frame_live = [&](int q) {
+    const int g = q - fastdiv(q, p.dGd) * p.Gd;
+    const int lo = g * p.sD - p.pT + kt_lo, hi = g * p.sD - p.pT + kt_hi;
+    return hi >= 0 && lo < p.Di;
+  };
+  auto next_live = [&](int c) {
+    if (!p.skip_pad) return c < nchunk ? c : nchunk;
+    for (; c < nchunk; ++c) {
+      const int r0 = row_begin + c * RK, r1 = min(r0 + RK, row_end) - 1;
+      const int q0 = fastdiv(r0, p.dP), q1 = fastdiv(r1, p.dP);
+      if (q1 - q0 > 1 || frame_live(q0) || frame_live(q1)) break;
+    }
+    return c;
+  };
+  int c0 = next_live(0);
+  int c1 = next_live(c0 + 1);
+  int c2 = next_live(c1 + 1);
+  fetch_rows(c0, 0);
+  fetch_rows(c1, 1);
   __syncthreads();
-  if (nchunk > 0) {
+  if (c0 < nchunk) {
     read_rowtab(0);
-    issue(0, 0);
+    issue(c0, 0);
   }
-  __syncthreads();   // vmcnt(0) + barrier: chunk 0 landed
+  __syncthreads();   // vmcnt(0) + barrier: the first chunk landed
 
-  int buf = 0;
-  for (int c = 0; c < nchunk; ++c) {
-    const bool more = c + 1 < nchunk;
+  int buf = 0, slot = 0;
+  for (int c3 = 0; c0 < nchunk; c0 = c1, c1 = c2, c2 = c3, slot = slot == 2 ? 0 : slot + 1) {
+    const bool more = c1 < nchunk;
     // 1. every LDS access of this iteration first (hipcc orders LDS accesses behind pending LDS-DMA); the row table goes
     //    first so that the copies' address math does not wait for the whole fragment burst
-    if (more) read_rowtab((c + 1) % 3);
+    if (more) read_rowtab(slot == 2 ? 0 : slot + 1);
     const float* a = At + buf * RK * BM + wm * WM + TM * l32;
     const float* b = Bt + buf * RK * BN + wn * WN + TN * l32;
     // MFMA row m of sub-tile i is channel TM*m + i (columns likewise), so a lane's TM (TN) operands for one k-step are
@@ -449,13 +510,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
       bf[s2] = *reinterpret_cast<const typename FragVec<TN>::type*>(b + (2 * s2 + h) * BN);
     }
 #ifdef RSP_TUNE
-    if (!(p.tune & 512)) fetch_rows(c + 2, (c + 2) % 3);
-    if (more && !(p.tune & 1024)) issue(c + 1, buf ^ 1);
+    if (!(p.tune & 512)) fetch_rows(c2, slot == 0 ? 2 : slot - 1);
+    if (more && !(p.tune & 1024)) issue(c1, buf ^ 1);
 #else
-    fetch_rows(c + 2, (c + 2) % 3);
+    fetch_rows(c2, slot == 0 ? 2 : slot - 1);      // (slot + 2) % 3
     // 2. next chunk's copies in flight under this chunk's MFMAs
-    if (more) issue(c + 1, buf ^ 1);
+    if (more) issue(c1, buf ^ 1);
 #endif
+    c3 = next_live(c2 + 1);      // (scalar; here it runs beside the MFMAs instead of behind the barrier)
     // 3. MFMAs
 #pragma unroll
     for (int s2 = 0; s2 < RK / 2; ++s2)
@@ -796,6 +858,28 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
   p.Kld = w.Kld;
   p.rows_per_split = w.rows_per_split; p.splitm = w.splitm;
   p.co_tiles = w.co_tiles; p.k_tiles = w.k_tiles;
+  static const bool no_skip = getenv("RSP_NO_PAD_SKIP") != nullptr;      // (A/B switch for measurements, read once)
+  p.skip_pad = (!no_skip && d->kT > 1 && d->pT > 0 && d->Ho * d->Wo >= RK) ? 1 : 0;
+  p.dP = fastdiv_make(d->Ho * d->Wo);
+  p.dGd = fastdiv_make(d->Do);
+  {   // k tiles that skip no frame: those whose kernel depths [kt_lo, kt_hi] reach inside the input for every output frame
+    const int khw = d->kH * d->kW;
+    p.kh0 = p.kh1 = 0;
+    bool open = false;
+    for (int j = 0; j < w.k_tiles; ++j) {
+      const int k0 = j * w.bn, k1 = (k0 + w.bn < p.K ? k0 + w.bn : p.K) - 1;
+      const int kt_lo = (k0 / d->Cin) / khw, kt_hi = (k1 / d->Cin) / khw;
+      bool skips = false;
+      for (int g = 0; g < d->Do && !skips; ++g) skips = g * d->sT - d->pT + kt_hi < 0 || g * d->sT - d->pT + kt_lo >= d->Di;
+      if (!skips && !open) { p.kh0 = j; open = true; }
+      if (!skips) p.kh1 = j + 1;
+    }
+    if (p.kh0 == 0 && p.kh1 == w.k_tiles) p.skip_pad = 0;      // nothing to skip (e.g. 4-channel stems: every k tile spans all depths)
+    const long long lds = 2ll * RK * (w.bm + w.bn) * 4 + 1024;
+    const long long slots = 256 * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);      // as in wplan()
+    p.lpt = (p.skip_pad && (long long)w.splitm * w.co_tiles * w.k_tiles * 2 > slots * 3) ? 1 : 0;
+    p.skip_pad = p.lpt;      // (one round: every unit runs at once and the full-length ones set the time — C3D conv2: 5.52 -> 5.65 ms with the walk)
+  }
   const bool va = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy);
   const bool vb = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x);
   const unsigned long long xb = (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
