@@ -85,6 +85,7 @@ struct IgemmParams {
   int nbuf;                                // LDS tile buffers: 2, or 1 (see igemm_body)
   int kmajor;                              // 1: channel-slice-major K order (k_slice_major)
   int skip_pad;                            // slice-major walk: skip the chunks of taps that are padding for the whole tile
+  int tm_skip, cpt;                        // the same in the tap-major DMA walk when a chunk is one tap for all lanes; cpt = Cin / BK
   int Nb;                                  // samples (M = Nb * Gd * Gh * Gw)
   int dmajor;                              // GEMM rows enumerate (part, depth, sample in part, h, w) instead of (sample, depth, h, w): row_decode
   int Np;                                  // samples per part (dmajor)
@@ -196,7 +197,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       const int q1 = fastdiv(r, p.dGw), gw = r - q1 * p.Gw;
       const int q2 = fastdiv(q1, p.dGh), gh = q1 - q2 * p.Gh;
       int n, gd;
-      row_decode(p, KS && p.dmajor, q2, n, gd);
+      row_decode(p, DMA && p.dmajor, q2, n, gd);
       aid[i] = gd * p.sD;
       aih[i] = gh * p.sH;
       aiw[i] = gw * p.sW;
@@ -264,8 +265,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   // first / last frame — a 3x3x3 convolution over T frames spends 2/(3T) of its products there: C3D conv3 8 %, conv4 17 %,
   // conv5 33 %, R3D-18 layer4 (T = 1) 67 %.  tmask = OR of the rows' validity bits (rbits), through the (still unused) row-address
   // table and the barrier that publishes the tap table.
+  const bool tms = DMA && !KS && p.tm_skip;      // tap-major walk with one tap per chunk for all lanes (Cin % BK == 0): same skipping
   unsigned tmask = 0x00ffffffu;
-  if (KS) {
+  if (KS || tms) {
     unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) m |= rbits[i];
@@ -274,10 +276,10 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     if (lane == 0) reinterpret_cast<unsigned*>(rowaddr)[wave] = m;
   }
   __syncthreads();  // tap table (and the waves' masks) ready
-  if (KS) {
+  if (KS || tms) {
     const unsigned* wmk = reinterpret_cast<const unsigned*>(rowaddr);
     tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(wmk[0] | wmk[1] | wmk[2] | wmk[3]));
-    if (!p.skip_pad) tmask = 0x00ffffffu;
+    if (KS && !p.skip_pad) tmask = 0x00ffffffu;
   }
 #pragma unroll
   for (int e = 0; e < NE && !KS; ++e) {
@@ -296,7 +298,15 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   // Channel-slice-major K order on the DMA path: every chunk is ONE tap of ONE 32-channel slice, the same for all lanes, so
   // the walk (kw fastest, then kh, kd, then the next slice) is kept in wave-uniform counters — scalar arithmetic beside the
   // matrix pipe — and a row costs and + compare + add + select per chunk; no tap table, no per-lane tap tracking.
-  int ukw = 0, ukh = 0, ukd = 0, uslice = 0;
+  int ukw = 0, ukh = 0, ukd = 0, uslice = 0;      // (tap-major skipping: uslice counts the chunks inside the current tap)
+  if (tms) {
+    const int tap0 = fastdiv(kc_begin * BK, p.dCin);
+    uslice = kc_begin - tap0 * p.cpt;
+    const int q = fastdiv(tap0, p.dTw);
+    ukw = tap0 - q * p.nTw;
+    ukd = fastdiv(q, p.dTh);
+    ukh = q - ukd * p.nTh;
+  }
   if (KS) {
     uslice = fastdiv(kc_begin, p.dNt);
     const int tap0 = kc_begin - uslice * ntaps;
@@ -330,6 +340,42 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     }
   };
 
+  // per-lane (tap, channel) state of the tap-major walk: on by one chunk (the next tap-table entry is fetched here, i.e. before any
+  // LDS-DMA of the chunk being loaded is issued)
+  auto lane_advance = [&]() {
+#pragma unroll
+    for (int e = 0; e < NE && !KS; ++e) {
+      if (p.kmajor) {
+        if (++ntap[e] >= ntaps) {
+          ntap[e] = 0;
+          nci[e] += BK;
+        }
+      } else {
+        nci[e] += adv_ci;
+        ntap[e] += adv_tap;
+        if (nci[e] >= p.Cin) {
+          nci[e] -= p.Cin;
+          ++ntap[e];
+        }
+      }
+      ntt[e] = taptab[min(ntap[e], ntaps - 1)];
+    }
+  };
+  // tap-major skipping: scalar tap counters beside the per-lane state
+  auto tm_step = [&]() {
+    ++ckc;
+    if (++uslice == p.cpt) {
+      uslice = 0;
+      if (++ukw == p.nTw) {
+        ukw = 0;
+        if (++ukh == p.nTh) {
+          ukh = 0;
+          ++ukd;
+        }
+      }
+    }
+  };
+
   auto load_chunk = [&](int kc, int buf) {
     const int k = kc * BK + kcol;
     if (KS) {
@@ -359,21 +405,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       ctap[e] = ntap[e];
       cci[e] = nci[e];
       ctt[e] = ntt[e];
-      if (p.kmajor) {
-        if (++ntap[e] >= ntaps) {
-          ntap[e] = 0;
-          nci[e] += BK;
-        }
-      } else {
-        nci[e] += adv_ci;
-        ntap[e] += adv_tap;
-        if (nci[e] >= p.Cin) {
-          nci[e] -= p.Cin;
-          ++ntap[e];
-        }
-      }
-      ntt[e] = taptab[min(ntap[e], ntaps - 1)];
     }
+    lane_advance();
     if (DMA) {
       const unsigned k4 = (unsigned)k * 4u;
       const bool kin = k < p.Kld;
@@ -457,6 +490,17 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       ks_step();
       ks_seek();
     }
+  } else if (tms) {
+    auto dead = [&]() { const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw)); return (tmask & need) != need; };
+    while (ckc < kc_end && dead()) {
+      lane_advance();
+      tm_step();
+    }
+    have = ckc < kc_end;
+    if (have) {
+      load_chunk(ckc, 0);
+      tm_step();
+    }
   } else if (have) {
     load_chunk(kc_begin, 0);
     store_chunk(0);
@@ -464,8 +508,15 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   __syncthreads();   // (with DMA in flight hipcc emits s_waitcnt vmcnt(0) before the barrier: the tile has landed)
 
   int buf = 0;
-  for (int kc = kc_begin; KS ? have : kc < kc_end; ++kc) {
-    const bool more = KS ? ckc < kc_end : kc + 1 < kc_end;
+  for (int kc = kc_begin; (KS || tms) ? have : kc < kc_end; ++kc) {
+    if (tms) {      // on to the next chunk with a live tap (LDS reads of the walk: no LDS-DMA is pending here)
+      auto dead = [&]() { const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw)); return (tmask & need) != need; };
+      while (ckc < kc_end && dead()) {
+        lane_advance();
+        tm_step();
+      }
+    }
+    const bool more = (KS || tms) ? ckc < kc_end : kc + 1 < kc_end;
     // 1. this chunk's operand fragments -> registers.  They are read BEFORE the next chunk's LDS-DMA is issued: hipcc
     //    orders every ds_read behind all pending LDS-DMA (s_waitcnt vmcnt(0)), so a read issued after the DMA would
     //    serialise the copy with the MFMAs instead of overlapping it.
@@ -484,15 +535,16 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     // 2. next chunk: LDS-DMA (or global loads into registers) in flight under this chunk's MFMAs
     if (nbuf == 1) __syncthreads();   // every wave holds its fragments: the buffer may be overwritten
 #ifdef RSP_TUNE
-    if (more && !(p.tune & 1)) load_chunk(KS ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
+    if (more && !(p.tune & 1)) load_chunk((KS || tms) ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
 #else
-    if (more) load_chunk(KS ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
+    if (more) load_chunk((KS || tms) ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
 #endif
     if (KS && more) {
       ks_step();
       ks_seek();
     }
-    if (KS) have = more;
+    if (tms && more) tm_step();
+    if (KS || tms) have = more;
     // 3. 16 k-steps x TM x TN MFMAs
 #ifdef RSP_TUNE
     if (p.tune & 32) __builtin_amdgcn_s_setprio(1);
@@ -535,7 +587,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
         const int q1 = fastdiv(r, p.dGw), gw = r - q1 * p.Gw;
         const int q2 = fastdiv(q1, p.dGh), gh = q1 - q2 * p.Gh;
         int n, gd;
-        row_decode(p, KS && p.dmajor, q2, n, gd);
+        row_decode(p, DMA && p.dmajor, q2, n, gd);
         addr = ((((long long)n * p.oDm + gd * p.oSd + p.oOd) * p.oHm + gh * p.oSh + p.oOh) * p.oWm + gw * p.oSw +
                 p.oOw) * p.out_ld;
       }
@@ -977,7 +1029,13 @@ inline void fill_fastdiv(IgemmParams& p) {
   // depth-major rows: slice-major kernels whose depth taps reach into the padding for some output frame
   const int dlo = p.offstep > 0 ? p.off0d : p.off0d - (p.nTd - 1);
   const int dhi = (p.Gd - 1) * p.sD + (p.offstep > 0 ? p.off0d + p.nTd - 1 : p.off0d);
-  p.dmajor = (p.skip_pad && !no_dmajor && p.kmajor && p.nTd > 1 && p.Gd > 1 && p.Nb > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
+  const int ntaps = p.nTd * p.nTh * p.nTw;
+  p.cpt = p.Cin / BK;
+  static const bool no_tm = getenv("RSP_NO_TM_SKIP") != nullptr;
+  // (padding in any dimension can make a tap dead for a whole tile, but only depth does so often enough to pay for the walk)
+  p.tm_skip = (p.skip_pad && !no_tm && !p.kmajor && p.Cin % BK == 0 && p.nTd > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
+  p.dmajor = (p.skip_pad && !no_dmajor && (p.kmajor || p.tm_skip) && p.nTd > 1 && p.Gd > 1 && p.Nb > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
+  (void)ntaps;
   p.dNt = fastdiv_make(p.nTd * p.nTh * p.nTw);
   fill_fastdiv_linear(p);
 }
@@ -1123,8 +1181,9 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
 #endif
   p.nchunks = rsp_cdiv(p.K, BK);
   fill_fastdiv(p);
-  if (!vec4 && p.dmajor) {      // only the slice-major DMA kernel (igemm_ks_kernel) knows the depth-major enumeration
+  if (!vec4) {      // only the LDS-DMA kernels know the depth-major enumeration and the skipping walks
     p.dmajor = 0;
+    p.tm_skip = 0;
     fill_fastdiv_linear(p);
   }
   int bn = tile_bn(p.Cout);
