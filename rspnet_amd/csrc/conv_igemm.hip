@@ -86,6 +86,8 @@ struct IgemmParams {
   int kmajor;                              // 1: channel-slice-major K order (k_slice_major)
   int skip_pad;                            // slice-major walk: skip the chunks of taps that are padding for the whole tile
   int tm_skip, cpt;                        // the same in the tap-major DMA walk when a chunk is one tap for all lanes; cpt = Cin / BK
+  int tpc;                                 // ... or, for narrow inputs (cpt == 0, BK % Cin == 0), tpc = BK / Cin whole taps: dead when
+  FastDiv dThw;                            //     every kernel DEPTH it spans is (taps / (nTh * nTw) = depth index)
   int Nb;                                  // samples (M = Nb * Gd * Gh * Gw)
   int dmajor;                              // GEMM rows enumerate (part, depth, sample in part, h, w) instead of (sample, depth, h, w): row_decode
   int Np;                                  // samples per part (dmajor)
@@ -364,7 +366,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   // tap-major skipping: scalar tap counters beside the per-lane state
   auto tm_step = [&]() {
     ++ckc;
-    if (++uslice == p.cpt) {
+    if (p.cpt > 0 && ++uslice == p.cpt) {
       uslice = 0;
       if (++ukw == p.nTw) {
         ukw = 0;
@@ -491,7 +493,15 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       ks_seek();
     }
   } else if (tms) {
-    auto dead = [&]() { const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw)); return (tmask & need) != need; };
+    auto dead = [&]() {
+      if (p.cpt > 0) {
+        const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
+        return (tmask & need) != need;
+      }
+      const int t0 = ckc * p.tpc, t1 = min(t0 + p.tpc, ntaps) - 1;
+      const unsigned span = (2u << fastdiv(t1, p.dThw)) - (1u << fastdiv(t0, p.dThw));      // depth indices [d(t0), d(t1)]
+      return (tmask & span) == 0;
+    };
     while (ckc < kc_end && dead()) {
       lane_advance();
       tm_step();
@@ -510,7 +520,15 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   int buf = 0;
   for (int kc = kc_begin; (KS || tms) ? have : kc < kc_end; ++kc) {
     if (tms) {      // on to the next chunk with a live tap (LDS reads of the walk: no LDS-DMA is pending here)
-      auto dead = [&]() { const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw)); return (tmask & need) != need; };
+      auto dead = [&]() {
+      if (p.cpt > 0) {
+        const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
+        return (tmask & need) != need;
+      }
+      const int t0 = ckc * p.tpc, t1 = min(t0 + p.tpc, ntaps) - 1;
+      const unsigned span = (2u << fastdiv(t1, p.dThw)) - (1u << fastdiv(t0, p.dThw));      // depth indices [d(t0), d(t1)]
+      return (tmask & span) == 0;
+    };
       while (ckc < kc_end && dead()) {
         lane_advance();
         tm_step();
@@ -1033,7 +1051,9 @@ inline void fill_fastdiv(IgemmParams& p) {
   p.cpt = p.Cin / BK;
   static const bool no_tm = getenv("RSP_NO_TM_SKIP") != nullptr;
   // (padding in any dimension can make a tap dead for a whole tile, but only depth does so often enough to pay for the walk)
-  p.tm_skip = (p.skip_pad && !no_tm && !p.kmajor && p.Cin % BK == 0 && p.nTd > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
+  p.tpc = (p.Cin < BK && BK % p.Cin == 0) ? BK / p.Cin : 0;
+  p.dThw = fastdiv_make(p.nTh * p.nTw);
+  p.tm_skip = (p.skip_pad && !no_tm && !p.kmajor && (p.Cin % BK == 0 || p.tpc > 0) && p.nTd > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
   p.dmajor = (p.skip_pad && !no_dmajor && (p.kmajor || p.tm_skip) && p.nTd > 1 && p.Gd > 1 && p.Nb > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
   (void)ntaps;
   p.dNt = fastdiv_make(p.nTd * p.nTh * p.nTw);
