@@ -1054,7 +1054,13 @@ inline void fill_fastdiv(IgemmParams& p) {
   p.tpc = (p.Cin < BK && BK % p.Cin == 0) ? BK / p.Cin : 0;
   p.dThw = fastdiv_make(p.nTh * p.nTw);
   p.tm_skip = (p.skip_pad && !no_tm && !p.kmajor && (p.Cin % BK == 0 || p.tpc > 0) && p.nTd > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
-  p.dmajor = (p.skip_pad && !no_dmajor && (p.kmajor || p.tm_skip) && p.nTd > 1 && p.Gd > 1 && p.Nb > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
+  // depth-major rows where they buy something: frames of fewer than four tiles per sample (n-major tiles would straddle frames) or
+  // launches of fewer than ~8 rounds (the short-frames-last order matters); big frames in long launches keep the n-major rows and
+  // their linear epilogue (S3D-G's (7,1,1) convolution: 98 tiles per frame, 16 rounds — measured 0.25 % of the step slower depth-major)
+  const long long tiles_est = ((long long)p.M + 127) / 128 * ((p.Cout + 127) / 128);
+  const bool wants_dmajor = (long long)p.Gh * p.Gw < 4 * 128 || tiles_est < 8 * 768;
+  p.dmajor = (p.skip_pad && !no_dmajor && (p.kmajor || p.tm_skip) && wants_dmajor && p.nTd > 1 && p.Gd > 1 && p.Nb > 1 &&
+              (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
   (void)ntaps;
   p.dNt = fastdiv_make(p.nTd * p.nTh * p.nTw);
   fill_fastdiv_linear(p);
