@@ -86,8 +86,8 @@ struct IgemmParams {
   int kmajor;                              // 1: channel-slice-major K order (k_slice_major)
   int skip_pad;                            // slice-major walk: skip the chunks of taps that are padding for the whole tile
   int tm_skip, cpt;                        // the same in the tap-major DMA walk when a chunk is one tap for all lanes; cpt = Cin / BK
-  int tpc;                                 // ... or, for narrow inputs (cpt == 0, BK % Cin == 0), tpc = BK / Cin whole taps: dead when
-  FastDiv dThw;                            //     every kernel DEPTH it spans is (taps / (nTh * nTw) = depth index)
+  FastDiv dThw;                            // ... or, any other channel count (cpt == 0): a chunk is dead when every kernel DEPTH of the
+                                           //     taps it touches is (tap / (nTh * nTw) = depth index)
   int Nb;                                  // samples (M = Nb * Gd * Gh * Gw)
   int dmajor;                              // GEMM rows enumerate (part, depth, sample in part, h, w) instead of (sample, depth, h, w): row_decode
   int Np;                                  // samples per part (dmajor)
@@ -498,7 +498,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
         const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
         return (tmask & need) != need;
       }
-      const int t0 = ckc * p.tpc, t1 = min(t0 + p.tpc, ntaps) - 1;
+      const int t0 = fastdiv(ckc * BK, p.dCin), t1 = min(fastdiv(ckc * BK + BK - 1, p.dCin), ntaps - 1);      // taps the chunk touches
       const unsigned span = (2u << fastdiv(t1, p.dThw)) - (1u << fastdiv(t0, p.dThw));      // depth indices [d(t0), d(t1)]
       return (tmask & span) == 0;
     };
@@ -525,7 +525,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
         const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
         return (tmask & need) != need;
       }
-      const int t0 = ckc * p.tpc, t1 = min(t0 + p.tpc, ntaps) - 1;
+      const int t0 = fastdiv(ckc * BK, p.dCin), t1 = min(fastdiv(ckc * BK + BK - 1, p.dCin), ntaps - 1);      // taps the chunk touches
       const unsigned span = (2u << fastdiv(t1, p.dThw)) - (1u << fastdiv(t0, p.dThw));      // depth indices [d(t0), d(t1)]
       return (tmask & span) == 0;
     };
@@ -1048,12 +1048,11 @@ inline void fill_fastdiv(IgemmParams& p) {
   const int dlo = p.offstep > 0 ? p.off0d : p.off0d - (p.nTd - 1);
   const int dhi = (p.Gd - 1) * p.sD + (p.offstep > 0 ? p.off0d + p.nTd - 1 : p.off0d);
   const int ntaps = p.nTd * p.nTh * p.nTw;
-  p.cpt = p.Cin / BK;
+  p.cpt = p.Cin % BK == 0 ? p.Cin / BK : 0;
   static const bool no_tm = getenv("RSP_NO_TM_SKIP") != nullptr;
   // (padding in any dimension can make a tap dead for a whole tile, but only depth does so often enough to pay for the walk)
-  p.tpc = (p.Cin < BK && BK % p.Cin == 0) ? BK / p.Cin : 0;
   p.dThw = fastdiv_make(p.nTh * p.nTw);
-  p.tm_skip = (p.skip_pad && !no_tm && !p.kmajor && (p.Cin % BK == 0 || p.tpc > 0) && p.nTd > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
+  p.tm_skip = (p.skip_pad && !no_tm && !p.kmajor && p.nTd > 1 && (dlo < 0 || dhi >= p.Di)) ? 1 : 0;
   // depth-major rows where they buy something: frames of fewer than four tiles per sample (n-major tiles would straddle frames) or
   // launches of fewer than ~8 rounds (the short-frames-last order matters); big frames in long launches keep the n-major rows and
   // their linear epilogue (S3D-G's (7,1,1) convolution: 98 tiles per frame, 16 rounds — measured 0.25 % of the step slower depth-major)
