@@ -92,6 +92,8 @@ struct IgemmParams {
   int dmajor;                              // GEMM rows enumerate (part, depth, sample in part, h, w) instead of (sample, depth, h, w): row_decode
   int Np;                                  // samples per part (dmajor)
   FastDiv dNp, dGdNp;
+  int dm_dense;                            // dmajor over a dense output grid (forward, stride-1 dgrad): piecewise-linear epilogue
+  FastDiv dP;                              // Gh * Gw
   FastDiv dNt;                             // taps per slice (kmajor)
   int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
@@ -597,7 +599,27 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   // (address = base + row * pitch): plain arithmetic.  The strided parity classes of dgrad go through a per-tile table
   // of the general affine mapping.
   const bool linear = is_partial || p.linear_out;   // uniform
-  if (!linear) {
+  // Depth-major rows over a dense output: a tile's rows are consecutive positions of one frame of one sample, then of the next
+  // sample (or frame) — two linear runs unless a frame is shorter than the tile.  base A up to row `split`, base B from there on.
+  long long pwA = 0, pwD = 0;      // base of the first run; what the second run adds to it
+  int pw_split = 0;
+  bool piecewise = false;
+  if (DMA && !linear && p.dm_dense) {
+    const int P = p.Gh * p.Gw;
+    const int q2a = fastdiv(m0, p.dP), f0 = m0 - q2a * P;
+    pw_split = __builtin_amdgcn_readfirstlane(P - f0);
+    if (BM <= pw_split + P) {
+      piecewise = true;
+      int n, gd;
+      row_decode(p, true, q2a, n, gd);
+      const int ra = (n * p.oDm + gd) * P + f0;                               // output position (< 2^31) of row m0
+      row_decode(p, true, min(q2a + 1, p.Nb * p.Gd - 1), n, gd);
+      const int rb = (n * p.oDm + gd) * P - pw_split;                         // ... of row m0 + split, minus split
+      pwA = (long long)__builtin_amdgcn_readfirstlane(ra) * p.out_ld;
+      pwD = (long long)__builtin_amdgcn_readfirstlane(rb - ra) * p.out_ld;
+    }
+  }
+  if (!linear && !piecewise) {
     if (t < BM) {
       const int r = m0 + t;
       long long addr = -1;
@@ -626,6 +648,18 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       const int col = n0 + wn * WN + j * 32 + l32;
       if (col < p.Cout) {
         const float bv = (p.bias && !is_partial) ? p.bias[col] : 0.f;
+        if (LIN && piecewise) {      // two linear runs (depth-major rows)
+          float* laneA = dst + pwA + (long long)(wm * WM + h * 4) * p.out_ld + col;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int rl = wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
+              if (!CHK || m0 + rl < p.M)
+                laneA[(long long)(i * 32 + (e >> 2) * 8 + (e & 3)) * p.out_ld + (rl < pw_split ? 0ll : pwD)] = acc[i][j][e] + bv;
+            }
+          continue;
+        }
         float* lane0 = dst + lin_base + (long long)(m0 + wm * WM + h * 4) * lin_ld + col;   // LIN: row (i, e) = lane0 + const * pitch
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -646,7 +680,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     }
   };
   const bool whole = m0 + BM <= p.M;
-  if (linear) {
+  if (linear || piecewise) {
     if (whole) store_tile(std::false_type{}, std::true_type{});
     else store_tile(std::true_type{}, std::true_type{});
   } else {
@@ -1024,8 +1058,11 @@ int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
 }
 
 inline void fill_fastdiv_linear(IgemmParams& p) {
-  p.linear_out = p.oSd == 1 && p.oSh == 1 && p.oSw == 1 && p.oOd == 0 && p.oOh == 0 && p.oOw == 0 && p.oDm == p.Gd &&
-                 p.oHm == p.Gh && p.oWm == p.Gw && !p.dmajor;
+  const bool dense = p.oSd == 1 && p.oSh == 1 && p.oSw == 1 && p.oOd == 0 && p.oOh == 0 && p.oOw == 0 && p.oDm == p.Gd &&
+                     p.oHm == p.Gh && p.oWm == p.Gw;
+  p.linear_out = dense && !p.dmajor;
+  p.dm_dense = dense && p.dmajor;
+  p.dP = fastdiv_make(p.Gh * p.Gw);
 }
 
 inline void fill_fastdiv(IgemmParams& p) {
