@@ -409,6 +409,9 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "GB of L2-miss (fabric) traffic per launch: PMC FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache "
                             "hits (MI355X_MICROARCH.md), so an upper bound of the HBM bytes",
+            "flop_count": "algorithmic: 2 x MACs of the convolution INCLUDING the taps that fall into the zero padding (SURVEY.md 8d); "
+                          "the kernels skip the chunks of taps that are padding for a whole tile (DESIGN.md 5d), so the matrix pipe "
+                          "executes fewer — up to a third fewer on the 2-frame layers",
             "algorithmic_gb_per_launch": round(alg_gb, 4),
             "traffic_over_algorithmic": None if traffic is None or alg_gb <= 0 else round(traffic / alg_gb, 2),
             "traffic_source": traffic_src,
