@@ -58,8 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=32, help="clips per CPU-baseline step (BASELINE config 1: 32)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps after one warm-up step")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="run the step as one replayed HIP graph (rspnet_amd/graph_step.py; N=1 only).  auto: for the backbones it "
-                         "pays for (everything but C3D, whose 250 long launches leave the host nothing to hide)")
+                    help="run the step as one replayed HIP graph (rspnet_amd/graph_step.py; N=1 only; auto = on).  What it buys is "
+                         "concurrency between the step's independent passes: S3D-G's small launches, and — since the kernels skip "
+                         "padded taps and tiles differ in length (DESIGN.md 5d) — also C3D's long ones (96.9 -> 94.0 ms)")
     ap.add_argument("--no-other-workloads", dest="other_workloads", action="store_false",
                     help="skip BASELINE configs 3-5 (R3D-18, R(2+1)D, S3D-G) that the default N=1 C3D run appends")
     ap.add_argument("--other-steps", type=int, default=30)
@@ -270,7 +271,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     im_q = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
     im_k = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
 
-    use_graph = cuda and ws == 1 and (args.graph == "on" or (args.graph == "auto" and arch != "c3d"))
+    use_graph = cuda and ws == 1 and args.graph in ("on", "auto")
     stepper = None
     if use_graph:
         from rspnet_amd.graph_step import GraphedPretextStep
