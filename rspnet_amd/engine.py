@@ -307,8 +307,14 @@ class BranchStreams:
     side stream is consumed there or, after that join, on the trunk."""
     _streams: Dict[Tuple, "torch.cuda.Stream"] = {}
     origin = None          # raw handle of the capturing stream, set by GraphedPretextStep around the capture
-    SMALL_WGRAD_FLOPS = 50e9      # weight gradients below this size run beside the input gradient (side_task); swept 50 / 120 /
+    SMALL_WGRAD_FLOPS = float(os.environ.get("RSP_WGRAD_ASIDE_GFLOP", "50")) * 1e9      # weight gradients below this size run beside the input gradient (side_task); swept 50 / 120 /
     #   300 / 1000 GFLOP: larger ones compete with the input gradient for the matrix pipe (R(2+1)D 77.9 -> 80.2 ms at 300)
+
+    # ... and mid-sized ones whose operands are small enough not to fight the input gradient for HBM: since tiles differ in length
+    # (DESIGN 5d) a second matrix kernel fills the ragged ends of the launches — C3D 93.7 -> 92.9 ms with conv3a / conv4 included;
+    # R(2+1)D's 266-GFLOP weight gradients stream 1.3 GB each and stay in line (77.9 -> 80.2 ms beside the input gradient)
+    MID_WGRAD_FLOPS = float(os.environ.get("RSP_WGRAD_MID_GFLOP", "400")) * 1e9
+    MID_WGRAD_BYTES = 450e6
 
     def __init__(self, x: torch.Tensor):
         self.dev = x.device
@@ -691,7 +697,8 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 gb.zero_()
         # (a channel-padded geometry writes only the parameter's own channels: the reduce drops the padding's gradients)
         gw = grad_of(node.conv.weight)
-        if sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS:      # (a no-op outside a single-rank graph capture)
+        if sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS or (sv.cg.flops < BranchStreams.MID_WGRAD_FLOPS and
+                                                             sv.cg.bytes < BranchStreams.MID_WGRAD_BYTES):      # (a no-op outside a single-rank graph capture)
             branches.side_task(lambda: be.conv_wgrad(sv.cg, sv.x, dy, gw), (sv.x, dy))
         else:
             be.conv_wgrad(sv.cg, sv.x, dy, gw)
