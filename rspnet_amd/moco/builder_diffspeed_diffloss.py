@@ -162,6 +162,9 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._ptr_on_device = False           # True: queue_ptr lives on the device only (graph-captured steps)
         self.overlap_query = not os.environ.get("RSP_NO_QOVERLAP")     # (switches for A/B runs of tools/)
         self.overlap_keys = not os.environ.get("RSP_NO_KOVERLAP")
+        # issued eagerly (more than one rank; --no-graph) the same fork pays when the host runs far ahead of the GPU — C3D's 250 long
+        # launches — and the unequal tiles of DESIGN 5d leave slots for it to fill
+        self.overlap_query_eager = not os.environ.get("RSP_NO_EAGER_OVERLAP")
         self._query_stream = self._key_stream = None
         self._ema_k = self._ema_map = None
         self._q_pre = None
@@ -511,7 +514,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             # logits.  Inside a captured HIP graph (rspnet_amd/graph_step.py) it is forked onto its own stream and runs beside them:
             # the small late layers of either pass leave most of the machine idle on their own.
             side = None
-            if self.overlap_query and dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            if self.overlap_query and dev.type == "cuda" and (torch.cuda.is_current_stream_capturing() or self.overlap_query_eager):
                 main = torch.cuda.current_stream(dev)
                 side = self._query_stream = self._query_stream or torch.cuda.Stream(device=dev)
                 side.wait_stream(main)
@@ -524,7 +527,8 @@ class MoCoDiffLossTwoFc(nn.Module):
             self._nbt_k += 2
             self.encoder_k._packed.refresh_now()      # (re-pack of the momentum-updated weights: before the passes fork)
             side_k = None
-            if side is not None and self.overlap_keys:
+            # (eagerly only at one rank: with more, the key passes carry the feature all-gathers, which stay on the main stream)
+            if side is not None and self.overlap_keys and (torch.cuda.is_current_stream_capturing() or _world()[1] == 1):
                 main = torch.cuda.current_stream(dev)
                 side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
                 side_k.wait_stream(main)
