@@ -326,8 +326,8 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     gc.freeze()
     fence()
     graphed = stepper is not None and not stepper.disabled and len(stepper.graphs) > 0
-    if cuda and not graphed:
-        be.event_log = []                      # (a replayed graph has no per-launch events: see the roofline pass below)
+    # (per-launch events are not recorded in the timed region: a replayed graph has none, and the eager step runs its independent
+    #  passes on side streams, where a launch's interval also holds its neighbours' time — see the roofline pass below)
     if ws > 1:
         inner.comm_log = {}
     marks, host = [], []
@@ -345,8 +345,6 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     fence()
     dt = time.perf_counter() - t0
     log = []
-    if cuda and not graphed:
-        log, be.event_log = be.event_log, None
     comm, inner.comm_log = inner.comm_log, None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if ws > 1:
@@ -359,17 +357,24 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     if stepper is not None and not graphed:
         res["graph_fallback"] = stepper.fallback_reason or "not captured within the warm-up steps"
     roof_steps = steps
-    if graphed:
-        # roofline pass: the same step issued eagerly with a HIP-event pair around every convolution launch (kernel durations
-        # cannot be read out of a replayed graph); outside the timed region, continuing the same training state
+    if cuda:
+        # roofline pass: the same step issued eagerly ON ONE STREAM with a HIP-event pair around every convolution launch — the
+        # kernels' own durations, as rocprofv3's serialised trace reports them; outside the timed region, continuing the same
+        # training state (the step's results do not depend on how it is issued)
+        from rspnet_amd.engine import BranchStreams
         roof_steps = max(2, min(10, steps))
-        eager_step()
-        fence()
-        be.event_log = []
-        for _ in range(roof_steps):
+        saved = (inner.overlap_query_eager, BranchStreams.EAGER_TASKS)
+        inner.overlap_query_eager, BranchStreams.EAGER_TASKS = False, False
+        try:
             eager_step()
-        fence()
-        log, be.event_log = be.event_log, None
+            fence()
+            be.event_log = []
+            for _ in range(roof_steps):
+                eager_step()
+            fence()
+            log, be.event_log = be.event_log, None
+        finally:
+            inner.overlap_query_eager, BranchStreams.EAGER_TASKS = saved
     if marks:
         per = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         res["steps_ms"] = {"p50": round(_pct(per, 0.5), 3), "min": round(min(per), 3), "max": round(max(per), 3),
@@ -493,7 +498,9 @@ def run_rank(args):
                        "global_batch": B * ws, "parallelism": f"dp{ws}"},
             "final_loss": round(m["final_loss"], 5),
         }
-        res["config"]["step_issue"] = "one replayed HIP graph (rspnet_amd/graph_step.py)" if m["graph"] else "eager launches"
+        res["config"]["step_issue"] = ("one replayed HIP graph (rspnet_amd/graph_step.py)" if m["graph"] else
+                                       "eager launches (independent passes on side streams)") + \
+            "; roofline numbers from a one-stream eager pass of the same step outside the timed region"
         for k in ("steps_ms", "comm_ms", "roofline", "graph_fallback"):
             if k in m:
                 res[k] = m[k]
@@ -523,8 +530,7 @@ def run_rank(args):
                                 "conv_ms_per_step": rf["all_conv_launches"]["ms_per_step"], "dominant_kernel": rf["kernel"],
                                 "dominant_kernel_frac": rf["frac"], "dominant_kernel_share_of_step": rf["share_of_step"],
                                 "final_loss": od["final_loss"],
-                                "step_issue": od["config"]["step_issue"] + ("; roofline numbers from an eager pass of the same step"
-                                                                            if od["config"]["step_issue"].startswith("one replayed") else "")
+                                "step_issue": od["config"]["step_issue"]
                                 + (f" (graph capture fell back: {od['graph_fallback']})" if "graph_fallback" in od else "")}
             except Exception as e:      # noqa: BLE001 - reported in the line, never fatal for the headline
                 others[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}

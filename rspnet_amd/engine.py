@@ -315,12 +315,21 @@ class BranchStreams:
     # R(2+1)D's 266-GFLOP weight gradients stream 1.3 GB each and stay in line (77.9 -> 80.2 ms beside the input gradient)
     MID_WGRAD_FLOPS = float(os.environ.get("RSP_WGRAD_MID_GFLOP", "400")) * 1e9
     MID_WGRAD_BYTES = 450e6
+    EAGER_TASKS = not os.environ.get("RSP_NO_EAGER_OVERLAP")
 
     def __init__(self, x: torch.Tensor):
         self.dev = x.device
         self.on = bool(x.is_cuda and _ops.backend().name == "hip" and BranchStreams.origin is not None
                        and torch.cuda.is_current_stream_capturing()
                        and torch.cuda.current_stream(self.dev).cuda_stream == BranchStreams.origin)
+        self.origin_h = BranchStreams.origin
+        self.fork_branches = self.on
+        # issued eagerly, the weight-gradient side task still pays (the host is far ahead of those kernels); the inception branches
+        # do not (x1.00: dozens of tiny launches, the host feeds one at a time) and stay in line
+        if (not self.on and BranchStreams.EAGER_TASKS and x.is_cuda and _ops.backend().name == "hip"
+                and not torch.cuda.is_current_stream_capturing()):
+            self.on = True
+            self.origin_h = torch.cuda.current_stream(self.dev).cuda_stream
         self.active: Dict[int, "torch.cuda.Stream"] = {}
         self.task = None       # (task stream, tensors its kernels still read) of the outstanding side task
 
@@ -337,7 +346,7 @@ class BranchStreams:
         the trunk (flat forks); one task outstanding, the previous one is joined first.  `keepalive`: the tensors it reads,
         held until the join so that the graph's memory pool does not hand their blocks out again underneath it."""
         cur = torch.cuda.current_stream(self.dev) if self.on else None
-        if cur is None or cur.cuda_stream != BranchStreams.origin:
+        if cur is None or cur.cuda_stream != self.origin_h:
             return fn()
         self.join_task()
         ts = self._get("task")
@@ -352,7 +361,7 @@ class BranchStreams:
             self.task = None
 
     def run(self, node, fn):
-        br = getattr(node, "branch", 0) if self.on else 0
+        br = getattr(node, "branch", 0) if (self.on and self.fork_branches) else 0
         if br == 0:
             self.join()
             return fn()
@@ -697,8 +706,10 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 gb.zero_()
         # (a channel-padded geometry writes only the parameter's own channels: the reduce drops the padding's gradients)
         gw = grad_of(node.conv.weight)
-        if sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS or (sv.cg.flops < BranchStreams.MID_WGRAD_FLOPS and
-                                                             sv.cg.bytes < BranchStreams.MID_WGRAD_BYTES):      # (a no-op outside a single-rank graph capture)
+        # (side stream: single rank only — a gradient hook, i.e. the bucketed all-reduce of the data-parallel path, must see the
+        #  gradient finished on the stream it is called on)
+        if after_param_grads is None and (sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS or
+                                          (sv.cg.flops < BranchStreams.MID_WGRAD_FLOPS and sv.cg.bytes < BranchStreams.MID_WGRAD_BYTES)):
             branches.side_task(lambda: be.conv_wgrad(sv.cg, sv.x, dy, gw), (sv.x, dy))
         else:
             be.conv_wgrad(sv.cg, sv.x, dy, gw)

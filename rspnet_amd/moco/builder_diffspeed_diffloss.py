@@ -440,7 +440,8 @@ class MoCoDiffLossTwoFc(nn.Module):
                     launched.add(bi)
                     handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
 
-        self.encoder_q.backward_ndhwc(ectx, dqA, dqM, grad_of, after)
+        # (no buckets, no hook: the engine may then put weight gradients on a side stream — a hook would have to see them finished)
+        self.encoder_q.backward_ndhwc(ectx, dqA, dqM, grad_of, after if buckets else None)
         for bi, (s, e, ids) in enumerate(buckets):
             if bi not in launched:
                 handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
