@@ -168,6 +168,35 @@ def test_conv_fuzz(hip, case):
     close(db, db_ref, 2e-5, "dbias")
 
 
+def _fuzz_depth_cases(n=20, seed=20261003):
+    """Seeded random geometries for the padded-tap skipping: depth taps with depth padding, batches of 2 / 8 / 16 (one and eight
+    parts of the depth-major enumeration), channel counts on the slice-major (C % 32 == 0, long K) and the tap-major walks (one tap
+    per chunk, several taps per chunk, taps straddling chunks), strides, frames from a fraction of a tile to several tiles."""
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < n:
+        k = (rng.choice((3, 3, 3, 5, 7)), rng.choice((1, 3, 3)), rng.choice((1, 3, 3)))
+        s = tuple(rng.choice((1, 1, 1, 2)) for _ in range(3))
+        p = (rng.randint(1, k[0] // 2), rng.randint(0, k[1] // 2), rng.randint(0, k[2] // 2))
+        N = rng.choice((2, 8, 8, 16))
+        D, H, W = rng.randint(1, 6), rng.randint(4, 24), rng.randint(4, 24)
+        if any((i + 2 * pp - kk) < 0 for i, kk, pp in zip((D, H, W), k, p)):
+            continue
+        cin = rng.choice((4, 32, 32, 64, 96, 128, 144, 160))
+        cout = rng.choice((32, 64, 128, 144))
+        flop = 2.0 * N * D * H * W * cin * cout * k[0] * k[1] * k[2] / (s[0] * s[1] * s[2])
+        if flop > 25e9 or cin * k[0] * k[1] * k[2] > 14000:
+            continue
+        cases.append((N, D, H, W, cin, cout, k, s, p))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_depth_cases(), ids=lambda c: "x".join(map(str, c[:6])) + f"k{c[6]}s{c[7]}p{c[8]}")
+def test_conv_fuzz_padded_depth(hip, case):
+    test_conv_fuzz(hip, case)
+
+
 def test_conv_is_run_to_run_deterministic(hip):
     g = ConvGeom(1, 2, 7, 7, 256, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1))   # split-K path
     x, w = rnd(1, 2, 7, 7, 256, seed=5).to(DEV), rnd(512, 256, 3, 3, 3, seed=6).to(DEV)
