@@ -323,13 +323,18 @@ class BranchStreams:
                        and torch.cuda.is_current_stream_capturing()
                        and torch.cuda.current_stream(self.dev).cuda_stream == BranchStreams.origin)
         self.origin_h = BranchStreams.origin
-        self.fork_branches = self.on
+        # Inception branches as parallel graph branches: x1.14-1.31 on a block of its own and 51 -> 47 ms per S3D-G step when they were
+        # the only concurrency in the graph; with the three forward passes and the weight gradients on streams of their own the
+        # machine is already fed and the extra forks cost more in joins than they fill (41.6 -> 40.1 ms without them): off,
+        # RSP_BRANCH_FORKS=1 brings them back
+        self.fork_branches = self.on and bool(os.environ.get("RSP_BRANCH_FORKS"))
         # issued eagerly, the weight-gradient side task still pays (the host is far ahead of those kernels); the inception branches
         # do not (x1.00: dozens of tiny launches, the host feeds one at a time) and stay in line
         if (not self.on and BranchStreams.EAGER_TASKS and x.is_cuda and _ops.backend().name == "hip"
                 and not torch.cuda.is_current_stream_capturing()):
             self.on = True
             self.origin_h = torch.cuda.current_stream(self.dev).cuda_stream
+            # (measured: S3D-G issued eagerly 394 clips/s with the branches in line, 355-358 forked)
         self.active: Dict[int, "torch.cuda.Stream"] = {}
         self.task = None       # (task stream, tensors its kernels still read) of the outstanding side task
 
