@@ -12,8 +12,12 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for a in "${ARCHS[@]}"; do
   # the bench line as the driver runs it for this backbone (step issue: bench.py --graph auto), then the profiled passes with the
-  # step issued EAGERLY (--graph off): per-dispatch rows in launch order, one counter pass each
+  # step issued EAGERLY ON ONE STREAM (--graph off, RSP_NO_EAGER_OVERLAP=1): per-dispatch rows in launch order, kernel durations that
+  # are the kernels' own (on side streams / as graph branches a dispatch's interval also holds its neighbours' time) — the same
+  # conditions as bench.py's roofline pass, whose avg_launch_ms they must agree with; one counter pass each
+  unset RSP_NO_EAGER_OVERLAP
   python3 "$R/bench.py" --arch "$a" --no-cpu-baseline --no-other-workloads > "$OUT/bench_${TAG}_$a.json" 2> "$OUT/bench_${TAG}_$a.err"
+  export RSP_NO_EAGER_OVERLAP=1
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --graph off \
     > "$OUT/bench_under_rocprof_${TAG}_$a.json" 2> "$OUT/prof_${TAG}_$a.err"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_${TAG}_$a" -- python3 "$R/bench.py" --arch "$a" --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --graph off \

@@ -21,7 +21,8 @@ out = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
 BATCH = {"c3d": 32, "resnet18": 32, "r2plus1d-vcop": 32, "s3dg": 16}
-PROFILED_STEPS = 3          # --steps 2 --warmup 1 in the PMC passes
+PROFILED_STEPS = 6          # --steps 2 --warmup 1 in the PMC passes, + bench.py's roofline pass behind them (1 + 2 steps)
+TRACED_STEPS = 24           # --steps 10 --warmup 3 in the kernel-trace pass, + the roofline pass (1 + 10 steps)
 
 
 def short(name):
@@ -86,7 +87,7 @@ for arch, B in BATCH.items():
     traffic[f"{arch}_b{B}"] = ent
     rows = list(csv.DictReader(open(ks)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    print(f"== {arch} B={B}: GPU time {tot / 1e6 / 13:.2f} ms/step over 13 profiled steps")
+    print(f"== {arch} B={B}: GPU time {tot / 1e6 / TRACED_STEPS:.2f} ms/step over {TRACED_STEPS} profiled steps")
     for r in rows[:10]:
         k = short(r["Name"])
         t = traffic[f"{arch}_b{B}"].get(k, {})
