@@ -2,6 +2,7 @@
 time per step, achieved TFLOP/s and the kernel instance that ran it — sorted by time.  `python tools/layer_table.py --arch s3dg`."""
 import argparse
 import os
+os.environ.setdefault("RSP_NO_EAGER_OVERLAP", "1")      # per-launch event intervals: the step on ONE stream (no side streams)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
