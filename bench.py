@@ -69,6 +69,12 @@ def parse_args(argv=None):
                     help="self-launcher only: seconds after which a still-running job is killed and rc=124 returned")
     ap.add_argument("--collective-timeout", type=float, default=300.0,
                     help="process-group timeout (rendezvous and every collective), seconds")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="--gpus 1 only: initialise the real nccl (RCCL) process group with ONE rank and run the data-parallel step — "
+                         "clip all-to-all, fused key all-gather, bucketed gradient all-reduce, gloo side group — as N > 1 runs it "
+                         "(MoCoDiffLossTwoFc(force_collectives=True)); the line carries comm_ms")
+    ap.add_argument("--eager-steps", type=int, default=10,
+                    help="N=1 graphed runs: also time this many eagerly issued steps (the way N > 1 issues them) after the timed region")
     ap.add_argument("--selftest-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--selftest-parity", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-cpu", action="store_true",
@@ -262,8 +268,9 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     cfg = {"model": {"arch": arch},
            "moco": {"dim": 128, "k": K, "m": 0.999, "t": 0.07, "fc_type": "linear", "diff_speed": [2]}}
     torch.manual_seed(1234)
-    model = ModelFactory(cfg).build_moco_diffloss(device=dev)
+    model = ModelFactory(cfg).build_moco_diffloss(device=dev, force_collectives=True if args.force_dp else None)
     model.train()
+    coll = bool(model.module._dp()[2])
     crit = Loss(margin=2.0, A=1.0, M=1.0)
     lr = base_lr * ws * B / 64                            # framework/utils/environment.py:13-16
     opt = SGD(model.parameters(), lr=lr, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=False)  # pretrain.py:65-72
@@ -271,7 +278,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     im_q = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
     im_k = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
 
-    use_graph = cuda and ws == 1 and args.graph in ("on", "auto")
+    use_graph = cuda and (not coll or os.environ.get("RSP_GRAPH_COLLECTIVES")) and args.graph in ("on", "auto")
     stepper = None
     if use_graph:
         from rspnet_amd.graph_step import GraphedPretextStep
@@ -328,7 +335,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     graphed = stepper is not None and not stepper.disabled and len(stepper.graphs) > 0
     # (per-launch events are not recorded in the timed region: a replayed graph has none, and the eager step runs its independent
     #  passes on side streams, where a launch's interval also holds its neighbours' time — see the roofline pass below)
-    if ws > 1:
+    if coll and not graphed:
         inner.comm_log = {}
     marks, host = [], []
     if cuda:
@@ -353,7 +360,17 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     final_loss = float(loss.detach())
     step_ms = dt / steps * 1e3
     res = {"clips_per_s": ws * B * steps / dt, "ms_per_step": step_ms, "final_loss": final_loss, "K": K, "lr": lr, "B": B,
-           "hw": hw, "graph": bool(graphed)}
+           "hw": hw, "graph": bool(graphed), "collectives": coll}
+    if graphed and args.eager_steps > 0:
+        # the same step issued eagerly with its side streams — how a run with more than one rank issues it (RCCL collectives are
+        # not captured): the N = 1 point of a scaling curve in the N > 1 issue mode
+        eager_step()
+        fence()
+        te = time.perf_counter()
+        for _ in range(args.eager_steps):
+            eager_step()
+        fence()
+        res["eager_ms_per_step"] = (time.perf_counter() - te) / args.eager_steps * 1e3
     if stepper is not None and not graphed:
         res["graph_fallback"] = stepper.fallback_reason or "not captured within the warm-up steps"
     roof_steps = steps
@@ -464,7 +481,13 @@ def run_rank(args):
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if ws > 1:
+    if args.force_dp and ws != 1:
+        raise SystemExit("bench.py: --force-dp is a one-rank run (--gpus 1); with more ranks the collectives are on anyway")
+    if args.force_dp and not cpu_selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ws > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # a rank that never arrives / a collective that never completes ends the job with rc != 0 (watchdog abort) instead of
         # holding the node until the driver's own limit
@@ -501,6 +524,14 @@ def run_rank(args):
         res["config"]["step_issue"] = ("one replayed HIP graph (rspnet_amd/graph_step.py)" if m["graph"] else
                                        "eager launches (independent passes on side streams)") + \
             "; roofline numbers from a one-stream eager pass of the same step outside the timed region"
+        if m["collectives"]:
+            res["config"]["collectives"] = ("RCCL (nccl backend): clip all-to-all x2, fused key all-gather x1, bucketed gradient "
+                                            "all-reduce from inside backward, gloo side group for the step's random draws"
+                                            + (" — forced in a world of one rank (--force-dp)" if args.force_dp else ""))
+        if "eager_ms_per_step" in m:
+            res["issued_eagerly"] = {"ms_per_step": round(m["eager_ms_per_step"], 3),
+                                     "clips_per_s": round(ws * B / m["eager_ms_per_step"] * 1e3, 2), "steps": args.eager_steps,
+                                     "note": "same step, eager launches with the same side streams: how N > 1 ranks issue it"}
         for k in ("steps_ms", "comm_ms", "roofline", "graph_fallback"):
             if k in m:
                 res[k] = m[k]
@@ -535,6 +566,22 @@ def run_rank(args):
             except Exception as e:      # noqa: BLE001 - reported in the line, never fatal for the headline
                 others[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}
         res["other_workloads"] = others
+        # ... and the data-parallel path itself on this one GPU: a child run with the real RCCL group of one rank and every
+        # collective of the N > 1 step forced on (what the 2/4/8-GPU runs execute, minus the wires)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-dp", "--steps", str(args.other_steps), "--warmup",
+               str(args.other_warmup), "--queue", str(args.queue), "--no-cpu-baseline", "--no-other-workloads"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr.strip()[-300:]}")
+            od = json.loads(lines[-1])
+            res["dp_path_at_one_rank"] = {"clips_per_s": round(od["value"], 2), "ms_per_step": od["ms_per_step"], "steps": od["steps"],
+                                          "comm_ms": od.get("comm_ms"), "collectives": od["config"].get("collectives"),
+                                          "step_issue": od["config"]["step_issue"], "final_loss": od["final_loss"],
+                                          "vs_this_line": round(od["value"] / res["value"], 4)}
+        except Exception as e:      # noqa: BLE001
+            res["dp_path_at_one_rank"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
         if want_cpu:
             try:
@@ -546,7 +593,7 @@ def run_rank(args):
             except Exception as e:      # noqa: BLE001 - the measured line still goes out
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         print(json.dumps(res), flush=True)
-    if ws > 1:
+    if ws > 1 or args.force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

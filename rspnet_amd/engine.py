@@ -640,8 +640,10 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
 def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, after_param_grads=None,
                  want_input_grad: bool = False, packed: Optional[PackedWeights] = None):
     """Backward through the plan.  `grad_of(param)` returns the (pre-allocated, flat-buffer) gradient view to
-    fill for a parameter, or None to skip it.  `after_param_grads(node_index)` is called once a node's parameter
-    gradients are complete (used to launch bucketed all-reduces overlapped with the rest of backward).
+    fill for a parameter, or None to skip it.  `after_param_grads(node_index, join_side_tasks)` is called once a node's parameter
+    gradients have been ISSUED (used to launch bucketed all-reduces overlapped with the rest of backward); a weight gradient may
+    still be running on the side-task stream then — the hook calls `join_side_tasks()` before it reads gradients on the
+    current stream.
     want_input_grad: also propagate to the plan's input slot and return that gradient (projection-head sub-plans, whose
     input is the backbone feature; the backbone's own input is the clip and needs none)."""
     be = _ops.backend()
@@ -678,7 +680,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 # every real filter element appears once in a class's virtual filter: unique indices, order-independent
                 gflat.index_add_(0, vs.dst[c], gv.view(-1).index_select(0, vs.src[c]))
         if after_param_grads is not None:
-            after_param_grads(ni)
+            after_param_grads(ni, branches.join_task)
 
     def convbn_bwd(node, key, ni):
         sv = ctx.saved.pop(key)
@@ -695,7 +697,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                                     grad_of(bn.weight), grad_of(bn.bias), grad_of(gnode.conv.weight), grad_of(gnode.conv.bias))
             dres = None
             if after_param_grads is not None:
-                after_param_grads(gi)
+                after_param_grads(gi, branches.join_task)
         else:
             dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout) if node.into is not None else dslots.pop(node.dst)
             dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
@@ -711,15 +713,15 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 gb.zero_()
         # (a channel-padded geometry writes only the parameter's own channels: the reduce drops the padding's gradients)
         gw = grad_of(node.conv.weight)
-        # (side stream: single rank only — a gradient hook, i.e. the bucketed all-reduce of the data-parallel path, must see the
-        #  gradient finished on the stream it is called on)
-        if after_param_grads is None and (sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS or
-                                          (sv.cg.flops < BranchStreams.MID_WGRAD_FLOPS and sv.cg.bytes < BranchStreams.MID_WGRAD_BYTES)):
+        # (side stream: a gradient hook — the bucketed all-reduce of the data-parallel path — joins the task before it lets a
+        #  bucket go, see run_backward's docstring)
+        if (sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS or
+                (sv.cg.flops < BranchStreams.MID_WGRAD_FLOPS and sv.cg.bytes < BranchStreams.MID_WGRAD_BYTES)):
             branches.side_task(lambda: be.conv_wgrad(sv.cg, sv.x, dy, gw), (sv.x, dy))
         else:
             be.conv_wgrad(sv.cg, sv.x, dy, gw)
         if after_param_grads is not None:
-            after_param_grads(ni)
+            after_param_grads(ni, branches.join_task)
         if node.src != plan.input_slot or want_input_grad:
             add_grad(node.src, be.conv_dgrad_packed(sv.cg, dy, packed.get_dgrad(node, sv.cg)))
 
@@ -749,7 +751,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                     g.copy_(tmp[off:off + g.shape[0]])
                 off += m.conv.weight.shape[0]
         if after_param_grads is not None:
-            after_param_grads(ni)
+            after_param_grads(ni, branches.join_task)
         if ms[0].src != plan.input_slot or want_input_grad:
             add_grad(ms[0].src, be.conv_dgrad_packed(cg, dy_cat, packed.get_dgrad(node._cat_node(), cg)))
 
@@ -764,7 +766,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             dz = be.eltwise("relu_bwd", y, dout.contiguous()) if node.relu else dout.contiguous()
             be.conv_wgrad(cg, xin, dz, grad_of(node.conv.weight), grad_of(node.conv.bias))
             if after_param_grads is not None:
-                after_param_grads(ni)
+                after_param_grads(ni, branches.join_task)
             if node.src != plan.input_slot or want_input_grad:
                 add_grad(node.src, be.conv_dgrad_packed(cg, dz, packed.get_dgrad(node, cg)))
             del dz, dout
@@ -782,7 +784,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             add_grad(node.src, be.gate_bwd(xin, dout, node.conv.weight.data, mean, gate, grad_of(node.conv.weight),
                                            grad_of(node.conv.bias)))
             if after_param_grads is not None:
-                after_param_grads(ni)
+                after_param_grads(ni, branches.join_task)
         else:
             raise NotImplementedError(f"plan node {type(node).__name__}")
 

@@ -19,8 +19,8 @@ pinned buffer and copied to a static device buffer before the replay.  Everythin
 graph: momentum update, the device-side randperm of _diff_speed (graph-safe Philox offsets), both key passes, query forward,
 logits, losses, backward, SGD, enqueue (pointer read and advanced on the device: rsp_queue_enqueue_dev).
 
-Single rank only (the collectives of the data-parallel path are issued eagerly); any failure to capture falls back to the
-eager loop with a logged warning — the result is the same either way, kernel for kernel.
+Single rank by default (the collectives of the data-parallel path are issued eagerly, with the same side streams); any failure to
+capture falls back to the eager loop with a logged warning — the result is the same either way, kernel for kernel.
 """
 from __future__ import annotations
 
@@ -48,8 +48,12 @@ class GraphedPretextStep:
         self.eager_steps: Dict[Tuple, int] = {}
         self.static = None
         self.pool = None                          # one memory pool for all graphs of this stepper: only one replays at a time
-        self.disabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.fallback_reason = "more than one rank" if self.disabled else None
+        # with the data-parallel collectives on, the step is issued eagerly — same kernels, same side streams (query forward, second
+        # key pass, small weight gradients), RCCL on its own stream.  RSP_GRAPH_COLLECTIVES=1 captures the collectives too
+        # (exercised at one rank with force_collectives; not the default at N > 1, where it has never run).
+        import os
+        self.disabled = bool(self.model._dp()[2]) and not os.environ.get("RSP_GRAPH_COLLECTIVES")
+        self.fallback_reason = "data-parallel collectives on (issued eagerly)" if self.disabled else None
 
     # ---- the five statements ------------------------------------------------------------------------------------------------
     def _eager(self, im_q, im_k, host):
@@ -81,6 +85,8 @@ class GraphedPretextStep:
             m._ptr_on_device = True
             m._ptr_host = None
         st = self.static
+        if not m._ptr_checked:
+            m._check_queue_ptr(B * (dist.get_world_size() if dist.is_initialized() else 1))
         if im_q.shape != st["im_q"].shape:
             raise ValueError("GraphedPretextStep: the clip shape changed; build a new GraphedPretextStep for it")
         if im_q.data_ptr() != st["im_q"].data_ptr():
@@ -135,8 +141,11 @@ class GraphedPretextStep:
             # configuration may rebuild a packed-weight set, and the superseded buffers — still baked into this graph's kernel
             # arguments — would be freed.  (The library's scratch buffers come from the graph's own pool: ops.HipOps._workspace.)
             m = self.model
+            # (also baked into captured kernel arguments: the deferred BatchNorm-update set of encoder_k — its moment buffer and job
+            #  table — and the virtual-pixel stems' derived filters and index vectors; both are rebuilt when pointers / devices change)
             keep = [list(m.encoder_q._packed._sets), list(m.encoder_k._packed._sets), m._flat,
-                    getattr(m._flat, "m_flat", None), getattr(m, "_nbt_q", None), getattr(m, "_nbt_k", None), st]
+                    getattr(m._flat, "m_flat", None), getattr(m, "_nbt_q", None), getattr(m, "_nbt_k", None), st,
+                    m._ema_k, m._ema_map, list(m.encoder_q._packed._virtual.values()), list(m.encoder_k._packed._virtual.values())]
             self.graphs[key] = (g, outs, keep)
             log.info("rspnet_amd: pretext step captured as a HIP graph (speed %s, clips %s)", key[0], key[1])
             # the capture itself executed nothing: run the step it stands for

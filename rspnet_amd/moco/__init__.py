@@ -36,7 +36,7 @@ class DataParallelPretext(nn.Module):
     def __init__(self, module: MoCoDiffLossTwoFc):
         super().__init__()
         self.module = module
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if module._dp()[2]:
             module._prepare()
             with torch.no_grad():
                 dist.broadcast(module._flat.q_flat, src=0)
@@ -49,7 +49,7 @@ class DataParallelPretext(nn.Module):
     @torch.no_grad()
     def sync_buffers(self):
         """Broadcast rank 0's buffers (what DDP's broadcast_buffers does before each forward)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.module._dp()[2]:
             for b in self.module.buffers():
                 dist.broadcast(b, src=0)
             self.module._ptr_host = None
@@ -62,7 +62,8 @@ class ModelFactory:
     def __init__(self, cfg):
         self.cfg = cfg
 
-    def build_moco_diffloss(self, device=None):
+    def build_moco_diffloss(self, device=None, force_collectives=None):
+        """force_collectives: see MoCoDiffLossTwoFc (run the data-parallel collectives in a world of one rank)."""
         moco_dim = int(_get(self.cfg, "moco.dim"))
         moco_t = float(_get(self.cfg, "moco.t"))
         moco_k = int(_get(self.cfg, "moco.k"))
@@ -75,7 +76,8 @@ class ModelFactory:
             return MultiTaskWrapper(base_model_class, num_classes=num_classes, fc_type=moco_fc_type, finetune=False,
                                     groups=1)
 
-        model = MoCoDiffLossTwoFc(model_class, dim=moco_dim, K=moco_k, m=moco_m, T=moco_t, diff_speed=moco_diff_speed)
+        model = MoCoDiffLossTwoFc(model_class, dim=moco_dim, K=moco_k, m=moco_m, T=moco_t, diff_speed=moco_diff_speed,
+                                  force_collectives=force_collectives)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         if device is not None:

@@ -140,10 +140,16 @@ class _PretextFn(torch.autograd.Function):
 
 class MoCoDiffLossTwoFc(nn.Module):
     def __init__(self, base_encoder, dim=128, K=65536, m=0.999, T=0.07, mlp=False,
-                 diff_speed: Optional[List[int]] = None):
+                 diff_speed: Optional[List[int]] = None, *, force_collectives: Optional[bool] = None):
+        """Reference signature (:286-296) + one keyword: `force_collectives` (default: the RSP_FORCE_COLLECTIVES environment
+        variable) makes every collective of the data-parallel step run even in a world of ONE rank — the clip all-to-all with
+        its split lists, the fused key all-gather, the bucketed gradient all-reduce launched from inside backward, the host-side
+        broadcast of the step's random draws.  With one rank they move nothing, so the results are those of the plain step; the
+        switch exists so that the RCCL path executes on a 1-GPU machine (tests/test_rccl_gpu.py, bench.py --force-dp)."""
         super().__init__()
         self.K, self.m, self.T = K, m, T
         self.diff_speed = diff_speed
+        self.force_collectives = bool(os.environ.get("RSP_FORCE_COLLECTIVES")) if force_collectives is None else bool(force_collectives)
         self.encoder_q = base_encoder(num_classes=dim)
         self.encoder_k = base_encoder(num_classes=dim)
         if mlp:
@@ -160,6 +166,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._q_params: List[nn.Parameter] = []
         self._ptr_host: Optional[int] = None
         self._ptr_on_device = False           # True: queue_ptr lives on the device only (graph-captured steps)
+        self._ptr_checked = False             # the device-resident pointer has been validated against the enqueue size
         self.overlap_query = not os.environ.get("RSP_NO_QOVERLAP")     # (switches for A/B runs of tools/)
         self.overlap_keys = not os.environ.get("RSP_NO_KOVERLAP")
         # issued eagerly (more than one rank; --no-graph) the same fork pays when the host runs far ahead of the GPU — C3D's 250 long
@@ -178,9 +185,16 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._q_version = None
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
 
+    def _dp(self):
+        """(rank, world size, collectives on?) — the data-parallel exchanges run with more than one rank, or with any
+        initialised process group when `force_collectives` is set."""
+        rank, ws = _world()
+        return rank, ws, ws > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
+
     # ---- state ----------------------------------------------------------------------------------------------------
     def _state_loaded(self):
         self._ptr_host = None
+        self._ptr_checked = False
         self._q_version = None
         self.encoder_q.weights_changed()
         self.encoder_k.weights_changed()
@@ -271,10 +285,10 @@ class MoCoDiffLossTwoFc(nn.Module):
         (random.choice :430, torch.randperm :372 twice); rank 0's values win (:375-378 broadcasts idx_shuffle; the speed must be
         rank-shared as well, or T_real — hence every all-to-all / all-gather shape — would differ across ranks when
         diff_speed has several entries).  One host-side broadcast carries all three."""
-        rank, ws = _world()
+        rank, ws, coll = self._dp()
         speed = random.choice(self.diff_speed)
         sh1, sh2 = torch.randperm(B * ws), torch.randperm(B * ws)
-        if ws > 1:
+        if coll:
             msg = torch.cat([torch.tensor([speed], dtype=torch.int64), sh1.to(torch.int64), sh2.to(torch.int64)])
             group = self._cpu_pg()
             if group is not None:
@@ -288,13 +302,14 @@ class MoCoDiffLossTwoFc(nn.Module):
         return speed, sh1.numpy().astype(np.int64), sh2.numpy().astype(np.int64)
 
     @staticmethod
-    def _exchange_plan(idx: np.ndarray, B: int, rank: int, ws: int):
+    def _exchange_plan(idx: np.ndarray, B: int, rank: int, ws: int, splits: bool = False):
         """Host arithmetic of one shuffle-BN exchange under the global permutation `idx` (:361-387): which of my clips go
         where (send order, all-to-all splits), where every global sample ends up (for the un-shuffle) and the position each
-        arriving clip has in the reference's shuffled batch."""
+        arriving clip has in the reference's shuffled batch.  `splits`: build the all-to-all split lists at one rank too
+        (force_collectives)."""
         G = idx.reshape(ws, B)
         owner = G // B
-        if ws == 1:
+        if ws == 1 and not splits:
             send_src, in_splits, out_splits = idx.astype(np.int32), None, None
         else:
             parts, in_splits = [], []
@@ -334,20 +349,20 @@ class MoCoDiffLossTwoFc(nn.Module):
         return out
 
     @torch.no_grad()
-    def _shuffle_exchange(self, im: Tensor, step: Tensor, T_out: int, plan, src: Tensor, loc_t: Tensor):
+    def _shuffle_exchange(self, im: Tensor, step: Tensor, T_out: int, plan, src: Tensor):
         """First half of a key pass: shuffle-BN's sample exchange (:361-387).  The clips are sub-sampled first (each has exactly
         one destination rank) and travel in ONE all-to-all, issued asynchronously: both key passes' exchanges are started back
         to back at the top of the step — the permutations are known then — so the second one runs over xGMI under the first
         key pass's convolutions.  Returns the state `_key_pass` consumes."""
         be = _ops.backend()
-        _, ws = _world()
+        _, _, coll = self._dp()
         _, _, in_splits, out_splits, arrival = plan
         handle = None
         x = be.clip_gather(im, src, step[src.long()].contiguous(), T_out, max(im.shape[1], INPUT_CHANNEL_PAD))
-        if ws > 1:
+        if coll:
             xs, x = x, torch.empty_like(x)
             handle = dist.all_to_all_single(x, xs, out_splits, in_splits, async_op=True)
-        return x, handle, loc_t, arrival
+        return x, handle, arrival
 
     @torch.no_grad()
     def _deferred_k(self):
@@ -363,13 +378,9 @@ class MoCoDiffLossTwoFc(nn.Module):
         return self._ema_map
 
     def _key_pass(self, exchange, tag: str, deferred=None, bump: bool = True):
-        """Second half (:408-419): encoder_k on the exchanged clips, then ONE all-gather of the fused (A | M) features that
-        serves both the un-shuffle (:389-406) and the queue's key all-gather (:348).  Returns (features [A | M] of my samples
-        in my order, features of ALL samples in global order (B*ws rows), width of the A part)."""
-        be = _ops.backend()
-        rank, ws = _world()
-        x, handle, loc_t, arrival = exchange
-        B = x.shape[0]
+        """Second half (:408-419): encoder_k on the exchanged clips.  Returns this rank's fused (A | M) features in ARRIVAL
+        order and the width of the A part; `_gather_keys` un-shuffles them."""
+        x, handle, arrival = exchange
         if handle is not None:
             with self._comm("all_to_all_" + tag):
                 handle.wait()
@@ -380,26 +391,58 @@ class MoCoDiffLossTwoFc(nn.Module):
         # introspection only (tests compare with the reference's encoder_k outputs): this rank's key features in arrival
         # order + the position each arrival has in the reference's shuffled batch G[rank]
         self._last_k[0 if tag == "kneg" else 1] = (feats, arrival)
-        if ws > 1:
-            gathered = torch.empty((B * ws, feats.shape[1]), dtype=feats.dtype, device=feats.device)
-            with self._comm("all_gather_" + tag):
-                dist.all_gather_into_tensor(gathered, feats)
+        return feats, a.shape[1]
+
+    @staticmethod
+    def _pair_rows(loc: np.ndarray, B: int, which: int) -> np.ndarray:
+        """Row of global sample g of key pass `which` (0: k_negative, 1: k) in the gathered (ws, 2, B, width) feature block,
+        given its row `loc[g]` in that pass's own rank-major (ws, B) order."""
+        return ((loc // B) * (2 * B) + which * B + loc % B).astype(np.int32)
+
+    def _gather_keys(self, feats_neg: Tensor, feats_k: Tensor, rows_neg: Tensor, rows_k: Tensor):
+        """ONE all-gather per step carries the fused (A | M) features of BOTH key passes: it serves the two un-shuffles
+        (:389-406, twice) and the queue's key all-gather (:348) — five small collectives in the reference.  Returns
+        (k_negative features of all samples in global order, k features of all samples in global order)."""
+        be = _ops.backend()
+        _, ws, coll = self._dp()
+        B = feats_neg.shape[0]
+        mine = torch.stack([feats_neg, feats_k])                    # (2, B, width)
+        if coll:
+            gathered = torch.empty((ws * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+            with self._comm("all_gather_keys"):
+                dist.all_gather_into_tensor(gathered, mine)
         else:
-            gathered = feats
-        all_feats = be.rows_gather(gathered, loc_t)
-        return all_feats[rank * B:(rank + 1) * B], all_feats, a.shape[1]
+            gathered = mine
+        flat = gathered.view(-1, mine.shape[2])
+        return be.rows_gather(flat, rows_neg), be.rows_gather(flat, rows_k)
 
     def _forward_encoder_k(self, im: Tensor, step: Tensor, T_out: int, idx: np.ndarray):
-        """Key pass with shuffle-BN (:408-419) under the global permutation `idx` (exchange + pass, back to back)."""
-        rank, ws = _world()
-        plan = self._exchange_plan(idx, im.shape[0], rank, ws)
-        src, loc_t = self._upload_indices(plan[:2], im.device)
-        return self._key_pass(self._shuffle_exchange(im, step, T_out, plan, src, loc_t), "k")
+        """One key pass with shuffle-BN (:408-419) under the global permutation `idx` (exchange + pass + un-shuffle, back to
+        back).  Returns (features [A | M] of my samples in my order, features of ALL samples in global order, width of A)."""
+        rank, ws, coll = self._dp()
+        B = im.shape[0]
+        plan = self._exchange_plan(idx, B, rank, ws, splits=coll)
+        src, rows, rows2 = self._upload_indices([plan[0], self._pair_rows(plan[1], B, 0), self._pair_rows(plan[1], B, 1)], im.device)
+        self._last_k = [None, None]
+        feats, dim = self._key_pass(self._shuffle_exchange(im, step, T_out, plan, src), "k")
+        all_feats, _ = self._gather_keys(feats, feats, rows, rows2)
+        return all_feats[rank * B:(rank + 1) * B], all_feats, dim
 
     def _comm(self, name: str):
         """Context that books the time the compute stream (CPU backends: the host) is stalled by a collective under `name` in
         `self.comm_log` (a dict the caller installs, e.g. bench.py at N > 1); a no-op otherwise."""
         return _CommTimer(self.comm_log, name, self.queue.device)
+
+    def _check_queue_ptr(self, n: int):
+        """The device-side enqueue (rsp_queue_enqueue_dev) writes a slab only if it fits [ptr, ptr + n) inside the queue; a
+        pointer that is not a multiple of the global batch — a checkpoint saved with another batch size or world size — would
+        silently stop the queue from being refreshed.  The reference's slice assignment (:356) raises there; so does this, once
+        per loaded state (one host read of the pointer)."""
+        ptr = int(self.queue_ptr)
+        if ptr < 0 or ptr >= self.K or ptr % n != 0:
+            raise ValueError(f"queue_ptr = {ptr} is not a multiple of the global batch {n} below K = {self.K}: the queue state "
+                             "was saved with another batch size / world size (reference :353-356 fails on the slab shape here)")
+        self._ptr_checked = True
 
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys_all: Tensor):
@@ -408,6 +451,8 @@ class MoCoDiffLossTwoFc(nn.Module):
         assert self.K % n == 0  # for simplicity (reference :353)
         if self._ptr_on_device:
             # graph-captured steps (rspnet_amd/graph_step.py): the pointer is read and advanced on the device
+            if not self._ptr_checked and not (keys_all.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._check_queue_ptr(n)
             _ops.backend().queue_enqueue_dev(self.queue, self.queue_ptr, keys_all.contiguous())
             self._ptr_host = None
             return
@@ -421,26 +466,29 @@ class MoCoDiffLossTwoFc(nn.Module):
 
     # ---- backward of the query encoder -------------------------------------------------------------------------------
     def _backward_encoder_q(self, ectx, dqA, dqM):
-        """Backward of encoder_q into the flat gradient buffer; with >1 rank, each 32 MiB bucket's all-reduce is
+        """Backward of encoder_q into the flat gradient buffer; with the collectives on, each 32 MiB bucket's all-reduce is
         launched as soon as the layer that completes it has run (RCCL works on its own stream under the rest of the
         backward), then gradients are averaged as DDP does (moco/__init__.py:49-53)."""
         flat = self._flat
-        _, ws = _world()
-        buckets = flat.buckets(BUCKET_FLOATS) if ws > 1 else []
+        _, ws, coll = self._dp()
+        buckets = flat.buckets(BUCKET_FLOATS) if coll else []
         handed_out, launched, handles = set(), set(), []
 
         def grad_of(p):
             handed_out.add(id(p))
             return flat.grad_of(p)
 
-        def after(_node_index):
-            # runs after each plan node: every gradient view handed out so far has been written (same stream)
+        def after(_node_index, join_side_tasks=None):
+            # runs after each plan node: every gradient view handed out so far has been written — on this stream or by a
+            # weight-gradient task the engine put on its side stream (engine.BranchStreams.side_task), which is joined before a
+            # bucket leaves: the collective is ordered behind the stream it is issued from
             for bi, (s, e, ids) in enumerate(buckets):
                 if bi not in launched and all(pid in handed_out for pid in ids):
+                    if join_side_tasks is not None:
+                        join_side_tasks()
                     launched.add(bi)
                     handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
 
-        # (no buckets, no hook: the engine may then put weight gradients on a side stream — a hook would have to see them finished)
         self.encoder_q.backward_ndhwc(ectx, dqA, dqM, grad_of, after if buckets else None)
         for bi, (s, e, ids) in enumerate(buckets):
             if bi not in launched:
@@ -459,10 +507,11 @@ class MoCoDiffLossTwoFc(nn.Module):
         exchange plans derived from them, and their index vectors on the device.  `static` (rspnet_amd/graph_step.py): a
         (pinned staging tensor, device tensor) pair of 4*B*ws int32 the index vectors are written to IN PLACE, so that a step
         captured in a HIP graph reads this step's permutations at replay."""
-        rank, ws = _world()
+        rank, ws, coll = self._dp()
         speed, sh1, sh2 = self._draw_step_randomness(B)
-        plan1, plan2 = self._exchange_plan(sh1, B, rank, ws), self._exchange_plan(sh2, B, rank, ws)
-        arrays = plan1[:2] + plan2[:2]
+        plan1, plan2 = self._exchange_plan(sh1, B, rank, ws, splits=coll), self._exchange_plan(sh2, B, rank, ws, splits=coll)
+        # (src: my clips in send order; rows: where each global sample's features sit in the step's one gathered block)
+        arrays = (plan1[0], self._pair_rows(plan1[1], B, 0), plan2[0], self._pair_rows(plan2[1], B, 1))
         if static is None:
             src1, loc1, src2, loc2 = self._upload_indices(arrays, dev)
         else:
@@ -506,14 +555,14 @@ class MoCoDiffLossTwoFc(nn.Module):
             src1, loc1, src2, loc2 = host["idx"]
             # both shuffle-BN exchanges and the query clips are issued up front (one all-to-all each at > 1 rank: the second
             # one overlaps the first key pass); the key passes keep the reference's order (k_negative first, :445, then k, :512)
-            ex_neg = self._shuffle_exchange(im_k, step_kn, T_real, plan1, src1, loc1)
-            ex_k = self._shuffle_exchange(im_k, step_q, T_real, plan2, src2, loc2)
+            ex_neg = self._shuffle_exchange(im_k, step_kn, T_real, plan1, src1)
+            ex_k = self._shuffle_exchange(im_k, step_q, T_real, plan2, src2)
             src = torch.arange(B, dtype=torch.int32, device=dev)
             x_q = be.clip_gather(im_q, src, step_q, T_real, max(C, INPUT_CHANNEL_PAD))
             self._nbt_q += 1
             # The query encoder's forward does not depend on the key passes (other weights, other BatchNorm buffers) before the
-            # logits.  Inside a captured HIP graph (rspnet_amd/graph_step.py) it is forked onto its own stream and runs beside them:
-            # the small late layers of either pass leave most of the machine idle on their own.
+            # logits: it is forked onto its own stream and runs beside them — the small late layers of either pass leave most of
+            # the machine idle on their own.  (Captured into a HIP graph, rspnet_amd/graph_step.py, or issued eagerly; any world size.)
             side = None
             if self.overlap_query and dev.type == "cuda" and (torch.cuda.is_current_stream_capturing() or self.overlap_query_eager):
                 main = torch.cuda.current_stream(dev)
@@ -522,26 +571,29 @@ class MoCoDiffLossTwoFc(nn.Module):
                 with torch.cuda.stream(side):
                     self._q_pre = self.encoder_q.forward_ndhwc(x_q, keep=True)
             # The two key passes (k_negative first, :445; then k, :512) go through the same encoder_k.  The second one defers its
-            # running-statistics update (_deferred_k), so under capture it is forked onto its own stream beside the first (and
-            # beside the query forward); the deferred update is applied after both, in the reference's order.
+            # running-statistics update (_deferred_k), so it is forked onto its own stream beside the first (and beside the query
+            # forward); the deferred update is applied after both, in the reference's order.  Neither pass holds a collective of
+            # its own beyond the wait for its clips: the features of both travel in one all-gather after the join.
             deferred = self._deferred_k()
             self._nbt_k += 2
             self.encoder_k._packed.refresh_now()      # (re-pack of the momentum-updated weights: before the passes fork)
             side_k = None
-            # (eagerly only at one rank: with more, the key passes carry the feature all-gathers, which stay on the main stream)
-            if side is not None and self.overlap_keys and (torch.cuda.is_current_stream_capturing() or _world()[1] == 1):
+            if side is not None and self.overlap_keys:
                 main = torch.cuda.current_stream(dev)
                 side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
                 side_k.wait_stream(main)
                 with torch.cuda.stream(side_k):
-                    k_mine, _, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
-            kneg_mine, kneg_all, dim = self._key_pass(ex_neg, "kneg", bump=False)
+                    feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
+            feats_neg, dim = self._key_pass(ex_neg, "kneg", bump=False)
             if side_k is None:
-                k_mine, _, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
+                feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
             else:
                 torch.cuda.current_stream(dev).wait_stream(side_k)
             self._ema_k.run()
             del ex_neg, ex_k
+            rank = self._dp()[0]
+            kneg_all, k_all = self._gather_keys(feats_neg, feats_k, loc1, loc2)
+            k_mine, kneg_mine = k_all[rank * B:(rank + 1) * B], kneg_all[rank * B:(rank + 1) * B]
             k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
             kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
             if side is not None:

@@ -205,7 +205,7 @@ class MultiTaskWrapper(nn.Module):
             if dfeat is None:
                 dfeat = be.spatial_mean_bwd(dpooled_feat, ctx.feat_shape)
         if after_param_grads is not None:
-            after_param_grads(-1)
+            after_param_grads(-1, None)
         run_backward(self.plan(), ctx, dfeat, grad_of, after_param_grads)
 
     def _to_ndhwc(self, x: Tensor) -> Tensor:

@@ -158,7 +158,7 @@ class Engine:
         sums = torch.zeros(4, device=self.device)
         n = 0
         t0 = time.perf_counter()
-        if self._stepper is None and self.args.world_size <= 1 and not getattr(self.args, "no_graph", False):
+        if self._stepper is None and not self.model.module._dp()[2] and not getattr(self.args, "no_graph", False):
             # one rank: the five statements below run as ONE replayed HIP graph per (speed, learning rate) — rspnet_amd/graph_step.py
             from .graph_step import GraphedPretextStep
             self._stepper = GraphedPretextStep(self.model, self.criterion, self.optimizer)
@@ -290,9 +290,10 @@ def main_worker(local_rank: int, args, dist_url: str):
     np.random.seed(seed)
     torch.manual_seed(seed)
     torch.cuda.set_device(local_rank)
-    if args.world_size > 1:
-        dist.init_process_group("nccl", init_method=dist_url, rank=local_rank, world_size=args.world_size,
-                                device_id=torch.device("cuda", local_rank))
+    forced = args.world_size <= 1 and bool(os.environ.get("RSP_FORCE_COLLECTIVES"))      # one rank, RCCL path on (see MoCoDiffLossTwoFc)
+    if args.world_size > 1 or forced:
+        dist.init_process_group("nccl", init_method=dist_url or f"tcp://127.0.0.1:{_free_port()}", rank=local_rank,
+                                world_size=max(args.world_size, 1), device_id=torch.device("cuda", local_rank))
     with open(args.config) as f:
         cfg = json.load(f)
     for snippet in args.ext_config or []:                           # -x overlays: JSON objects merged on top
@@ -307,7 +308,7 @@ def main_worker(local_rank: int, args, dist_url: str):
     if args.load_checkpoint is not None:
         engine.load_checkpoint(args.load_checkpoint)
     stats = engine.run()
-    if args.world_size > 1:
+    if args.world_size > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
     return stats
@@ -349,15 +350,36 @@ def parse_args(argv=None):
 
 
 def visible_gpu_count() -> int:
-    """Number of GPUs this launcher would spawn ranks for (the reference asks torch.cuda.device_count(), pretrain.py:318), found
-    WITHOUT touching the HIP runtime in the parent: ranks are fresh child processes and the launcher itself must stay GPU-free
-    (a process that has initialised the GPU must never be re-exec'ed or forked on this platform).  Honours
-    HIP_/ROCR_/CUDA_VISIBLE_DEVICES; otherwise counts the KFD topology nodes that are GPUs (simd_count > 0)."""
+    """Number of GPUs this launcher spawns ranks for — what the reference asks torch.cuda.device_count() for (pretrain.py:318) —
+    found WITHOUT touching the HIP runtime in the parent: ranks are fresh child processes and the launcher itself must stay
+    GPU-free (a process that has initialised the GPU must never be re-exec'ed or forked on this platform).  A short-lived CHILD
+    interpreter is asked for torch.cuda.device_count(): it sees exactly what a rank will see (HIP_/ROCR_/CUDA_VISIBLE_DEVICES,
+    container device filtering).  Only if that child cannot be run, the count falls back to the KFD topology intersected with the
+    *_VISIBLE_DEVICES lists.  Raises when no GPU is visible."""
+    import subprocess
+    n = None
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                           timeout=300)
+        if r.returncode == 0:
+            n = int(r.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        n = None
+    if n is None:
+        n = _kfd_gpu_count()
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):      # each list filters the previous one
+            v = os.environ.get(var)
+            if v is not None:
+                n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    if n <= 0:
+        raise EnvironmentError("rspnet_amd.pretrain: no GPU is visible to this process (check HIP_VISIBLE_DEVICES / "
+                               "ROCR_VISIBLE_DEVICES and the container's /dev/kfd, /dev/dri access); pass --ws to override")
+    return n
+
+
+def _kfd_gpu_count() -> int:
+    """GPUs in the KFD topology (nodes with simd_count > 0)."""
     import glob
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            return len([t for t in v.split(",") if t.strip() != ""])
     n = 0
     for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
         try:

@@ -28,10 +28,10 @@ def test_bench_self_launches_two_ranks():
     assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "selftest-cpu"
     assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
     assert "cpu_baseline" not in d                     # rank 0 at N=1 only
-    # the N > 1 line explains itself: per-step stall of rank 0 behind each collective (both clip exchanges, the key all-gathers
+    # the N > 1 line explains itself: per-step stall of rank 0 behind each collective (both clip exchanges, the one key all-gather
     # and the wait for the bucketed gradient all-reduce), and the per-step distribution is absent only because this is the CPU
     cm = d["comm_ms"]
-    assert {"all_to_all_kneg", "all_to_all_k", "all_gather_kneg", "all_gather_k", "allreduce_wait"} <= set(cm)
+    assert {"all_to_all_kneg", "all_to_all_k", "all_gather_keys", "allreduce_wait"} <= set(cm)
     assert all(v >= 0 for v in cm.values())
 
 

@@ -167,3 +167,18 @@ def test_four_rank_step_matches_oracle():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker_vs_oracle, args=(4, "c3d", 2, 16, 64, 3, _free_port(), tmp), nprocs=4, join=True)
         assert all(os.path.exists(os.path.join(tmp, f"ok{r}.npy")) for r in range(4))
+
+
+def test_one_rank_with_forced_collectives_matches_golden():
+    """force_collectives in a gloo world of ONE rank: every collective of the data-parallel step is issued (counted by the worker)
+    and the result is the 1-rank fixture's — the CPU twin of tests/test_rccl_gpu.py's RCCL run."""
+    import json
+    from forced_dp_util import forced_worker
+    from oracle.ref_harness import _free_port
+    arch, _, seed = cases_for("c3d", 1)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "ok.json")
+        mp.spawn(forced_worker, args=("gloo", arch, seed, _free_port(), out), nprocs=1, join=True)
+        with open(out) as f:
+            rep = json.load(f)
+    assert rep["calls"]["all_to_all_single"] == 2 and rep["calls"]["all_gather_into_tensor"] == 1

@@ -1,4 +1,8 @@
-"""GPU, needs >= 2 devices (skipped on the 1-GPU test box): the 2-rank DDP fixtures through REAL RCCL — one process per GPU,
+"""GPU.  (1) ONE device: the real `nccl` backend (RCCL) in a world of one rank with `force_collectives` — every collective of the
+data-parallel step executes on the 1-GPU box (clip all-to-all with split lists, fused key all-gather, bucketed gradient all-reduce
+from inside backward with the weight-gradient side tasks joined in front of it, the gloo side group created next to the RCCL group)
+and the step still matches the 1-rank fixture; eagerly and, with RSP_GRAPH_COLLECTIVES=1, as a captured HIP graph.
+(2) >= 2 devices (skipped on the 1-GPU test box): the 2-rank DDP fixtures through REAL RCCL — one process per GPU,
 `nccl` backend, the product's clip all-to-all (uneven splits), fused key all-gather, bucketed gradient all-reduce launched
 from inside backward and the gloo side group next to the RCCL group — compared with the reference-under-DDP goldens exactly as
 tests/test_distributed_cpu.py does over gloo with the checker backend and tests/test_two_rank_gpu.py does with the HIP kernels
@@ -51,3 +55,20 @@ def test_two_ranks_over_rccl_match_the_ddp_fixture(arch, seed):
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, arch, seed, _free_port(), tmp), nprocs=2, join=True)
         assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
+
+
+@pytest.mark.parametrize("arch", ["c3d", "s3dg"])
+def test_rccl_one_rank_forced_collectives_match_the_fixture(arch):
+    """RCCL itself, on the one GPU the box has: see forced_dp_util.forced_worker."""
+    import json
+    from forced_dp_util import forced_worker
+    from oracle.ref_harness import _free_port
+    a, _, seed = cases_for(arch, 1)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "ok.json")
+        mp.spawn(forced_worker, args=("nccl", a, seed, _free_port(), out), nprocs=1, join=True)
+        with open(out) as f:
+            rep = json.load(f)
+    print("\n", arch, rep)
+    assert rep["side_group"] == "gloo"
+    assert rep["calls"]["all_to_all_single"] == 2 and rep["calls"]["all_gather_into_tensor"] == 1 and rep["calls"]["all_reduce"] >= 2
