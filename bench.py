@@ -187,6 +187,22 @@ def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
         first = None
     moms = [{}]
     times = []
+    g64 = None
+    if first is not None:
+        # the same replay in fp64 first (on a copy of the pre-step state): the whole gradient has a conditioning floor — ReLU / max-pool
+        # decisions flip under fp32 rounding — that is a property of the STATE, not of the kernels; it is measured here as the distance
+        # of the oracle's own fp32 gradient from its fp64 gradient, and the GPU's gradient is held against the same fp64 gradient
+        t64 = time.perf_counter()
+        torch.set_default_dtype(torch.float64)
+        try:
+            st64 = {k: (v.clone().double() if v.dtype == torch.float32 else v.clone()) for k, v in state.items()}
+            o64 = S.moco_step(arch, [st64], [im_q.double()], [im_k.double()], [first[0]], first[1], first[2], K=K, lr=lr,
+                              momentum_buffers=[{}])[0]
+            g64 = {k: v.detach().clone() for k, v in o64["grads"].items() if v is not None}
+            del st64, o64
+        finally:
+            torch.set_default_dtype(torch.float32)
+        t64 = time.perf_counter() - t64
     for it in range(1 + steps):                      # step 0 = warm-up (allocator, oneDNN primitive caches)
         if it == 0 and first is not None:
             perm, sh, speed = first
@@ -204,11 +220,17 @@ def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
                 a, b = a.double(), b.double()
                 return float((a - b).abs().max() / b.abs().max().clamp_min(1e-5))
 
-            num = den = 0.0
-            for k, gr in o["grads"].items():
-                if gr is not None:
-                    d = (parity["grads"][k].double() - gr.double())
-                    num, den = num + float((d * d).sum()), den + float((gr.double() ** 2).sum())
+            def whole_l2(ga, gb):      # relative L2 distance of two whole gradients (one vector over all tensors)
+                num = den = 0.0
+                for k, gr in gb.items():
+                    if gr is not None and ga.get(k) is not None:
+                        dd = ga[k].double() - gr.double()
+                        num, den = num + float((dd * dd).sum()), den + float((gr.double() ** 2).sum())
+                return (num / den) ** 0.5 if den > 0 else None
+
+            grad_vs_oracle = whole_l2(parity["grads"], o["grads"])
+            floor = whole_l2(o["grads"], g64) if g64 is not None else None
+            grad_vs_fp64 = whole_l2(parity["grads"], g64) if g64 is not None else None
             ptr0 = parity["ptr0"]
             par = {"vs": "oracle/restatement.py:moco_step (pinned to the reference) replaying the GPU run's first step: same "
                          "pre-step state, clips, diff-speed and shuffle permutations",
@@ -218,11 +240,17 @@ def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
                    "ranking_logits_rel": max(rel(got["l_pos_M"], o["l_pos_M"]), rel(got["l_neg_M"], o["l_neg_M"])),
                    "features_rel": max(rel(got["q_A"], o["q_A"]), rel(got["q_M"], o["q_M"])),
                    "queue_slab_rel": rel(got["queue_slab"], state["queue"][:, ptr0:ptr0 + sample_b]),
-                   "grad_rel_l2": (num / den) ** 0.5 if den > 0 else None,
+                   "grad_rel_l2": grad_vs_oracle,
+                   # conditioning floor of this state: oracle fp32 vs oracle fp64; the GPU gradient against the same fp64 gradient
+                   "grad_floor_rel_l2": floor, "grad_vs_fp64_rel_l2": grad_vs_fp64,
+                   "grad_gate": "grad_vs_fp64_rel_l2 <= 2 x grad_floor_rel_l2 + 1e-4 (as close to the fp64 gradient as the reference's own "
+                                "fp32 arithmetic, within a factor 2)", "fp64_replay_s": round(t64, 1) if g64 is not None else None,
                    "loss_gpu": float(got["loss"]), "loss_oracle": float(o["loss"]), "tolerance": 1e-3}
             par = {k: (float(f"{v:.3e}") if isinstance(v, float) and k.endswith(("_rel", "_l2")) else v) for k, v in par.items()}
-            par["ok"] = bool(all(par[k] <= 1e-3 for k in ("loss_rel", "loss_A_rel", "loss_M_rel", "logits_rel",
-                                                          "ranking_logits_rel", "features_rel", "queue_slab_rel")))
+            par["forward_ok"] = bool(all(par[k] <= 1e-3 for k in ("loss_rel", "loss_A_rel", "loss_M_rel", "logits_rel",
+                                                                  "ranking_logits_rel", "features_rel", "queue_slab_rel")))
+            par["grad_ok"] = bool(floor is not None and grad_vs_fp64 is not None and grad_vs_fp64 <= 2.0 * floor + 1e-4)
+            par["ok"] = par["forward_ok"] and par["grad_ok"]
     timed = times[1:] or times
     dt = sum(timed) / len(timed)
     res = {"value": round(sample_b / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": model,
@@ -238,16 +266,17 @@ def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
 # one rank
 # ----------------------------------------------------------------------------------------------------------------------
 def load_traffic(arch, B, kernel):
-    """Measured L2-miss bytes per launch of `kernel` (PMC passes, profiles/traffic.json), GB, or None."""
+    """(L2-miss GB per launch, matrix-pipe busy share, source file) of `kernel` from the committed PMC passes
+    (profiles/traffic.json, written by tools/summarize_profiles.py) — STATIC: counters cannot be collected inside a bench run."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
-        return None, None
+        return None, None, None
     with open(tpath) as f:
         t = json.load(f)
     ent = t.get(f"{arch}_b{B}", {}).get(kernel)
     if ent is None:
-        return None, None
-    return round(ent["hbm_bytes_per_launch"] / 1e9, 4), ent.get("source")
+        return None, None, None
+    return round(ent["hbm_bytes_per_launch"] / 1e9, 4), ent.get("mfma_busy"), ent.get("source")
 
 
 def _pct(xs, q):
@@ -337,7 +366,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     #  passes on side streams, where a launch's interval also holds its neighbours' time — see the roofline pass below)
     if coll and not graphed:
         inner.comm_log = {}
-    marks, host = [], []
+    marks, host, hbm = [], [], []
     if cuda:
         marks.append(torch.cuda.Event(enable_timing=True))
         marks[0].record()
@@ -385,11 +414,12 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         try:
             eager_step()
             fence()
-            be.event_log = []
+            be.event_log, be.hbm_log = [], []
             for _ in range(roof_steps):
                 eager_step()
             fence()
             log, be.event_log = be.event_log, None
+            hbm, be.hbm_log = be.hbm_log, None
         finally:
             inner.overlap_query_eager, BranchStreams.EAGER_TASKS = saved
     if marks:
@@ -408,28 +438,38 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         res["comm_ms"] = cm
     if log:
         per_kernel, per_kind = {}, {}
-        for kind, f, e0, e1, kernel, nbytes, _geom in log:
+        for kind, f, e0, e1, kernel, nbytes, _geom, fx in log:
             ms = e0.elapsed_time(e1)
             for table, key in ((per_kernel, kernel), (per_kind, kind)):
-                a = table.setdefault(key, [0.0, 0.0, 0, 0.0])
+                a = table.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0])
                 a[0] += f
                 a[1] += ms
                 a[2] += 1
                 a[3] += nbytes
+                a[4] += fx
         flops = sum(v[0] for v in per_kernel.values())
         ms = sum(v[1] for v in per_kernel.values())
         all_tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # dominant kernel of THIS backbone = the template instance with the largest share of the timed step.  Each timed
         # group also holds the small helpers launched with it (split-K reduce, dgrad weight re-pack, wgrad slab reduce).
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
-        dflops, dms, dn, dbytes = per_kernel[dom]
+        dflops, dms, dn, dbytes, dexec = per_kernel[dom]
         achieved = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-        traffic, traffic_src = load_traffic(arch, B, dom)
+        executed = dexec / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        fx_all = sum(v[4] for v in per_kernel.values())
+        traffic, busy, traffic_src = load_traffic(arch, B, dom)
         alg_gb = dbytes / max(dn, 1) / 1e9
         whole = flops / roof_steps / (step_ms * 1e-3) / 1e12
         res["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            # what the matrix pipe is asked to do: the same launches priced with the multiply-adds the kernels EXECUTE (the K / row
+            # chunks that are zero padding for a whole tile are skipped: rsp_conv3d_executed_fraction, the kernels' own planning code)
+            "executed_achieved": round(executed, 2), "executed_frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+            "executed_over_algorithmic": round(dexec / dflops, 4) if dflops > 0 else None,
+            "mfma_busy": busy, "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of this kernel in the committed "
+                                                 "PMC pass (static, see traffic_source)",
+            "traffic": traffic, "traffic_static": True,
             "traffic_unit": "GB of L2-miss (fabric) traffic per launch: PMC FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache "
                             "hits (MI355X_MICROARCH.md), so an upper bound of the HBM bytes",
             "flop_count": "algorithmic: 2 x MACs of the convolution INCLUDING the taps that fall into the zero padding (SURVEY.md 8d); "
@@ -442,15 +482,36 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
             "share_of_step": round(dms / roof_steps / step_ms, 4),
             "algorithmic_gflop_per_launch": round(dflops / max(dn, 1) / 1e9, 2),
             "whole_step": {"algorithmic_conv_gflop_per_clip": round(flops / roof_steps / B / 1e9, 2),
-                           "achieved": round(whole, 2), "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4)},
+                           "achieved": round(whole, 2), "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4),
+                           "executed_frac": round(whole * (fx_all / flops) / PEAK_F32_MFMA_TFLOPS, 4) if flops > 0 else None},
             "all_conv_launches": {"achieved": round(all_tf, 2), "frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "executed_frac": round(all_tf * (fx_all / flops) / PEAK_F32_MFMA_TFLOPS, 4) if flops > 0 else None,
                                   "ms_per_step": round(ms / roof_steps, 3), "launches": len(log)},
-            "per_kernel": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms_per_step": round(v[1] / roof_steps, 3),
+            "per_kernel": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "executed_tflops": round(v[4] / (v[1] * 1e-3) / 1e12, 2),
+                               "ms_per_step": round(v[1] / roof_steps, 3),
                                "launches_per_step": round(v[2] / roof_steps, 2),
                                "avg_launch_ms": round(v[1] / v[2], 4)}
                            for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "per_kind_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 2) for k, v in per_kind.items()},
             "per_kind_ms_per_step": {k: round(v[1] / roof_steps, 3) for k, v in per_kind.items()}}
+    if hbm:
+        # the streaming kernels of the step against the HBM roofline: algorithmic bytes (every operand tensor moved once) / HIP-event
+        # time of the launch group, from the same one-stream pass as the matrix kernels
+        PEAK_HBM_TBS = 8.0
+        groups = {}
+        for kind, nbytes, e0, e1 in hbm:
+            a = groups.setdefault(kind, [0, 0.0, 0])
+            a[0] += nbytes
+            a[1] += e0.elapsed_time(e1)
+            a[2] += 1
+        res["hbm_kernels"] = {
+            "peak_tb_s": PEAK_HBM_TBS, "bound": "hbm",
+            "note": "algorithmic bytes / HIP-event time per launch group in the one-stream roofline pass; small launches are latency-, "
+                    "not bandwidth-bound, and tensors a producer just wrote may come from the Infinity Cache",
+            "groups": {k: {"tb_s": round(v[0] / (v[1] * 1e-3) / 1e12, 3), "frac": round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
+                           "ms_per_step": round(v[1] / roof_steps, 3), "launches_per_step": round(v[2] / roof_steps, 1),
+                           "gb_per_step": round(v[0] / roof_steps / 1e9, 3)}
+                       for k, v in sorted(groups.items(), key=lambda kv: -kv[1][1]) if v[1] > 0}}
     gc.unfreeze()
     # let the next workload start from an empty device
     del model, opt, im_q, im_k, inner
@@ -532,7 +593,7 @@ def run_rank(args):
             res["issued_eagerly"] = {"ms_per_step": round(m["eager_ms_per_step"], 3),
                                      "clips_per_s": round(ws * B / m["eager_ms_per_step"] * 1e3, 2), "steps": args.eager_steps,
                                      "note": "same step, eager launches with the same side streams: how N > 1 ranks issue it"}
-        for k in ("steps_ms", "comm_ms", "roofline", "graph_fallback"):
+        for k in ("steps_ms", "comm_ms", "roofline", "hbm_kernels", "graph_fallback"):
             if k in m:
                 res[k] = m[k]
     # BASELINE.json configs 3-5 on the same box (N=1, default run only): the other three backbones at their own batch / clip

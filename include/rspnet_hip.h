@@ -114,6 +114,13 @@ int rsp_conv3d_wgrad_v(const rsp_conv3d_desc* d, const float* x, const float* dy
  * backbone and match it to the rocprofv3 kernel-trace row.  Static string, never NULL. */
 const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which);
 
+/* Share (0..1] of the convolution's algorithmic multiply-adds — 2*MACs counted with the taps that read the zero padding, as
+ * cuDNN / oneDNN under the reference's nn.Conv3d count them (models/c3d.py:21-52) — that the launched kernels actually execute:
+ * the implicit-GEMM walks skip K chunks (forward / dgrad) and row chunks (wgrad) that are padding for a whole tile.  Host
+ * arithmetic only (the kernels' own planning code), no GPU.  which: 0 forward, 1 dgrad, 2 wgrad (frame-granular estimate).
+ * bench.py prices roofline.executed_frac with it next to the algorithmic rate. */
+double rsp_conv3d_executed_fraction(const rsp_conv3d_desc* d, int which);
+
 /* Host evaluation of the constant division the conv kernels use to decode GEMM rows and k positions (multiply-high by a
  * host-computed magic number + shift, exact for 0 <= n < 2^31): returns n / d computed that way.  No GPU needed; exists so
  * the CPU test suite can check the derivation over the full range. */

@@ -15,6 +15,7 @@
 // against 8 x 16-B global loads per thread: staging hides completely behind the matrix pipe; tap re-reads of the
 // input are served by L2 (27 x re-read of conv2's 411 MB input = 1.6 TB/s of L2 traffic, L2 peak 34 TB/s).
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 #include "conv_stem.h"
 
@@ -54,7 +55,16 @@ __host__ __device__ inline int k_index(bool slice_major, int tap, int c, int C, 
   return slice_major ? (c >> 5) * (ntaps * 32) + tap * 32 + (c & 31) : tap * C + c;
 }
 
+#ifdef RSP_PHASE_PROBE
+unsigned long long* g_phase_dbg = nullptr;     // tools/phase_probe.py: per-workgroup phase timestamps
+#define PHASE_MARK(i) if (p.dbg) { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) p.dbg[((long long)bid * 4 + (threadIdx.x >> 6)) * 8 + i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PHASE_MARK(i)
+#endif
 struct IgemmParams {
+#ifdef RSP_PHASE_PROBE
+  unsigned long long* dbg;
+#endif
   const float* __restrict__ x;
   const float* __restrict__ w;     // packed [Cout][Kld]
   const float* __restrict__ bias;  // nullable
@@ -152,6 +162,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nTd * p.nTh * p.nTw + 1);  // [BM]
 
   const int t = threadIdx.x;
+  PHASE_MARK(0)
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) become SALU arithmetic
   const int l32 = lane & 31, h = lane >> 5;
@@ -518,6 +529,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     store_chunk(0);
   }
   __syncthreads();   // (with DMA in flight hipcc emits s_waitcnt vmcnt(0) before the barrier: the tile has landed)
+  PHASE_MARK(1)
 
   int buf = 0;
   for (int kc = kc_begin; (KS || tms) ? have : kc < kc_end; ++kc) {
@@ -594,6 +606,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     buf = nbuf == 1 ? 0 : buf ^ 1;
   }
 
+  PHASE_MARK(2)
   // ---- epilogue -------------------------------------------------------------------------------------------
   // GEMM row -> output address.  Forward outputs, stride-1 input gradients and the K-split partials are LINEAR in the row
   // (address = base + row * pitch): plain arithmetic.  The strided parity classes of dgrad go through a per-tile table
@@ -688,6 +701,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     else store_tile(std::true_type{}, std::false_type{});
   }
 
+  PHASE_MARK(3)
   if (p.stat && !is_partial) {
     // per-channel (sum, sumsq) of the bias-free conv output per 128-row block; rows >= M contributed zeros.
     constexpr int SB = BM / 128;             // stat blocks per tile
@@ -729,10 +743,23 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       }
     }
   }
+#ifdef RSP_PHASE_PROBE
+  PHASE_MARK(4)
+  if (p.dbg && (t & 63) == 0) {
+    unsigned long long* o = p.dbg + ((long long)bid * 4 + wave) * 8;
+    o[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    o[6] = wall_clock64();
+    o[7] = (unsigned long long)tile | ((unsigned long long)(kc_end - kc_begin) << 32);
+  }
+#endif
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
+#ifdef RSP_PHASE_PROBE
+__global__ __launch_bounds__(256, (BN <= 128 && VEC == 4) ? 3 : MINW) void igemm_kernel(const IgemmParams p) {
+#else
 __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
+#endif
   igemm_body<BM, BN, WAVES_M, WAVES_N, VEC>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // the same tile with the channel-slice-major K walk (LDS-DMA path)
@@ -1235,6 +1262,9 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
     return RSP_ELAUNCH;
   }
   p.zero = zero_page;
+#ifdef RSP_PHASE_PROBE
+  p.dbg = g_phase_dbg;
+#endif
 #ifdef RSP_TUNE
   {
     const char* e = getenv("RSP_TUNE");
@@ -1382,14 +1412,128 @@ DgradClass dgrad_class(const rsp_conv3d_desc* d, int c) {
   return g;
 }
 
+// Host replica of the kernels' walk over K: the share of a problem's (tile, chunk) pairs that igemm_body executes once the chunks
+// whose taps are padding for a whole tile are skipped (1.0 when nothing is skipped).  Same row enumeration (row_decode), same
+// validity bits (span), same liveness tests as the device code; the column segments of one GEMM share the rows, hence the share.
+double igemm_live_fraction(IgemmParams p, bool vec4) {
+  p.nchunks = rsp_cdiv(p.K, BK);
+  fill_fastdiv(p);
+  if (!vec4) return 1.0;
+  const bool KS = p.kmajor != 0;
+  const bool tms = !KS && p.tm_skip;
+  if (!(KS && p.skip_pad) && !tms) return 1.0;
+  auto span = [&](int base, int D, int nT) -> unsigned {
+    const int c = p.offstep > 0 ? base : D - 1 - base;
+    const int lo = std::min(std::max(0, -c), 8), hi = std::min(nT - 1, D - 1 - c);
+    return hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+  };
+  const int ntaps = p.nTd * p.nTh * p.nTw, m_tiles = rsp_cdiv(p.M, 128);
+  long long live = 0;
+  for (int mt = 0; mt < m_tiles; ++mt) {
+    unsigned tmask = 0;
+    for (int r = mt * 128; r < std::min(p.M, mt * 128 + 128); ++r) {
+      const int gw = r % p.Gw, q1 = r / p.Gw, gh = q1 % p.Gh, q2 = q1 / p.Gh;
+      int gd;
+      if (p.dmajor) {
+        const int rem = q2 % (p.Gd * p.Np), g = rem / p.Np;
+        gd = g + 1 == p.Gd ? 0 : g + 1;
+      } else {
+        gd = q2 % p.Gd;
+      }
+      tmask |= span(gd * p.sD + p.off0d, p.Di, p.nTd) | (span(gh * p.sH + p.off0h, p.Hi, p.nTh) << 8) |
+               (span(gw * p.sW + p.off0w, p.Wi, p.nTw) << 16);
+    }
+    if (KS || p.cpt > 0) {
+      int live_taps = 0;
+      for (int ad = 0; ad < p.nTd; ++ad)
+        for (int ah = 0; ah < p.nTh; ++ah)
+          for (int aw = 0; aw < p.nTw; ++aw) {
+            const unsigned need = (1u << ad) | (1u << (8 + ah)) | (1u << (16 + aw));
+            live_taps += (tmask & need) == need ? 1 : 0;
+          }
+      live += (long long)live_taps * (p.Cin / BK);
+    } else {
+      for (int kc = 0; kc < p.nchunks; ++kc) {
+        const int t0 = kc * BK / p.Cin, t1 = std::min((kc * BK + BK - 1) / p.Cin, ntaps - 1);
+        const unsigned sp = (2u << (t1 / (p.nTh * p.nTw))) - (1u << (t0 / (p.nTh * p.nTw)));
+        live += (tmask & sp) != 0 ? 1 : 0;
+      }
+    }
+  }
+  return (double)live / ((double)m_tiles * p.nchunks);
+}
+
 size_t dgrad_wpack_bytes(const rsp_conv3d_desc* d) {
   const int nclass = d->sT * d->sH * d->sW;
   return rsp_align_up(((size_t)d->kT * d->kH * d->kW * d->Cout + 4 * (size_t)nclass) * d->Cin * sizeof(float), 256);
 }
 
+// The GEMM description of a forward convolution; returns whether the LDS-DMA kernels apply (16-byte rows, 32-bit offsets).
+static bool fill_fwd_params(const rsp_conv3d_desc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                            float* stat_partials, IgemmParams& p) {
+  memset(&p, 0, sizeof p);
+  p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.stat = stat_partials;
+  p.M = d->N * d->Do * d->Ho * d->Wo;
+  p.Nb = d->N;
+  p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
+  p.oDm = d->Do; p.oHm = d->Ho; p.oWm = d->Wo;
+  p.oSd = p.oSh = p.oSw = 1;
+  p.oOd = p.oOh = p.oOw = 0;
+  p.out_ld = d->out_ld; p.Cout = d->Cout;
+  p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.in_ld = d->in_ld; p.Cin = d->Cin;
+  p.sD = d->sT; p.sH = d->sH; p.sW = d->sW;
+  p.nTd = d->kT; p.nTh = d->kH; p.nTw = d->kW;
+  p.off0d = -d->pT; p.off0h = -d->pH; p.off0w = -d->pW;
+  p.offstep = 1;
+  p.K = d->kT * d->kH * d->kW * d->Cin;
+  p.Kld = (int)rsp_align_up((size_t)p.K, 4);
+  const unsigned long long xb = (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
+  const unsigned long long wb = (unsigned long long)d->Cout * p.Kld * 4ull;
+  p.x_bytes = (unsigned)xb;
+  p.w_bytes = (unsigned)wb;
+  // the LDS-DMA path addresses with 32-bit byte offsets; bigger tensors take the (slower) scalar-gather path
+  return (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x) && xb < (1ull << 32) && wb < (1ull << 32) &&
+                    d->kT <= 8 && d->kH <= 8 && d->kW <= 8;   // per-dimension validity bits of the DMA path
+}
+
+// ... and of one stride-parity class of its input gradient (w: this class's packed weights).
+static bool fill_dgrad_class_params(const rsp_conv3d_desc* d, const DgradClass& g, const float* dy, const float* w, float* dx,
+                                    IgemmParams& p) {
+  const int Kld = (int)rsp_align_up((size_t)g.nt * g.nh * g.nw * d->Cout, 4);
+    memset(&p, 0, sizeof p);
+    p.x = dy; p.w = w; p.bias = nullptr; p.y = dx; p.stat = nullptr;
+    p.M = d->N * g.Gd * g.Gh * g.Gw;
+    p.Nb = d->N;
+    p.Gd = g.Gd; p.Gh = g.Gh; p.Gw = g.Gw;
+    p.oDm = d->Di; p.oHm = d->Hi; p.oWm = d->Wi;
+    p.oSd = d->sT; p.oSh = d->sH; p.oSw = d->sW;
+    p.oOd = g.rt; p.oOh = g.rh; p.oOw = g.rw;
+    p.out_ld = d->in_ld; p.Cout = d->Cin;
+    p.Di = d->Do; p.Hi = d->Ho; p.Wi = d->Wo; p.in_ld = d->out_ld; p.Cin = d->Cout;
+    p.sD = p.sH = p.sW = 1;
+    p.nTd = g.nt; p.nTh = g.nh; p.nTw = g.nw;
+    // tap a (kernel index k = k0 + a*s) reads dy at  g + (r + p - k)/s  =  g + off0 - a
+    p.off0d = (g.rt + d->pT - g.k0t) / d->sT;
+    p.off0h = (g.rh + d->pH - g.k0h) / d->sH;
+    p.off0w = (g.rw + d->pW - g.k0w) / d->sW;
+    p.offstep = -1;
+    p.K = g.nt * g.nh * g.nw * d->Cout;
+    p.Kld = Kld;
+    const unsigned long long xb = (unsigned long long)d->N * d->Do * d->Ho * d->Wo * d->out_ld * 4ull;
+    const unsigned long long wb = (unsigned long long)d->Cin * Kld * 4ull;
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+    return (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && rsp_aligned16(p.w) && xb < (1ull << 32) &&
+                 wb < (1ull << 32) && g.nt <= 8 && g.nh <= 8 && g.nw <= 8;
+}
+
 }  // namespace
 
 extern "C" {
+
+#ifdef RSP_PHASE_PROBE
+void rsp_phase_probe_set(unsigned long long* dbg) { g_phase_dbg = dbg; }
+#endif
 
 size_t rsp_conv3d_packed_fwd_elems(const rsp_conv3d_desc* d) {
   if (!desc_ok(d)) return 0;
@@ -1436,30 +1580,33 @@ int rsp_conv3d_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_pack
   rsp_note_reset();
   if (rsp_stem_applicable(d)) return rsp_stem_fwd(d, x, w_packed, bias, y, stat_partials, (hipStream_t)stream);
   IgemmParams p;
-  memset(&p, 0, sizeof p);
-  p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.stat = stat_partials;
-  p.M = d->N * d->Do * d->Ho * d->Wo;
-  p.Nb = d->N;
-  p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
-  p.oDm = d->Do; p.oHm = d->Ho; p.oWm = d->Wo;
-  p.oSd = p.oSh = p.oSw = 1;
-  p.oOd = p.oOh = p.oOw = 0;
-  p.out_ld = d->out_ld; p.Cout = d->Cout;
-  p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.in_ld = d->in_ld; p.Cin = d->Cin;
-  p.sD = d->sT; p.sH = d->sH; p.sW = d->sW;
-  p.nTd = d->kT; p.nTh = d->kH; p.nTw = d->kW;
-  p.off0d = -d->pT; p.off0h = -d->pH; p.off0w = -d->pW;
-  p.offstep = 1;
-  p.K = d->kT * d->kH * d->kW * d->Cin;
-  p.Kld = (int)rsp_align_up((size_t)p.K, 4);
-  const unsigned long long xb = (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
-  const unsigned long long wb = (unsigned long long)d->Cout * p.Kld * 4ull;
-  p.x_bytes = (unsigned)xb;
-  p.w_bytes = (unsigned)wb;
-  // the LDS-DMA path addresses with 32-bit byte offsets; bigger tensors take the (slower) scalar-gather path
-  const bool vec4 = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x) && xb < (1ull << 32) && wb < (1ull << 32) &&
-                    d->kT <= 8 && d->kH <= 8 && d->kW <= 8;   // per-dimension validity bits of the DMA path
+  const bool vec4 = fill_fwd_params(d, x, w_packed, bias, y, stat_partials, p);
   return run_igemm(p, vec4, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Share of the algorithmic multiply-adds (padded taps included) that the kernels launched for this descriptor execute
+// after skipping the K chunks / row chunks that are zero padding for a whole tile.  which: 0 forward, 1 dgrad, 2 wgrad.
+double rsp_conv3d_executed_fraction(const rsp_conv3d_desc* d, int which) {
+  if (!desc_ok(d)) return 1.0;
+  float* const al = reinterpret_cast<float*>(uintptr_t(1) << 20);      // stands for any 16-byte aligned tensor
+  if (which == 2) return rsp_wgrad_executed_fraction(d);
+  if (which == 0) {
+    if (rsp_stem_applicable(d)) return 1.0;
+    IgemmParams p;
+    const bool vec4 = fill_fwd_params(d, al, al, nullptr, al, nullptr, p);
+    return igemm_live_fraction(p, vec4);
+  }
+  double live = 0.0, tot = 0.0;
+  for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
+    const DgradClass g = dgrad_class(d, c);
+    if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+    IgemmParams p;
+    const bool vec4 = fill_dgrad_class_params(d, g, al, al, al, p);
+    const double wgt = (double)p.M * p.K;
+    live += wgt * igemm_live_fraction(p, vec4);
+    tot += wgt;
+  }
+  return tot > 0 ? live / tot : 1.0;
 }
 
 // Host evaluation of the kernels' constant division (same magic numbers, same multiply-high + shift): lets the CPU test suite
@@ -1586,31 +1733,7 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
     if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
     const int Kld = (int)rsp_align_up((size_t)g.nt * g.nh * g.nw * d->Cout, 4);
     IgemmParams& p = cls[ncls];
-    memset(&p, 0, sizeof p);
-    p.x = dy; p.w = wpk + woff; p.bias = nullptr; p.y = dx; p.stat = nullptr;
-    p.M = d->N * g.Gd * g.Gh * g.Gw;
-    p.Nb = d->N;
-    p.Gd = g.Gd; p.Gh = g.Gh; p.Gw = g.Gw;
-    p.oDm = d->Di; p.oHm = d->Hi; p.oWm = d->Wi;
-    p.oSd = d->sT; p.oSh = d->sH; p.oSw = d->sW;
-    p.oOd = g.rt; p.oOh = g.rh; p.oOw = g.rw;
-    p.out_ld = d->in_ld; p.Cout = d->Cin;
-    p.Di = d->Do; p.Hi = d->Ho; p.Wi = d->Wo; p.in_ld = d->out_ld; p.Cin = d->Cout;
-    p.sD = p.sH = p.sW = 1;
-    p.nTd = g.nt; p.nTh = g.nh; p.nTw = g.nw;
-    // tap a (kernel index k = k0 + a*s) reads dy at  g + (r + p - k)/s  =  g + off0 - a
-    p.off0d = (g.rt + d->pT - g.k0t) / d->sT;
-    p.off0h = (g.rh + d->pH - g.k0h) / d->sH;
-    p.off0w = (g.rw + d->pW - g.k0w) / d->sW;
-    p.offstep = -1;
-    p.K = g.nt * g.nh * g.nw * d->Cout;
-    p.Kld = Kld;
-    const unsigned long long xb = (unsigned long long)d->N * d->Do * d->Ho * d->Wo * d->out_ld * 4ull;
-    const unsigned long long wb = (unsigned long long)d->Cin * Kld * 4ull;
-    p.x_bytes = (unsigned)xb;
-    p.w_bytes = (unsigned)wb;
-    cvec[ncls] = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy) && rsp_aligned16(p.w) && xb < (1ull << 32) &&
-                 wb < (1ull << 32) && g.nt <= 8 && g.nh <= 8 && g.nw <= 8;
+    cvec[ncls] = fill_dgrad_class_params(d, g, dy, wpk + woff, dx, p);
     max_taps = max_taps > g.nt * g.nh * g.nw ? max_taps : g.nt * g.nh * g.nw;
     woff += (size_t)d->Cin * Kld;
     ++ncls;

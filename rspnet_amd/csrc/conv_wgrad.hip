@@ -776,10 +776,64 @@ size_t wgrad_ws_one(const rsp_conv3d_desc* d) {
   return w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes;
 }
 
+// Which (k tile, output frame) pairs the row walk of wgrad_dma_kernel skips, and whether it is switched on for this geometry.
+struct WSkip {
+  int skip_pad, kh0, kh1, lpt;
+  long long dead_frames;      // (k tile, frame) pairs whose kernel depths all fall into the padding
+};
+
+WSkip wgrad_skip_plan(const rsp_conv3d_desc* d, const WPlan& w) {
+  WSkip k = {0, 0, 0, 0, 0};
+  static const bool no_skip = getenv("RSP_NO_PAD_SKIP") != nullptr;      // (A/B switch for measurements, read once)
+  k.skip_pad = (!no_skip && d->kT > 1 && d->pT > 0 && d->Ho * d->Wo >= RK) ? 1 : 0;
+  const int K = d->kT * d->kH * d->kW * d->Cin;
+  // k tiles that skip no frame: those whose kernel depths [kt_lo, kt_hi] reach inside the input for every output frame
+  const int khw = d->kH * d->kW;
+  bool open = false;
+  for (int j = 0; j < w.k_tiles; ++j) {
+    const int k0 = j * w.bn, k1 = (k0 + w.bn < K ? k0 + w.bn : K) - 1;
+    const int kt_lo = (k0 / d->Cin) / khw, kt_hi = (k1 / d->Cin) / khw;
+    int dead = 0;
+    for (int g = 0; g < d->Do; ++g) dead += (g * d->sT - d->pT + kt_hi < 0 || g * d->sT - d->pT + kt_lo >= d->Di) ? 1 : 0;
+    k.dead_frames += dead;
+    if (!dead && !open) { k.kh0 = j; open = true; }
+    if (!dead) k.kh1 = j + 1;
+  }
+  // worth the walk and the re-ordered units (which cost some L2 locality) from ~6 % of the (k tile, frame) pairs on:
+  // C3D conv2 4 % (measured 5.52 -> 5.66 ms with it), conv3 8 %, conv4 17 %, conv5 33 %
+  if (k.dead_frames * 100 < 6ll * w.k_tiles * d->Do) k.skip_pad = 0;
+  if (k.kh0 == 0 && k.kh1 == w.k_tiles) k.skip_pad = 0;      // nothing to skip (e.g. 4-channel stems: every k tile spans all depths)
+  const long long lds = 2ll * RK * (w.bm + w.bn) * 4 + 1024;
+  const long long slots = 256 * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);      // as in wplan()
+  k.lpt = (k.skip_pad && (long long)w.splitm * w.co_tiles * w.k_tiles * 2 > slots * 3) ? 1 : 0;
+  k.skip_pad = k.lpt;      // (one round: every unit runs at once and the full-length ones set the time — C3D conv2: 5.52 -> 5.65 ms with the walk)
+  return k;
+}
+
 int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
               size_t workspace_bytes, void* stream, bool rowgeom_ready, int cout_valid, int cin_valid);
 
 }  // namespace
+
+double rsp_wgrad_executed_fraction(const rsp_conv3d_desc* d0) {
+  if (!wdesc_ok(d0)) return 1.0;
+  const WSegs g = wgrad_segments(d0);
+  double live = 0.0, tot = 0.0;
+  for (int i = 0; i < g.n; ++i) {
+    rsp_conv3d_desc seg = *d0;
+    seg.Cout = g.width[i];
+    const WPlan w = wplan(&seg);
+    const bool dma = seg.Cout % 4 == 0 && seg.out_ld % 4 == 0 && seg.Cin % 4 == 0 && seg.in_ld % 4 == 0 && seg.kT <= 8 && seg.kH <= 8 &&
+                     seg.kW <= 8;
+    const WSkip k = wgrad_skip_plan(&seg, w);
+    // (frame-granular: a 32-row chunk that straddles a live and a dead frame still runs)
+    const double f = (dma && k.skip_pad) ? 1.0 - (double)k.dead_frames / ((double)w.k_tiles * seg.Do) : 1.0;
+    live += f * seg.Cout;
+    tot += seg.Cout;
+  }
+  return tot > 0 ? live / tot : 1.0;
+}
+
 
 extern "C" {
 
@@ -874,32 +928,11 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
   p.Kld = w.Kld;
   p.rows_per_split = w.rows_per_split; p.splitm = w.splitm;
   p.co_tiles = w.co_tiles; p.k_tiles = w.k_tiles;
-  static const bool no_skip = getenv("RSP_NO_PAD_SKIP") != nullptr;      // (A/B switch for measurements, read once)
-  p.skip_pad = (!no_skip && d->kT > 1 && d->pT > 0 && d->Ho * d->Wo >= RK) ? 1 : 0;
   p.dP = fastdiv_make(d->Ho * d->Wo);
   p.dGd = fastdiv_make(d->Do);
-  {   // k tiles that skip no frame: those whose kernel depths [kt_lo, kt_hi] reach inside the input for every output frame
-    const int khw = d->kH * d->kW;
-    p.kh0 = p.kh1 = 0;
-    bool open = false;
-    long long dead_frames = 0;
-    for (int j = 0; j < w.k_tiles; ++j) {
-      const int k0 = j * w.bn, k1 = (k0 + w.bn < p.K ? k0 + w.bn : p.K) - 1;
-      const int kt_lo = (k0 / d->Cin) / khw, kt_hi = (k1 / d->Cin) / khw;
-      int dead = 0;
-      for (int g = 0; g < d->Do; ++g) dead += (g * d->sT - d->pT + kt_hi < 0 || g * d->sT - d->pT + kt_lo >= d->Di) ? 1 : 0;
-      dead_frames += dead;
-      if (!dead && !open) { p.kh0 = j; open = true; }
-      if (!dead) p.kh1 = j + 1;
-    }
-    // worth the walk and the re-ordered units (which cost some L2 locality) from ~6 % of the (k tile, frame) pairs on:
-    // C3D conv2 4 % (measured 5.52 -> 5.66 ms with it), conv3 8 %, conv4 17 %, conv5 33 %
-    if (dead_frames * 100 < 6ll * w.k_tiles * d->Do) p.skip_pad = 0;
-    if (p.kh0 == 0 && p.kh1 == w.k_tiles) p.skip_pad = 0;      // nothing to skip (e.g. 4-channel stems: every k tile spans all depths)
-    const long long lds = 2ll * RK * (w.bm + w.bn) * 4 + 1024;
-    const long long slots = 256 * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);      // as in wplan()
-    p.lpt = (p.skip_pad && (long long)w.splitm * w.co_tiles * w.k_tiles * 2 > slots * 3) ? 1 : 0;
-    p.skip_pad = p.lpt;      // (one round: every unit runs at once and the full-length ones set the time — C3D conv2: 5.52 -> 5.65 ms with the walk)
+  {
+    const WSkip sk = wgrad_skip_plan(d, w);
+    p.skip_pad = sk.skip_pad; p.kh0 = sk.kh0; p.kh1 = sk.kh1; p.lpt = sk.lpt;
   }
   const bool va = (d->Cout % 4 == 0) && (d->out_ld % 4 == 0) && rsp_aligned16(dy);
   const bool vb = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && rsp_aligned16(x);

@@ -15,6 +15,7 @@ Activations are (N, D, H, W, C) tensors.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -360,6 +361,21 @@ class BranchStreams:
             fn()
         self.task = (ts, keepalive)
 
+    @contextlib.contextmanager
+    def grads_ready(self):
+        """Stream context ordered behind everything issued so far on the trunk AND on the side-task stream — for work that reads
+        this pass's gradients but that the trunk need not wait for (an asynchronous all-reduce of a finished gradient bucket:
+        RCCL orders it behind the stream it is issued from).  The trunk itself is not held up, unlike with join_task()."""
+        cur = torch.cuda.current_stream(self.dev) if self.on else None
+        if cur is None or cur.cuda_stream != self.origin_h or torch.cuda.is_current_stream_capturing():
+            self.join_task()
+            yield
+            return
+        ts = self._get("task")
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            yield
+
     def join_task(self):
         if self.task is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.task[0])
@@ -640,10 +656,10 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
 def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, after_param_grads=None,
                  want_input_grad: bool = False, packed: Optional[PackedWeights] = None):
     """Backward through the plan.  `grad_of(param)` returns the (pre-allocated, flat-buffer) gradient view to
-    fill for a parameter, or None to skip it.  `after_param_grads(node_index, join_side_tasks)` is called once a node's parameter
+    fill for a parameter, or None to skip it.  `after_param_grads(node_index, grads_ready)` is called once a node's parameter
     gradients have been ISSUED (used to launch bucketed all-reduces overlapped with the rest of backward); a weight gradient may
-    still be running on the side-task stream then — the hook calls `join_side_tasks()` before it reads gradients on the
-    current stream.
+    still be running on the side-task stream then — the hook issues whatever reads gradients inside `with grads_ready():`, a
+    stream context ordered behind all of them (BranchStreams.grads_ready).
     want_input_grad: also propagate to the plan's input slot and return that gradient (projection-head sub-plans, whose
     input is the backbone feature; the backbone's own input is the clip and needs none)."""
     be = _ops.backend()
@@ -680,7 +696,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                 # every real filter element appears once in a class's virtual filter: unique indices, order-independent
                 gflat.index_add_(0, vs.dst[c], gv.view(-1).index_select(0, vs.src[c]))
         if after_param_grads is not None:
-            after_param_grads(ni, branches.join_task)
+            after_param_grads(ni, branches.grads_ready)
 
     def convbn_bwd(node, key, ni):
         sv = ctx.saved.pop(key)
@@ -697,7 +713,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                                     grad_of(bn.weight), grad_of(bn.bias), grad_of(gnode.conv.weight), grad_of(gnode.conv.bias))
             dres = None
             if after_param_grads is not None:
-                after_param_grads(gi, branches.join_task)
+                after_param_grads(gi, branches.grads_ready)
         else:
             dout = _view(dslots[node.into[0]], node.into, sv.cg.Cout) if node.into is not None else dslots.pop(node.dst)
             dy, dres = be.bn_act_pool_bwd(sv.pg, sv.y, sv.res, dout, bn.weight.data, sv.mi, sv.ss, node.relu,
@@ -721,7 +737,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
         else:
             be.conv_wgrad(sv.cg, sv.x, dy, gw)
         if after_param_grads is not None:
-            after_param_grads(ni, branches.join_task)
+            after_param_grads(ni, branches.grads_ready)
         if node.src != plan.input_slot or want_input_grad:
             add_grad(node.src, be.conv_dgrad_packed(sv.cg, dy, packed.get_dgrad(node, sv.cg)))
 
@@ -751,7 +767,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
                     g.copy_(tmp[off:off + g.shape[0]])
                 off += m.conv.weight.shape[0]
         if after_param_grads is not None:
-            after_param_grads(ni, branches.join_task)
+            after_param_grads(ni, branches.grads_ready)
         if ms[0].src != plan.input_slot or want_input_grad:
             add_grad(ms[0].src, be.conv_dgrad_packed(cg, dy_cat, packed.get_dgrad(node._cat_node(), cg)))
 
@@ -766,7 +782,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             dz = be.eltwise("relu_bwd", y, dout.contiguous()) if node.relu else dout.contiguous()
             be.conv_wgrad(cg, xin, dz, grad_of(node.conv.weight), grad_of(node.conv.bias))
             if after_param_grads is not None:
-                after_param_grads(ni, branches.join_task)
+                after_param_grads(ni, branches.grads_ready)
             if node.src != plan.input_slot or want_input_grad:
                 add_grad(node.src, be.conv_dgrad_packed(cg, dz, packed.get_dgrad(node, cg)))
             del dz, dout
@@ -784,7 +800,7 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
             add_grad(node.src, be.gate_bwd(xin, dout, node.conv.weight.data, mean, gate, grad_of(node.conv.weight),
                                            grad_of(node.conv.bias)))
             if after_param_grads is not None:
-                after_param_grads(ni, branches.join_task)
+                after_param_grads(ni, branches.grads_ready)
         else:
             raise NotImplementedError(f"plan node {type(node).__name__}")
 

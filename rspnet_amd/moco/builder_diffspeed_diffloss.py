@@ -13,6 +13,7 @@ the key passes, two train-mode key passes, queue enqueue of k_neg_A).  What diff
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import random
 from typing import List, Optional, Tuple
@@ -478,16 +479,16 @@ class MoCoDiffLossTwoFc(nn.Module):
             handed_out.add(id(p))
             return flat.grad_of(p)
 
-        def after(_node_index, join_side_tasks=None):
-            # runs after each plan node: every gradient view handed out so far has been written — on this stream or by a
-            # weight-gradient task the engine put on its side stream (engine.BranchStreams.side_task), which is joined before a
-            # bucket leaves: the collective is ordered behind the stream it is issued from
+        def after(_node_index, grads_ready=None):
+            # runs after each plan node: every gradient view handed out so far has been issued — on this stream or as a
+            # weight-gradient task on the engine's side stream (engine.BranchStreams.side_task).  A finished bucket's all-reduce is
+            # issued from a stream context ordered behind both (RCCL runs it behind the stream it is issued from); the backward
+            # itself does not wait.
             for bi, (s, e, ids) in enumerate(buckets):
                 if bi not in launched and all(pid in handed_out for pid in ids):
-                    if join_side_tasks is not None:
-                        join_side_tasks()
                     launched.add(bi)
-                    handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
+                    with (grads_ready() if grads_ready is not None else contextlib.nullcontext()):
+                        handles.append(dist.all_reduce(flat.g_flat[s:e], async_op=True))
 
         self.encoder_q.backward_ndhwc(ectx, dqA, dqM, grad_of, after if buckets else None)
         for bi, (s, e, ids) in enumerate(buckets):

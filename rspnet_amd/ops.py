@@ -96,6 +96,14 @@ def _conv_plan(lib_id, g: "ConvGeom", in_ld, out_ld):
             lib.rsp_conv3d_wgrad_workspace(ref), g.out_dims, names)
 
 
+@functools.lru_cache(maxsize=4096)
+def executed_fraction(g: "ConvGeom", which: int) -> float:
+    """Share of the algorithmic MACs of one pass (0 forward, 1 dgrad, 2 wgrad) the kernels execute after skipping padding chunks
+    (rsp_conv3d_executed_fraction; host arithmetic, measurement bookkeeping only)."""
+    d = g.desc()
+    return float(_lib.load().rsp_conv3d_executed_fraction(C.byref(d), which))
+
+
 @functools.lru_cache(maxsize=8192)
 def _pack_signature(g: "ConvGeom", which: int, cout_src: int, cin_src: int):
     lib = _lib.load()
@@ -171,6 +179,7 @@ class HipOps:
         # bytes, geometry) per MFMA launch
         # group, recorded on the stream the kernels run on (torch's current stream).
         self.event_log = None
+        self.hbm_log = None      # (kind, algorithmic bytes, start, end) per streaming launch group, with event_log
 
     def _ev(self):
         if self.event_log is None:
@@ -184,7 +193,16 @@ class HipOps:
         if e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.event_log.append((kind, g.flops, e0, e1, kernel, g.bytes, g))
+            which = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}[kind]
+            self.event_log.append((kind, g.flops, e0, e1, kernel, g.bytes, g, g.flops * executed_fraction(g, which)))
+
+    def _log_hbm(self, kind, nbytes, e0):
+        """bench.py's roofline pass: a streaming (HBM-bound) launch group with its algorithmic bytes — every operand tensor moved
+        once."""
+        if e0 is not None and self.hbm_log is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.hbm_log.append((kind, int(nbytes), e0, e1))
 
     # one grow-only scratch buffer per (device, stream): kernels on one stream are serialised, so they can share it; work issued
     # on different streams (independent branches of a layer graph) must not
@@ -317,8 +335,11 @@ class HipOps:
             do, ho, wo = pg.out_dims
             out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
         d, dref, _, _ = _pool_plan(0, pg, in_ld, _rows_ld(out, "out"), None if residual is None else _rows_ld(residual, "residual"))
+        e0 = self._ev()
         _lib.check(self.lib.rsp_bn_act_pool_fwd(dref, _ptr(y), _ptr(scale_shift), _ptr(residual), int(relu), _ptr(out),
                                                 _stream()), "rsp_bn_act_pool_fwd")
+        n_in = pg.N * pg.Di * pg.Hi * pg.Wi * pg.C
+        self._log_hbm("bn_act_pool_fwd", 4 * (n_in * (1 if residual is None else 2) + out.numel()), e0)
         return out
 
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu: bool,
@@ -337,10 +358,14 @@ class HipOps:
         dres = torch.empty_like(y) if want_dres else None
         ws = self._workspace(y.device, wsb)
         c_valid = pg.C if gamma is None else int(gamma.shape[0])      # < C: zero-padded channels (gamma / dgamma / dbeta are short)
+        e0 = self._ev()
         _lib.check(self.lib.rsp_bn_act_pool_bwd_v(dref, _ptr(y), _ptr(residual), _ptr(dout), _ptr(gamma),
                                                   _ptr(mean_invstd), _ptr(scale_shift), int(relu), _ptr(dy), _ptr(dres),
                                                   _ptr(dgamma_out), _ptr(dbeta_out), c_valid, _ptr(ws), wsb, _stream()),
                    "rsp_bn_act_pool_bwd")
+        # reduce pass: y (+ residual) + dout read; apply pass: the same again, dy (+ dres) written
+        n_in = y.numel()
+        self._log_hbm("bn_bwd(reduce+apply)", 4 * (2 * (n_in * (1 if residual is None else 2) + dout.numel()) + n_in * (2 if want_dres else 1)), e0)
         return dy, dres
 
     # ---- stand-alone pooling / gating --------------------------------------------------------------------------
@@ -575,17 +600,23 @@ class HipOps:
         B_out = src.shape[0]
         c_out = c_out or Cc
         out = torch.empty((B_out, T_out, H, W, c_out), dtype=torch.float32, device=im.device)
+        e0 = self._ev()
         _lib.check(self.lib.rsp_clip_gather(_ptr(im), B_in, Cc, T_in, H, W, _ptr(src), _ptr(step), B_out, T_out, c_out, _ptr(out),
                                             _stream()), "rsp_clip_gather")
+        self._log_hbm("clip_gather", 4 * (B_out * T_out * H * W * Cc + out.numel()), e0)
         return out
 
     def momentum_update(self, k_flat, q_flat, m: float):
+        e0 = self._ev()
         _lib.check(self.lib.rsp_momentum_update(_ptr(_chk(k_flat, "k")), _ptr(_chk(q_flat, "q")), k_flat.numel(), m,
                                                 _stream()), "rsp_momentum_update")
+        self._log_hbm("momentum_update", 4 * 3 * k_flat.numel(), e0)
 
     def sgd_step(self, p, g, buf, lr: float, mu: float, wd: float, gscale: float, first: bool):
+        e0 = self._ev()
         _lib.check(self.lib.rsp_sgd_step(_ptr(_chk(p, "p")), _ptr(_chk(g, "g")), _ptr(_chk(buf, "buf")), p.numel(), lr, mu,
                                          wd, gscale, int(first), _stream()), "rsp_sgd_step")
+        self._log_hbm("sgd_step", 4 * 5 * p.numel(), e0)
 
     def rows_gather(self, x, idx):
         _chk(x, "x")

@@ -56,7 +56,7 @@ torch.cuda.synchronize()
 log, be.event_log = be.event_log, None
 step_ms = e0.elapsed_time(e1) / args.steps
 tab = {}
-for kind, f, a, b, kernel, nbytes, geom in log:
+for kind, f, a, b, kernel, nbytes, geom, _fx in log:
     key = (kind, geom, kernel)
     t = tab.setdefault(key, [0, 0.0, 0.0])
     t[0] += 1
