@@ -90,6 +90,8 @@ struct IgemmParams {
   int m_tiles, n_tiles;
   const float* __restrict__ zero;  // >= 64 B of zeros (g_zero)
   unsigned x_bytes, w_bytes;       // extents for the buffer descriptors of the DMA path (< 4 GiB)
+  unsigned y_bytes, partial_bytes; // ... and of the persistent kernels' output stores (0: output not addressable with 32 bits)
+  FastDiv dR, dNtl;                // tail tiles (m_tiles * n_tiles - full_tiles), n_tiles
   FastDiv dGw, dGh, dGd, dCin, dTw, dTh;   // filled by fill_fastdiv() from Gw, Gh, Gd, Cin, nTw, nTh
   int adv_tap, adv_ci;                     // BK / Cin, BK % Cin
   int nbuf;                                // LDS tile buffers: 2, or 1 (see igemm_body)
@@ -768,6 +770,562 @@ __global__ __launch_bounds__(256, 2) void igemm_ks_kernel(const IgemmParams p) {
   igemm_body<BM, BN, WAVES_M, WAVES_N, 4, true>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent variant of the LDS-DMA implicit GEMM (round 4).  Same tiles, same K walks and the same arithmetic per tile as
+// igemm_body; what changes is who pays the per-tile fixed cost.  Measured with per-wave timestamps (tools/phase_probe.py,
+// profiles/r04/phase_*.txt): a short-K tile (K = 288 ... 1152) spends 15-30 us of a 70-250 us life between its launch and its
+// first MFMA (kernel arguments, ~1 100 VALU + 700 SALU instructions of geometry — a third of them reloads of spilled scalars —,
+// the tap table, the first copy's round trip) and another 8-10 us storing (64-bit address arithmetic per store, more reloads).
+// Here a workgroup stays resident and walks a list of units (tile, K slice):
+//   * launch constants — tap table, buffer descriptors, lane geometry — are set up once per workgroup;
+//   * the NEXT unit's row geometry is computed and its first chunk is copied to LDS under the LAST chunk's MFMAs of the current
+//     one, so a unit starts with its operands in LDS;
+//   * the epilogue addresses its stores as raw-buffer offsets: 4 VGPR offsets per lane + scalar row-group offsets + an immediate
+//     column offset, no per-store address arithmetic; rows / columns outside the tensor get an out-of-range offset, which the
+//     hardware drops (no checked / unchecked code variants).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct UnitPos {
+  int m0, n0, m_tile, z, kc_begin, kc_end;
+  bool is_partial;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS>
+__device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg, const int nwg, const int n_units) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
+  constexpr int LDR = BK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nbuf = p.nbuf;
+  const int ntaps = p.nTd * p.nTh * p.nTw;
+  float* As = reinterpret_cast<float*>(smem_raw);                 // [nbuf][BM][LDR]
+  float* Bs = As + nbuf * BM * LDR;                               // [nbuf][BN][LDR]
+  int2* taptab = reinterpret_cast<int2*>(Bs + nbuf * BN * LDR);    // [ntaps + 1] {validity bits the tap needs, input offset}
+  unsigned* rowaddr = reinterpret_cast<unsigned*>(taptab + ntaps + 1);   // [BM] byte offsets of the strided-output rows
+  float* red = reinterpret_cast<float*>(rowaddr + BM);            // [WAVES_M][BN][2] statistics scratch
+  unsigned* xch = reinterpret_cast<unsigned*>(red + WAVES_M * BN * 2);   // [4] the waves' tap masks
+  unsigned char* pblk = reinterpret_cast<unsigned char*>(xch + 4);       // copy of the argument block (see below)
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // Launch constants that only the per-unit code needs (row decoding, walk start, epilogue: ~80 scalars) are read from a copy of
+  // the argument block in LDS where they are used, instead of living in — and being spilled from — the scalar registers across
+  // the K loop (the compiler cannot carry an LDS value over a barrier, so nothing stays resident).
+  {
+    const int* src = reinterpret_cast<const int*>(&p);
+    int* dstw = reinterpret_cast<int*>(pblk);
+    for (int i = t; i < (int)(sizeof(IgemmParams) / 4); i += 256) dstw[i] = src[i];
+  }
+  const IgemmParams& vp = *reinterpret_cast<const IgemmParams*>(pblk);
+  auto fdv = [](int n, const FastDiv& f) { return fastdiv(n, f); };
+  auto row_decode_v = [&](const IgemmParams& v, bool dmajor, int q2, int& n, int& gd) { row_decode(v, dmajor, q2, n, gd); };
+  // ---- once per workgroup ---------------------------------------------------------------------------------------------------
+  for (int i = t; i < ntaps && !KS; i += 256) {
+    const int q = fastdiv(i, p.dTw), aw = i - q * p.nTw;
+    const int ad = fastdiv(q, p.dTh), ah = q - ad * p.nTh;
+    const int od = p.off0d + ad * p.offstep, oh = p.off0h + ah * p.offstep, ow = p.off0w + aw * p.offstep;
+    taptab[i] = make_int2((1 << ad) | (1 << (8 + ah)) | (1 << (16 + aw)), ((od * p.Hi + oh) * p.Wi + ow) * p.in_ld);
+  }
+  __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(p.partial ? p.partial : p.y, 0, (int)(p.partial ? p.partial_bytes : 4u), 0x00020000);
+  const int arow = t >> 3;
+  const int kcol = ((t & 7) ^ ((arow >> 1) & 7)) * 4;      // de-swizzled k offset of this thread inside a chunk
+  const bool tms = !KS && p.tm_skip;
+  const int R = p.m_tiles * p.n_tiles - p.full_tiles;
+
+  auto unit_pos = [&](int u) {
+    UnitPos q;
+    int tile;
+    q.z = 0;
+    q.is_partial = false;
+    if (u < vp.full_tiles) {
+      tile = rsp_xcd_remap(u, vp.full_tiles);
+    } else {
+      const int uu = rsp_xcd_remap(u - vp.full_tiles, n_units - vp.full_tiles);
+      q.z = fdv(uu, vp.dR);
+      tile = vp.full_tiles + (uu - q.z * R);
+      q.is_partial = vp.splitk > 1;
+    }
+    q.m_tile = fdv(tile, vp.dNtl);
+    const int n_tile = tile - q.m_tile * vp.n_tiles;
+    q.m0 = q.m_tile * BM;
+    q.n0 = n_tile * BN;
+    q.kc_begin = q.is_partial ? q.z * vp.chunks_per_split : 0;
+    q.kc_end = q.is_partial ? min(vp.nchunks, q.kc_begin + vp.chunks_per_split) : vp.nchunks;
+    // (values read from the LDS copy are wave-uniform but live in vector registers: back to scalars)
+    q.m0 = __builtin_amdgcn_readfirstlane(q.m0);
+    q.n0 = __builtin_amdgcn_readfirstlane(q.n0);
+    q.m_tile = __builtin_amdgcn_readfirstlane(q.m_tile);
+    q.z = __builtin_amdgcn_readfirstlane(q.z);
+    q.kc_begin = __builtin_amdgcn_readfirstlane(q.kc_begin);
+    q.kc_end = __builtin_amdgcn_readfirstlane(q.kc_end);
+    q.is_partial = __builtin_amdgcn_readfirstlane((int)q.is_partial) != 0;
+    return q;
+  };
+
+  // ---- per-unit state of the loader (always that of the unit whose chunks are being COPIED) --------------------------------
+  unsigned abase32[AR], rbits[AR], wrowoff[BR];      // (a weight row beyond Cout carries an offset >= 2^31: out of range for any chunk)
+  unsigned tmask = 0x00ffffffu;
+  int ld_end = 0;                                        // kc_end of the loader's unit
+  int ckc = 0;                                           // next chunk to copy
+  int ukw = 0, ukh = 0, ukd = 0, uslice = 0;             // wave-uniform tap counters (KS; tap-major skipping)
+  int ntap = 0, nci = 0;                                 // per-lane (tap, channel) of the tap-major walk
+  int2 ntt = make_int2(0, 0);
+
+  // rows of the unit -> lane geometry + this wave's OR of the validity bits (to xch)
+  auto rows_of = [&](const UnitPos& q) {
+    // (launch constants from the LDS copy, made scalar again: the vector registers are needed for the four rows' arithmetic)
+    auto S = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto SF = [&](const FastDiv& f) {
+      FastDiv r;
+      r.mul = (unsigned)S((int)f.mul);
+      r.shr = (unsigned)S((int)f.shr);
+      r.d = 0;
+      return r;
+    };
+    const int M = S(vp.M), Gw = S(vp.Gw), Gh = S(vp.Gh), Gd = S(vp.Gd), Np = S(vp.Np), dmaj = S(vp.dmajor);
+    const int sD = S(vp.sD), sH = S(vp.sH), sW = S(vp.sW), Di = S(vp.Di), Hi = S(vp.Hi), Wi = S(vp.Wi), in_ld = S(vp.in_ld);
+    const int o0d = S(vp.off0d), o0h = S(vp.off0h), o0w = S(vp.off0w), ostep = S(vp.offstep);
+    const int nTd = S(vp.nTd), nTh = S(vp.nTh), nTw = S(vp.nTw);
+    const FastDiv dGw = SF(vp.dGw), dGh = SF(vp.dGh), dGd = SF(vp.dGd), dNp = SF(vp.dNp), dGdNp = SF(vp.dGdNp);
+    unsigned m_or = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int r = q.m0 + arow + 32 * i;
+      unsigned m = 0, ab = 0;
+      if (r < M) {
+        const int q1 = fastdiv(r, dGw), gw = r - q1 * Gw;
+        const int q2 = fastdiv(q1, dGh), gh = q1 - q2 * Gh;
+        int n, gd;
+        if (dmaj) {
+          const int part = fastdiv(q2, dGdNp);
+          const int rem = q2 - part * (Gd * Np);
+          const int g = fastdiv(rem, dNp);
+          n = part * Np + (rem - g * Np);
+          gd = g + 1 == Gd ? 0 : g + 1;
+        } else {
+          n = fastdiv(q2, dGd);
+          gd = q2 - n * Gd;
+        }
+        const int id = gd * sD, ih = gh * sH, iw = gw * sW;
+        ab = (unsigned)(((((long long)n * Di + id) * Hi + ih) * Wi + iw) * in_ld * 4);
+        auto span = [&](int base, int D, int nT) -> unsigned {
+          const int c = ostep > 0 ? base : D - 1 - base;
+          const int lo = min(max(0, -c), 8), hi = min(nT - 1, D - 1 - c);
+          return hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+        };
+        m = span(id + o0d, Di, nTd) | (span(ih + o0h, Hi, nTh) << 8) | (span(iw + o0w, Wi, nTw) << 16);
+      }
+      abase32[i] = ab;
+      rbits[i] = m;
+      m_or |= m;
+    }
+    const int Cout = S(vp.Cout), Kld = S(vp.Kld);
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int co = q.n0 + arow + 32 * i;
+      wrowoff[i] = co < Cout ? (unsigned)co * (unsigned)Kld * 4u : 0x80000000u;
+    }
+    if (KS || tms) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m_or |= (unsigned)__shfl_xor((int)m_or, o);
+      if (lane == 0) xch[wave] = m_or;
+    }
+  };
+  // ... then, behind a barrier: the tile's tap mask and the walk's start position
+  auto dead_tm = [&]() {      // tap-major skipping: is chunk ckc dead for the whole tile?
+    if (p.cpt > 0) {
+      const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
+      return (tmask & need) != need;
+    }
+    const int t0 = fastdiv(ckc * BK, p.dCin), t1 = min(fastdiv(ckc * BK + BK - 1, p.dCin), ntaps - 1);
+    const unsigned sp = (2u << fastdiv(t1, p.dThw)) - (1u << fastdiv(t0, p.dThw));
+    return (tmask & sp) == 0;
+  };
+  auto lane_advance = [&]() {      // (the slice-major order always takes the KS instance: tap-major arithmetic only)
+    nci += p.adv_ci;
+    ntap += p.adv_tap;
+    if (nci >= p.Cin) {
+      nci -= p.Cin;
+      ++ntap;
+    }
+    ntt = taptab[min(ntap, ntaps - 1)];
+  };
+  auto ks_step = [&]() {
+    ++ckc;
+    if (++ukw == p.nTw) {
+      ukw = 0;
+      if (++ukh == p.nTh) {
+        ukh = 0;
+        if (++ukd == p.nTd) {
+          ukd = 0;
+          ++uslice;
+        }
+      }
+    }
+  };
+  auto tm_step = [&]() {
+    ++ckc;
+    if (p.cpt > 0 && ++uslice == p.cpt) {
+      uslice = 0;
+      if (++ukw == p.nTw) {
+        ukw = 0;
+        if (++ukh == p.nTh) {
+          ukh = 0;
+          ++ukd;
+        }
+      }
+    }
+  };
+  // move the cursor to the next LIVE chunk of the loader's unit (no-op for the plain tap-major walk)
+  auto seek = [&]() {
+    if (KS) {
+      while (ckc < ld_end) {
+        const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
+        if ((tmask & need) == need) break;
+        ks_step();
+      }
+    } else if (tms) {
+      while (ckc < ld_end && dead_tm()) {
+        lane_advance();
+        tm_step();
+      }
+    }
+  };
+  // start of a unit's walk, part 1 (before the barrier that publishes the waves' masks): cursor and tap state
+  auto walk_pre = [&](const UnitPos& q) {
+    ld_end = q.kc_end;
+    ckc = q.kc_begin;
+    if (KS) {
+      uslice = fdv(q.kc_begin, vp.dNt);
+      const int tap0 = q.kc_begin - uslice * ntaps;
+      const int qq = fdv(tap0, vp.dTw);
+      ukw = tap0 - qq * vp.nTw;
+      ukd = fdv(qq, vp.dTh);
+      ukh = qq - ukd * vp.nTh;
+      uslice = __builtin_amdgcn_readfirstlane(uslice);
+      ukw = __builtin_amdgcn_readfirstlane(ukw);
+      ukd = __builtin_amdgcn_readfirstlane(ukd);
+      ukh = __builtin_amdgcn_readfirstlane(ukh);
+    } else {
+      const int k = q.kc_begin * BK + kcol;
+      ntap = fdv(k, vp.dCin);
+      nci = k - ntap * vp.Cin;
+      ntt = taptab[min(ntap, ntaps - 1)];
+      if (tms) {
+        const int tap0 = fdv(q.kc_begin * BK, vp.dCin);
+        uslice = q.kc_begin - tap0 * vp.cpt;
+        const int qq = fdv(tap0, vp.dTw);
+        ukw = tap0 - qq * vp.nTw;
+        ukd = fdv(qq, vp.dTh);
+        ukh = qq - ukd * vp.nTh;
+        uslice = __builtin_amdgcn_readfirstlane(uslice);
+        ukw = __builtin_amdgcn_readfirstlane(ukw);
+        ukd = __builtin_amdgcn_readfirstlane(ukd);
+        ukh = __builtin_amdgcn_readfirstlane(ukh);
+      }
+    }
+  };
+  // ... part 2 (behind it): the tile's tap mask; on to the first live chunk
+  auto walk_mask = [&]() {
+    tmask = 0x00ffffffu;
+    if ((KS && p.skip_pad) || tms) tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(xch[0] | xch[1] | xch[2] | xch[3]));
+    seek();
+  };
+  // copy chunk ckc of the loader's unit into tile buffer `buf` and move the cursor on to the next live chunk.  (Every LDS read this
+  // needs — the next tap-table entry — is issued before the first copy.)
+  auto load_chunk = [&](int buf) {
+    const int k = ckc * BK + kcol;
+    const unsigned k4 = (unsigned)k * 4u;
+    if (KS) {
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const unsigned off = wrowoff[i] + k4;
+        float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, off, 0, 0, 0);
+      }
+      const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
+      const int od = p.off0d + ukd * p.offstep, oh = p.off0h + ukh * p.offstep, ow = p.off0w + ukw * p.offstep;
+      const unsigned delta4 = (unsigned)((((od * p.Hi + oh) * p.Wi + ow) * p.in_ld + uslice * BK) * 4) + (unsigned)kcol * 4u;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const unsigned off = (rbits[i] & need) == need ? abase32[i] + delta4 : 0xffffffffu;
+        float* dst = As + buf * BM * LDR + i * 32 * LDR + wave * 64 * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
+      }
+      ks_step();
+      seek();
+      return;
+    }
+    const int ctap = ntap, cci = nci;
+    const int2 ctt = ntt;
+    lane_advance();
+    const unsigned kout = k < p.Kld ? 0u : 0x80000000u;      // K tail: out of range
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const unsigned off = (wrowoff[i] + k4) | kout;
+      float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, off, 0, 0, 0);
+    }
+    const unsigned need = ctap < ntaps ? (unsigned)ctt.x : 0xffffffffu;      // (a lane past the last tap: never satisfied)
+    const unsigned delta4 = ((unsigned)ctt.y + (unsigned)cci) * 4u;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const unsigned off = (rbits[i] & need) == need ? abase32[i] + delta4 : 0xffffffffu;
+      float* dst = As + buf * BM * LDR + i * 32 * LDR + wave * 64 * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)dst, 16, off, 0, 0, 0);
+    }
+    if (tms) {
+      tm_step();
+      seek();
+    } else {
+      ++ckc;
+    }
+  };
+
+  floatx16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+
+  // ---- epilogue of one unit ---------------------------------------------------------------------------------------------------
+  auto epilogue = [&](const UnitPos& q) {
+    const bool linear = q.is_partial || vp.linear_out;
+    const int lin_ld = q.is_partial ? vp.Cout : vp.out_ld;
+    // byte offset of (local row 0, column 0 of the tile) for the linear forms; the piecewise form (depth-major rows over a dense
+    // output) has base A up to local row pw_split and base A + D from there on
+    unsigned base4 = 0, pwD4 = 0;
+    int pw_split = BM;
+    bool piecewise = false;
+    if (linear) {
+      const long long b = q.is_partial ? ((long long)q.z * (vp.M - vp.tail_row0) + (q.m0 - vp.tail_row0)) * vp.Cout : (long long)q.m0 * vp.out_ld;
+      base4 = (unsigned)(b * 4);
+    } else if (vp.dm_dense) {
+      const int P = vp.Gh * vp.Gw;
+      const int q2a = fdv(q.m0, vp.dP), f0 = q.m0 - q2a * P;
+      pw_split = P - f0;
+      if (BM <= pw_split + P) {
+        piecewise = true;
+        int n, gd;
+        row_decode(p, true, q2a, n, gd);
+        const int ra = (n * vp.oDm + gd) * P + f0;
+        row_decode(p, true, min(q2a + 1, vp.Nb * vp.Gd - 1), n, gd);
+        const int rb = (n * vp.oDm + gd) * P - pw_split;
+        base4 = (unsigned)ra * (unsigned)vp.out_ld * 4u;
+        pwD4 = (unsigned)(rb - ra) * (unsigned)vp.out_ld * 4u;
+      }
+    }
+    const bool table = !linear && !piecewise;
+    if (table) {
+      if (t < BM) {
+        const int r = q.m0 + t;
+        unsigned addr = 0xffffffffu;
+        if (r < vp.M) {
+          const int q1 = fdv(r, vp.dGw), gw = r - q1 * vp.Gw;
+          const int q2 = fdv(q1, vp.dGh), gh = q1 - q2 * vp.Gh;
+          int n, gd;
+          row_decode(p, vp.dmajor, q2, n, gd);
+          addr = (unsigned)(((((long long)n * vp.oDm + gd * vp.oSd + vp.oOd) * vp.oHm + gh * vp.oSh + vp.oOh) * vp.oWm + gw * vp.oSw + vp.oOw) *
+                            vp.out_ld * 4);
+        }
+        rowaddr[t] = addr;
+      }
+      __syncthreads();
+    }
+    const unsigned pitch4 = (unsigned)lin_ld * 4u;
+    __amdgpu_buffer_rsrc_t rs = q.is_partial ? rsrc_p : rsrc_y;
+    // rows of this lane: local row = wm*WM + h*4 + (group offset gb + k); rows at or beyond `lim` lie outside the M rows
+    const int lim = vp.M - q.m0 - (wm * WM + h * 4);
+    const int pw_lim = pw_split - (wm * WM + h * 4);      // piecewise: local rows from pw_split on belong to the second run
+    auto store_tile = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;      // 0 linear, 1 piecewise (two linear runs), 2 per-row table
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = q.n0 + wn * WN + j * 32 + l32;
+        const bool cok = col < vp.Cout;
+        const float bv = (vp.bias && !q.is_partial && cok) ? vp.bias[col] : 0.f;
+        // offset of (local row wm*WM + h*4 + k, this column), k = 0..3; the row groups (i, g4) add a SCALAR offset
+        unsigned vo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo[k] = base4 + (unsigned)(wm * WM + h * 4 + k) * pitch4 + (unsigned)col * 4u;
+        const int lim_c = cok ? lim : 0;      // a column beyond Cout: no row of it is stored
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int gb = i * 32 + g4 * 8;
+            const unsigned so = (unsigned)gb * pitch4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float v = acc[i][j][g4 * 4 + k] + bv;
+              if (MODE == 2) {
+                const unsigned a = rowaddr[wm * WM + gb + h * 4 + k];
+                const unsigned off = (cok && a != 0xffffffffu) ? a + (unsigned)col * 4u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off, 0, 0);
+              } else {
+                // (the hardware range-checks the VECTOR offset alone: in the piecewise form, where the second run's base may lie
+                //  below the first one's, the whole offset goes into it; the linear form keeps the row group in the scalar offset)
+                unsigned off = vo[k];
+                if (MODE == 1) off += so + (gb + k < pw_lim ? 0u : pwD4);
+                if (gb + k >= lim_c) off = 0x80000000u;      // outside the tensor: out of range (extents stay below 2 GiB), dropped by the hardware
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off, MODE == 1 ? 0u : so, 0);
+              }
+            }
+          }
+      }
+    };
+    if (table) store_tile(std::integral_constant<int, 2>{});
+    else if (piecewise) store_tile(std::integral_constant<int, 1>{});
+    else store_tile(std::integral_constant<int, 0>{});
+    if (vp.stat && !q.is_partial) {
+      constexpr int SB = BM / 128;
+      constexpr int WPB = WAVES_M / SB;
+      static_assert(SB >= 1 && WPB >= 1 && WPB * SB == WAVES_M, "stat blocks");
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = acc[i][j][e];
+            s += v;
+            ss = fmaf(v, v, ss);
+          }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (h == 0) {
+          const int c = wn * WN + j * 32 + l32;
+          red[(wm * BN + c) * 2 + 0] = s;
+          red[(wm * BN + c) * 2 + 1] = ss;
+        }
+      }
+      __syncthreads();
+      for (int idx = t; idx < SB * BN; idx += 256) {
+        const int sb = idx / BN, c = idx - sb * BN;
+        if (q.n0 + c < vp.Cout && (long long)(q.m_tile * SB + sb) * 128 < vp.M) {
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int w = 0; w < WPB; ++w) {
+            s += red[((sb * WPB + w) * BN + c) * 2 + 0];
+            ss += red[((sb * WPB + w) * BN + c) * 2 + 1];
+          }
+          float* o = vp.stat + ((long long)(q.m_tile * SB + sb) * vp.stat_ld + q.n0 + c) * 2;
+          o[0] = s;
+          o[1] = ss;
+        }
+      }
+      // (the next unit's statistics go through `red` again: its writers are behind that unit's K-loop barriers)
+    }
+  };
+
+  // ---- the unit loop ------------------------------------------------------------------------------------------------------------
+  // Per unit: a tight inner loop over all chunks but the last (fragments -> registers, next chunk's copy, MFMAs, barrier: the loop
+  // of igemm_body), then the BOUNDARY step, which computes the last chunk while the loader moves on to the next unit — its row
+  // geometry is decoded before the fragment reads (the finished unit's loader registers are free by then), its first live chunk is
+  // copied under this step's MFMAs — and the finished unit's epilogue behind the closing barrier.  A unit without a live chunk
+  // (the very start; a K slice whose chunks are all padding) runs the boundary step without fragments or MFMAs.
+  auto read_frags = [&](int buf, floatx4 (&af)[4][TM], floatx4 (&bf)[4][TN]) {
+    const float* a = As + buf * BM * LDR + (wm * WM + l32) * LDR;
+    const float* b = Bs + buf * BN * LDR + (wn * WN + l32) * LDR;
+    const int swz = (l32 >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int slot = ((h * 4 + kk) ^ swz) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const floatx4*>(a + i * 32 * LDR + slot);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[kk][j] = *reinterpret_cast<const floatx4*>(b + j * 32 * LDR + slot);
+    }
+  };
+  auto mfmas = [&](const floatx4 (&af)[4][TM], const floatx4 (&bf)[4][TN]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i][e], bf[kk][j][e], acc[i][j], 0, 0, 0);
+  };
+  zero_acc();
+  int u = wg - nwg;                      // the unit being computed (none yet)
+  UnitPos cur = unit_pos(0);
+  bool cur_valid = false, have = false;
+  int buf = 0;
+  __syncthreads();                       // tap table, argument block
+  for (;;) {
+    // ---- all chunks of the current unit but the last
+    while (have && ckc < ld_end) {
+      floatx4 af[4][TM], bf[4][TN];
+      read_frags(buf, af, bf);
+      const int nb = nbuf == 1 ? 0 : buf ^ 1;
+      if (nbuf == 1) __syncthreads();    // every wave holds its fragments: the buffer may be overwritten
+      load_chunk(nb);
+      mfmas(af, bf);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      buf = nb;
+    }
+    // ---- boundary step
+    const bool has_next = u + nwg < n_units;
+    UnitPos nxt = cur;
+    if (has_next) {
+      nxt = unit_pos(u + nwg);
+      rows_of(nxt);
+      walk_pre(nxt);
+    }
+    bool next_have = false;
+    const int nb = nbuf == 1 ? 0 : buf ^ 1;
+    if (have) {
+      floatx4 af[4][TM], bf[4][TN];
+      read_frags(buf, af, bf);
+      __syncthreads();                   // fragments held by every wave (single buffer); the waves' masks
+      if (has_next) {
+        walk_mask();
+        next_have = ckc < ld_end;
+        if (next_have) load_chunk(nb);
+      }
+      mfmas(af, bf);
+    } else {
+      __syncthreads();
+      if (has_next) {
+        walk_mask();
+        next_have = ckc < ld_end;
+        if (next_have) load_chunk(nb);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    buf = nb;
+    if (cur_valid) epilogue(cur);
+    if (!has_next) break;
+    u += nwg;
+    cur = nxt;
+    cur_valid = true;
+    have = next_have;
+    zero_acc();
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS, int MINW>
+__global__ __launch_bounds__(256, MINW) void igemm_persist_kernel(const IgemmParams p, const int n_units) {
+  igemm_persist<BM, BN, WAVES_M, WAVES_N, KS>(p, (int)blockIdx.x, (int)gridDim.x, n_units);
+}
+
 // Several independent problems of one tile shape in a single launch: the stride-parity classes of a strided convolution's
 // input gradient (8 for stride (2,2,2)) are small GEMMs — R3D-18's layer4.0: 8 x (512 rows x 256 columns) — that each left
 // most of the machine idle as launches of their own (0.32 ms for 3.6 GFLOP).  Workgroup b belongs to class c with
@@ -1084,6 +1642,74 @@ int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
   return rsp_check_launch("igemm_multi_kernel");
 }
 
+
+// waves per SIMD the persistent instances are compiled for (launch bound) = workgroups per CU the grid is sized with
+constexpr int persist_minw(int bn) { return bn > 128 ? 2 : (bn > 64 ? 3 : 4); }
+
+static bool persist_enabled() {
+  static const bool off = getenv("RSP_NO_PERSIST") != nullptr;      // (A/B switch for measurements, read once)
+  return !off;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS>
+int launch_persist_cfg(const IgemmParams& p, hipStream_t s) {
+  constexpr int MINW = persist_minw(BN);
+  const int ntaps = p.nTd * p.nTh * p.nTw;
+  auto lds_of = [&](int nbuf, int taps) {
+    return (size_t)nbuf * (BM + BN) * BK * sizeof(float) + (size_t)(taps + 2) / 2 * sizeof(int4) + BM * sizeof(unsigned) +
+           (size_t)WAVES_M * BN * 2 * sizeof(float) + 4 * sizeof(unsigned) + sizeof(IgemmParams);
+  };
+  const size_t lds = lds_of(p.nbuf, ntaps);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_persist_kernel<BM, BN, WAVES_M, WAVES_N, KS, MINW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(2, MAX_TAPS));
+    attr_set = true;
+  }
+  const int n_units = p.full_tiles + (p.m_tiles * p.n_tiles - p.full_tiles) * p.splitk;
+  // resident workgroups: LDS- and register-limited; every workgroup walks units wg, wg + G, wg + 2G, ... (G a multiple of 8 when
+  // it is smaller than the unit count, so that a workgroup's units keep its XCD's contiguous share of the tiles: rsp_xcd_remap)
+  int wpc = (int)(160 * 1024 / lds);
+  wpc = wpc > MINW ? MINW : (wpc < 1 ? 1 : wpc);
+  int G = 256 * wpc;
+  if (n_units <= G) G = n_units;
+  rsp_note_kernel("igemm_persist_kernel<%d, %d, %d, %d, %s, %d>", BM, BN, WAVES_M, WAVES_N, KS ? "true" : "false", MINW);
+  hipLaunchKernelGGL((igemm_persist_kernel<BM, BN, WAVES_M, WAVES_N, KS, MINW>), dim3(G), dim3(256), lds, s, p, n_units);
+  return rsp_check_launch("igemm_persist_kernel");
+}
+
+int launch_persist(IgemmParams& p, hipStream_t s) {
+  const int bn = tile_bn(p.Cout);
+  p.m_tiles = rsp_cdiv(p.M, 128);
+  p.n_tiles = rsp_cdiv(p.Cout, bn);
+  const int R = p.m_tiles * p.n_tiles - p.full_tiles;
+  p.dR = fastdiv_make(R > 0 ? R : 1);
+  p.dNtl = fastdiv_make(p.n_tiles);
+  if (p.kmajor) {
+    switch (bn) {
+      case 160: return launch_persist_cfg<128, 160, 4, 1, true>(p, s);
+      case 128: return launch_persist_cfg<128, 128, 2, 2, true>(p, s);
+      case 96: return launch_persist_cfg<128, 96, 4, 1, true>(p, s);
+      case 64: return launch_persist_cfg<128, 64, 2, 2, true>(p, s);
+      default: return launch_persist_cfg<128, 32, 4, 1, true>(p, s);
+    }
+  }
+  switch (bn) {
+    case 160: return launch_persist_cfg<128, 160, 4, 1, false>(p, s);
+    case 128: return launch_persist_cfg<128, 128, 2, 2, false>(p, s);
+    case 96: return launch_persist_cfg<128, 96, 4, 1, false>(p, s);
+    case 64: return launch_persist_cfg<128, 64, 2, 2, false>(p, s);
+    default: return launch_persist_cfg<128, 32, 4, 1, false>(p, s);
+  }
+}
+
+// bytes reachable from the output base pointer (all positions of the output tensor, this segment's columns); 0 if >= 4 GiB
+static unsigned out_extent_bytes(const IgemmParams& p) {
+  const unsigned long long pos = (unsigned long long)p.Nb * p.oDm * p.oHm * p.oWm;
+  const unsigned long long b = ((pos - 1) * (unsigned long long)p.out_ld + (unsigned long long)p.Cout) * 4ull;
+  return b < 0x7ffffff0ull ? (unsigned)b : 0u;      // (< 2 GiB: an offset with bit 31 set is out of range whatever is added to it)
+}
+
 inline void fill_fastdiv_linear(IgemmParams& p) {
   const bool dense = p.oSd == 1 && p.oSh == 1 && p.oSw == 1 && p.oOd == 0 && p.oOh == 0 && p.oOw == 0 && p.oDm == p.Gd &&
                      p.oHm == p.Gh && p.oWm == p.Gw;
@@ -1308,7 +1934,11 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   p.chunks_per_split = sp.cps;
   p.tail_row0 = sp.full_tiles / n_tiles * 128;
   p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
-  int rc = launch_igemm(p, vec4, s);
+  p.y_bytes = out_extent_bytes(p);
+  const size_t pbytes = split_partial_bytes(sp, p.M, n_tiles, p.Cout);
+  p.partial_bytes = pbytes < 0x7ffffff0ull ? (unsigned)pbytes : 0u;
+  const bool persist = vec4 && persist_enabled() && p.y_bytes != 0 && (p.splitk == 1 || p.partial_bytes != 0);
+  int rc = persist ? launch_persist(p, s) : launch_igemm(p, vec4, s);
   if (rc != RSP_OK) return rc;
   if (p.splitk > 1) {
     ReduceParams r;
@@ -1648,16 +2278,30 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   int bn = tile_bn(plan_segments(cols).width[0]);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   // spelled as rocprofv3 prints the demangled instance (minus namespace and argument list)
-  if (vec4 && which == 0 && k_slice_major(d->Cin, d->kT * d->kH * d->kW)) {
+  const bool ks = vec4 && ((which == 0 && k_slice_major(d->Cin, d->kT * d->kH * d->kW)) ||
+                           (which == 1 && d->sT * d->sH * d->sW == 1 && k_slice_major(d->Cout, d->kT * d->kH * d->kW)));
+  // output addressable with 32-bit offsets: the persistent instances (launch_persist)
+  const unsigned long long out_b = which == 0 ? (unsigned long long)d->N * d->Do * d->Ho * d->Wo * d->out_ld * 4ull
+                                              : (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
+  if (vec4 && persist_enabled() && out_b < 0x7ffffff0ull) {
+    if (ks) {
+      switch (bn) {
+        case 160: return "igemm_persist_kernel<128, 160, 4, 1, true, 2>";
+        case 128: return "igemm_persist_kernel<128, 128, 2, 2, true, 3>";
+        case 96: return "igemm_persist_kernel<128, 96, 4, 1, true, 3>";
+        case 64: return "igemm_persist_kernel<128, 64, 2, 2, true, 4>";
+        default: return "igemm_persist_kernel<128, 32, 4, 1, true, 4>";
+      }
+    }
     switch (bn) {
-      case 160: return "igemm_ks_kernel<128, 160, 4, 1>";
-      case 128: return "igemm_ks_kernel<128, 128, 2, 2>";
-      case 96: return "igemm_ks_kernel<128, 96, 4, 1>";
-      case 64: return "igemm_ks_kernel<128, 64, 2, 2>";
-      default: return "igemm_ks_kernel<128, 32, 4, 1>";
+      case 160: return "igemm_persist_kernel<128, 160, 4, 1, false, 2>";
+      case 128: return "igemm_persist_kernel<128, 128, 2, 2, false, 3>";
+      case 96: return "igemm_persist_kernel<128, 96, 4, 1, false, 3>";
+      case 64: return "igemm_persist_kernel<128, 64, 2, 2, false, 4>";
+      default: return "igemm_persist_kernel<128, 32, 4, 1, false, 4>";
     }
   }
-  if (vec4 && which == 1 && d->sT * d->sH * d->sW == 1 && k_slice_major(d->Cout, d->kT * d->kH * d->kW)) {
+  if (ks) {
     switch (bn) {
       case 160: return "igemm_ks_kernel<128, 160, 4, 1>";
       case 128: return "igemm_ks_kernel<128, 128, 2, 2>";

@@ -48,7 +48,7 @@ def test_bench_prints_one_contract_line():
     assert cb["cpu_model"] and cb["s_per_step"] > 0
     # the roofline block names the kernel that dominates THIS backbone and carries the per-kernel table
     # (the 128x128 tile: its channel-slice-major instance runs conv3-5 and their input gradients, the tap-major one conv2)
-    assert rf["kernel"].startswith(("igemm_ks_kernel<128, 128", "igemm_kernel<128, 128")) and rf["kernel"] in rf["per_kernel"]
+    assert rf["kernel"].startswith(("igemm_persist_kernel<128, 128", "igemm_ks_kernel<128, 128", "igemm_kernel<128, 128")) and rf["kernel"] in rf["per_kernel"]
     assert abs(rf["avg_launch_ms"] - rf["per_kernel"][rf["kernel"]]["avg_launch_ms"]) < 1e-3 and 0 < rf["share_of_step"] < 1
     # traffic is priced against the algorithmic bytes of the same launches; the whole-step fraction is in the line
     assert rf["algorithmic_gb_per_launch"] > 0 and "L2-miss" in rf["traffic_unit"] and 0.2 < rf["whole_step"]["frac"] < 1.0
@@ -82,4 +82,4 @@ def test_bench_roofline_is_arch_aware():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
     assert "resnet18" in d["metric"] and "cpu_baseline" not in d
-    assert d["roofline"]["kernel"].startswith("igemm_kernel<128, 64")      # R3D-18's layer-1 / stem launches dominate, not <128,128>
+    assert d["roofline"]["kernel"].startswith(("igemm_persist_kernel<128, 64", "igemm_kernel<128, 64"))      # R3D-18's layer-1 / stem launches dominate, not <128,128>
