@@ -73,6 +73,10 @@ def parse_args(argv=None):
                     help="--gpus 1 only: initialise the real nccl (RCCL) process group with ONE rank and run the data-parallel step — "
                          "clip all-to-all, fused key all-gather, bucketed gradient all-reduce, gloo side group — as N > 1 runs it "
                          "(MoCoDiffLossTwoFc(force_collectives=True)); the line carries comm_ms")
+    ap.add_argument("--grad-floor", choices=("static", "live"), default="static",
+                    help="parity block: conditioning floor of the whole gradient on the replayed state = the oracle's own fp32 gradient "
+                         "against its fp64 gradient.  live: recompute it (a 150 s fp64 replay on the CPU); static: take the committed value "
+                         "for this (seeded, hence identical) state from profiles/grad_floor.json after checking an input fingerprint")
     ap.add_argument("--eager-steps", type=int, default=10,
                     help="N=1 graphed runs: also time this many eagerly issued steps (the way N > 1 issues them) after the timed region")
     ap.add_argument("--selftest-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
@@ -159,7 +163,21 @@ def host_cpu():
     return model, max(1, min(len(pairs) or avail, avail))
 
 
-def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
+def _fingerprint(state, im_q, im_k, first):
+    """Cheap identity of what the replayed step consumes (the bench's state and clips are seeded: the same numbers on every box)."""
+    import torch
+    acc = float(im_q.double().sum()) * 3.0 + float(im_k.double().abs().sum())
+    for k in sorted(state):
+        if state[k].dtype == torch.float32:
+            acc += float(state[k].double().abs().sum())
+    perm = first[0].tolist() + first[1][0].tolist() + first[1][1].tolist() + [int(first[2])]
+    h = 0
+    for i, v in enumerate(perm):
+        h = (h * 1000003 + int(v) + i) % (1 << 61)
+    return {"sum": acc, "draws": h}
+
+
+def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None, grad_floor="static"):
     """Oracle restatement timed on this host (reported baseline).  With `parity` = what the GPU's first step consumed and
     produced (bench.py:parity_capture), the untimed warm-up step replays THAT step — same pre-step state, clips, diff-speed
     permutation and shuffle permutations — and the line gets a "parity" object: BASELINE config 2's "loss match vs
@@ -187,8 +205,21 @@ def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
         first = None
     moms = [{}]
     times = []
+    state0_fp = {k: v.clone() for k, v in state.items()} if first is not None else None
     g64 = None
-    if first is not None:
+    static_floor = None
+    if first is not None and grad_floor == "static":
+        fpath = os.path.join(ROOT, "profiles", "grad_floor.json")
+        key = f"{arch}_b{sample_b}_hw{hw}_k{K}"
+        if os.path.exists(fpath):
+            with open(fpath) as f:
+                ent = json.load(f).get(key)
+            fp = _fingerprint(state, im_q, im_k, first)
+            if ent is not None and ent["fingerprint"]["draws"] == fp["draws"] and \
+                    abs(ent["fingerprint"]["sum"] - fp["sum"]) <= 1e-6 * abs(fp["sum"]):
+                static_floor = ent
+    t64 = 0.0
+    if first is not None and static_floor is None:
         # the same replay in fp64 first (on a copy of the pre-step state): the whole gradient has a conditioning floor — ReLU / max-pool
         # decisions flip under fp32 rounding — that is a property of the STATE, not of the kernels; it is measured here as the distance
         # of the oracle's own fp32 gradient from its fp64 gradient, and the GPU's gradient is held against the same fp64 gradient
@@ -231,6 +262,13 @@ def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
             grad_vs_oracle = whole_l2(parity["grads"], o["grads"])
             floor = whole_l2(o["grads"], g64) if g64 is not None else None
             grad_vs_fp64 = whole_l2(parity["grads"], g64) if g64 is not None else None
+            floor_src = "live: fp64 replay of this step on the oracle"
+            if static_floor is not None:
+                floor, floor_src = static_floor["grad_floor_rel_l2"], static_floor["source"]
+            elif g64 is not None:
+                print("bench.py: grad floor entry for profiles/grad_floor.json: " + json.dumps(
+                    {f"{arch}_b{sample_b}_hw{hw}_k{K}": {"grad_floor_rel_l2": floor, "grad_vs_fp64_rel_l2": grad_vs_fp64,
+                                                        "fingerprint": _fingerprint(state0_fp, im_q, im_k, first)}}), file=sys.stderr)
             ptr0 = parity["ptr0"]
             par = {"vs": "oracle/restatement.py:moco_step (pinned to the reference) replaying the GPU run's first step: same "
                          "pre-step state, clips, diff-speed and shuffle permutations",
@@ -242,15 +280,18 @@ def cpu_baseline(arch, hw, sample_b, steps, K, lr, parity=None):
                    "queue_slab_rel": rel(got["queue_slab"], state["queue"][:, ptr0:ptr0 + sample_b]),
                    "grad_rel_l2": grad_vs_oracle,
                    # conditioning floor of this state: oracle fp32 vs oracle fp64; the GPU gradient against the same fp64 gradient
-                   "grad_floor_rel_l2": floor, "grad_vs_fp64_rel_l2": grad_vs_fp64,
-                   "grad_gate": "grad_vs_fp64_rel_l2 <= 2 x grad_floor_rel_l2 + 1e-4 (as close to the fp64 gradient as the reference's own "
-                                "fp32 arithmetic, within a factor 2)", "fp64_replay_s": round(t64, 1) if g64 is not None else None,
+                   "grad_floor_rel_l2": floor, "grad_floor_source": floor_src, "grad_floor_static": static_floor is not None,
+                   "grad_vs_fp64_rel_l2": grad_vs_fp64,
+                   "grad_gate": "grad_rel_l2 <= 3 x grad_floor_rel_l2 — the rule of tests/golden_util.py:grad_tol: two correct fp32 "
+                                "evaluations of this state differ by the floor each from the exact gradient (ReLU / max-pool decisions "
+                                "that flip under rounding), so by up to ~2 floors from one another",
+                   "fp64_replay_s": round(t64, 1) if g64 is not None else None,
                    "loss_gpu": float(got["loss"]), "loss_oracle": float(o["loss"]), "tolerance": 1e-3}
             par = {k: (float(f"{v:.3e}") if isinstance(v, float) and k.endswith(("_rel", "_l2")) else v) for k, v in par.items()}
             par["forward_ok"] = bool(all(par[k] <= 1e-3 for k in ("loss_rel", "loss_A_rel", "loss_M_rel", "logits_rel",
                                                                   "ranking_logits_rel", "features_rel", "queue_slab_rel")))
-            par["grad_ok"] = bool(floor is not None and grad_vs_fp64 is not None and grad_vs_fp64 <= 2.0 * floor + 1e-4)
-            par["ok"] = par["forward_ok"] and par["grad_ok"]
+            par["grad_ok"] = None if floor is None else bool(grad_vs_oracle <= 3.0 * floor)
+            par["ok"] = par["forward_ok"] and par["grad_ok"] is not False
     timed = times[1:] or times
     dt = sum(timed) / len(timed)
     res = {"value": round(sample_b / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": model,
@@ -366,7 +407,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     #  passes on side streams, where a launch's interval also holds its neighbours' time — see the roofline pass below)
     if coll and not graphed:
         inner.comm_log = {}
-    marks, host, hbm = [], [], []
+    marks, host, hbm, waits = [], [], [], []
     if cuda:
         marks.append(torch.cuda.Event(enable_timing=True))
         marks[0].record()
@@ -375,6 +416,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         h0 = time.perf_counter()
         loss = step()[0]
         host.append((time.perf_counter() - h0) * 1e3)       # time the host needs to ENQUEUE a step (it runs ahead of the GPU)
+        waits.append(getattr(stepper, "last_wait_s", 0.0) * 1e3 if stepper is not None else 0.0)
         if cuda:
             marks.append(torch.cuda.Event(enable_timing=True))
             marks[-1].record()
@@ -427,8 +469,11 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         res["steps_ms"] = {"p50": round(_pct(per, 0.5), 3), "min": round(min(per), 3), "max": round(max(per), 3),
                            "p90": round(_pct(per, 0.9), 3), "first": round(per[0], 3),
                            "host_enqueue_p50": round(_pct(host, 0.5), 3), "host_enqueue_max": round(max(host), 3),
-                           "note": "GPU-side step intervals (HIP events on the launch stream at step boundaries); host_enqueue = "
-                                   "host time to issue one step"}
+                           "host_submit_p50": round(_pct([h - w for h, w in zip(host, waits)], 0.5), 3),
+                           "host_backpressure_p50": round(_pct(waits, 0.5), 3),
+                           "note": "GPU-side step intervals (HIP events on the launch stream at step boundaries); host_enqueue = host "
+                                   "time per step() call = host_submit (Python + graph launch) + host_backpressure (the stepper lets the "
+                                   "host run at most 8 steps ahead: waiting there is GPU time, not submission cost)"}
     if comm:
         # per-rank stall of the compute stream behind each collective, ms per step (this rank)
         cm = {}
@@ -646,7 +691,8 @@ def run_rank(args):
     if rank == 0:
         if want_cpu:
             try:
-                cb, par = cpu_baseline(args.arch, hw, args.cpu_sample, args.cpu_steps, m["K"], m["lr"], parity=capture)
+                cb, par = cpu_baseline(args.arch, hw, args.cpu_sample, args.cpu_steps, m["K"], m["lr"], parity=capture,
+                                       grad_floor=args.grad_floor)
                 res["cpu_baseline"] = cb
                 res["vs_cpu_baseline"] = round(res["value"] / cb["value"], 1) if cb["value"] > 0 else None
                 if par is not None:

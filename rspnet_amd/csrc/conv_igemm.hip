@@ -55,16 +55,8 @@ __host__ __device__ inline int k_index(bool slice_major, int tap, int c, int C, 
   return slice_major ? (c >> 5) * (ntaps * 32) + tap * 32 + (c & 31) : tap * C + c;
 }
 
-#ifdef RSP_PHASE_PROBE
-unsigned long long* g_phase_dbg = nullptr;     // tools/phase_probe.py: per-workgroup phase timestamps
-#define PHASE_MARK(i) if (p.dbg) { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) p.dbg[((long long)bid * 4 + (threadIdx.x >> 6)) * 8 + i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define PHASE_MARK(i)
-#endif
+
 struct IgemmParams {
-#ifdef RSP_PHASE_PROBE
-  unsigned long long* dbg;
-#endif
   const float* __restrict__ x;
   const float* __restrict__ w;     // packed [Cout][Kld]
   const float* __restrict__ bias;  // nullable
@@ -107,7 +99,6 @@ struct IgemmParams {
   int dm_dense;                            // dmajor over a dense output grid (forward, stride-1 dgrad): piecewise-linear epilogue
   FastDiv dP;                              // Gh * Gw
   FastDiv dNt;                             // taps per slice (kmajor)
-  int tune;  // ablation bits, honoured only in -DRSP_TUNE builds (tools/conv_bench.py)
 };
 
 inline void fill_fastdiv(IgemmParams& p);
@@ -164,7 +155,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
   long long* rowaddr = reinterpret_cast<long long*>(taptab + p.nTd * p.nTh * p.nTw + 1);  // [BM]
 
   const int t = threadIdx.x;
-  PHASE_MARK(0)
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) become SALU arithmetic
   const int l32 = lane & 31, h = lane >> 5;
@@ -490,14 +480,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#ifdef RSP_TUNE
-  // experiment: start the second workgroup of each CU half a chunk late so that the two co-resident waves of a SIMD
-  // alternate (one in its MFMA burst while the other fetches) instead of running their phases in lockstep
-  if ((p.tune & 16) && ((bid >> 8) & 1)) {
-    const int reps = (p.tune >> 8) & 0xff;
-    for (int i = 0; i < (reps ? reps : 4); ++i) __builtin_amdgcn_s_sleep(16);
-  }
-#endif
   bool have = kc_begin < kc_end;
   if (KS) {
     ks_seek();
@@ -531,7 +513,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     store_chunk(0);
   }
   __syncthreads();   // (with DMA in flight hipcc emits s_waitcnt vmcnt(0) before the barrier: the tile has landed)
-  PHASE_MARK(1)
 
   int buf = 0;
   for (int kc = kc_begin; (KS || tms) ? have : kc < kc_end; ++kc) {
@@ -568,11 +549,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     }
     // 2. next chunk: LDS-DMA (or global loads into registers) in flight under this chunk's MFMAs
     if (nbuf == 1) __syncthreads();   // every wave holds its fragments: the buffer may be overwritten
-#ifdef RSP_TUNE
-    if (more && !(p.tune & 1)) load_chunk((KS || tms) ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
-#else
     if (more) load_chunk((KS || tms) ? ckc : kc + 1, nbuf == 1 ? 0 : buf ^ 1);
-#endif
     if (KS && more) {
       ks_step();
       ks_seek();
@@ -580,10 +557,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     if (tms && more) tm_step();
     if (KS || tms) have = more;
     // 3. 16 k-steps x TM x TN MFMAs
-#ifdef RSP_TUNE
-    if (p.tune & 32) __builtin_amdgcn_s_setprio(1);
-    if (p.tune & 64) __builtin_amdgcn_s_setprio(3);
-#endif
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -593,22 +566,14 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i][e], bf[kk][j][e], acc[i][j], 0, 0, 0);
-#ifdef RSP_TUNE
-    if (p.tune & 96) __builtin_amdgcn_s_setprio(0);
-    if (more && !(p.tune & 2)) store_chunk(buf ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(p.tune & 4)) __syncthreads();
-#else
     if (more) store_chunk(buf ^ 1);
     // keep the wait-for-DMA + barrier BEHIND the MFMAs (hipcc otherwise sinks the register-only MFMAs below it, which
     // exposes the copy latency instead of hiding it under the matrix pipe)
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-#endif
     buf = nbuf == 1 ? 0 : buf ^ 1;
   }
 
-  PHASE_MARK(2)
   // ---- epilogue -------------------------------------------------------------------------------------------
   // GEMM row -> output address.  Forward outputs, stride-1 input gradients and the K-split partials are LINEAR in the row
   // (address = base + row * pitch): plain arithmetic.  The strided parity classes of dgrad go through a per-tile table
@@ -681,9 +646,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int rl = wm * WM + i * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
-#ifdef RSP_TUNE
-            if ((p.tune & 256) && acc[i][j][e] != 12345.f) continue;
-#endif
             if (LIN) {
               if (!CHK || m0 + rl < p.M) lane0[(long long)(i * 32 + (e >> 2) * 8 + (e & 3)) * lin_ld] = acc[i][j][e] + bv;
             } else {
@@ -703,7 +665,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
     else store_tile(std::true_type{}, std::false_type{});
   }
 
-  PHASE_MARK(3)
   if (p.stat && !is_partial) {
     // per-channel (sum, sumsq) of the bias-free conv output per 128-row block; rows >= M contributed zeros.
     constexpr int SB = BM / 128;             // stat blocks per tile
@@ -745,23 +706,10 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid, 
       }
     }
   }
-#ifdef RSP_PHASE_PROBE
-  PHASE_MARK(4)
-  if (p.dbg && (t & 63) == 0) {
-    unsigned long long* o = p.dbg + ((long long)bid * 4 + wave) * 8;
-    o[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
-    o[6] = wall_clock64();
-    o[7] = (unsigned long long)tile | ((unsigned long long)(kc_end - kc_begin) << 32);
-  }
-#endif
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
-#ifdef RSP_PHASE_PROBE
-__global__ __launch_bounds__(256, (BN <= 128 && VEC == 4) ? 3 : MINW) void igemm_kernel(const IgemmParams p) {
-#else
 __global__ __launch_bounds__(256, MINW) void igemm_kernel(const IgemmParams p) {
-#endif
   igemm_body<BM, BN, WAVES_M, WAVES_N, VEC>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // the same tile with the channel-slice-major K walk (LDS-DMA path)
@@ -1619,9 +1567,6 @@ int launch_cfg(const IgemmParams& p, hipStream_t s) {
 // 90-100 % of the MFMA work useful, where 128 + a narrow second launch re-reads A for a few columns (R(2+1)D's 144-channel
 // layers, S3D-G's 96 / 160) and a 128-wide tile for 96 columns wastes a quarter of it.
 inline int tile_bn(int Cout) {
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_ODD_TILES")) return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-#endif
   if (Cout > 128 && Cout <= 160) return 160;
   if (Cout > 64 && Cout <= 96) return 96;
   return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
@@ -1729,9 +1674,6 @@ inline void fill_fastdiv(IgemmParams& p) {
   p.skip_pad = no_skip ? 0 : 1;
   // parts: eight (one per XCD) when each part's frame still spans several tiles, else one
   p.Np = (p.Nb % 8 == 0 && (long long)(p.Nb / 8) * p.Gh * p.Gw >= 4 * 128) ? p.Nb / 8 : (p.Nb > 0 ? p.Nb : 1);
-#ifdef RSP_TUNE
-  if (const char* e = getenv("RSP_DMAJOR_PARTS")) { const int parts = atoi(e); if (parts > 0 && p.Nb % parts == 0) p.Np = p.Nb / parts; }
-#endif
   p.dNp = fastdiv_make(p.Np);
   p.dGdNp = fastdiv_make(p.Gd * p.Np);
   // depth-major rows: slice-major kernels whose depth taps reach into the padding for some output frame
@@ -1761,12 +1703,6 @@ int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;      // the scalar-gather fallback only has the power-of-two tiles
   p.m_tiles = rsp_cdiv(p.M, 128);
   p.n_tiles = rsp_cdiv(p.Cout, bn);
-#ifdef RSP_TUNE
-  if (bn == 128 && vec4 && (p.tune & 8) && p.splitk == 1 && false) {   // experiment: one 256x128 workgroup per CU, 1 wave per SIMD
-    p.m_tiles = rsp_cdiv(p.M, 256);
-    return launch_cfg<256, 128, 2, 2, 4, 1>(p, s);
-  }
-#endif
   if (vec4 && p.kmajor) {
     switch (bn) {
       case 160: return launch_ks_cfg<128, 160, 4, 1>(p, s);
@@ -1799,9 +1735,6 @@ struct SplitPlan {
 // of at least one full 768-tile round: below that the dispatcher packs three workgroups onto some CUs while others idle
 // (392 tiles: +28 % time), and the 64-wide tile loses 9 % to the extra barrier without gaining a workgroup.
 bool single_buffer(int m_tiles, int n_tiles, int bn, bool vec4) {
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_SINGLE")) return false;
-#endif
   return vec4 && (bn == 128 || bn == 96) && (long long)m_tiles * n_tiles >= 768;
 }
 
@@ -1812,6 +1745,9 @@ SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, i
   if (single_buffer(m_tiles, n_tiles, bn, vec4)) wpc = 3;
   const int slots = 256 * wpc;
   SplitPlan best = {tiles, 1, nchunks};
+  static const int no_split = getenv("RSP_NO_SPLIT") ? atoi(getenv("RSP_NO_SPLIT")) : 0;      // (A/B switch for measurements, read once)
+  if (no_split == 1) return best;                                  // never split
+  if (no_split == 2 && tiles >= 256) return best;                  // split only launches of less than one workgroup per CU
   if (nchunks < 8) return best;
   const double t_chunk = 2.35e-6 * wpc * bn / 128.0, t_chunk1 = 2.7e-6 * bn / 128.0;   // measured on the 128x128 tile
   const double ovh = 3.0;   // prologue + epilogue of a unit, in chunk times
@@ -1888,15 +1824,6 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
     return RSP_ELAUNCH;
   }
   p.zero = zero_page;
-#ifdef RSP_PHASE_PROBE
-  p.dbg = g_phase_dbg;
-#endif
-#ifdef RSP_TUNE
-  {
-    const char* e = getenv("RSP_TUNE");
-    p.tune = e ? atoi(e) : 0;
-  }
-#endif
   p.nchunks = rsp_cdiv(p.K, BK);
   fill_fastdiv(p);
   if (!vec4) {      // only the LDS-DMA kernels know the depth-major enumeration and the skipping walks
@@ -1909,24 +1836,6 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
   SplitPlan sp = plan_split(m_tiles, n_tiles, bn, vec4, p.nchunks, p.Cout);
   p.nbuf = single_buffer(m_tiles, n_tiles, bn, vec4) ? 1 : 2;
-#ifdef RSP_TUNE
-  if (p.tune & 4096) sp = {m_tiles * n_tiles, 1, p.nchunks};   // ablation: no tail split
-  if (const char* e = getenv("RSP_SPLIT")) {                    // sweep: force S on the tail (RSP_FULL=0: split every tile)
-    const int S = atoi(e);
-    const char* f = getenv("RSP_FULL");
-    int full = sp.full_tiles == m_tiles * n_tiles ? (m_tiles * n_tiles) / 512 * 512 : sp.full_tiles;
-    if (f && atoi(f) == 0) full = 0;
-    const int cps = rsp_cdiv(p.nchunks, S);
-    sp = {S > 1 ? full : m_tiles * n_tiles, rsp_cdiv(p.nchunks, cps), cps};
-    if (sp.full_tiles >= m_tiles * n_tiles || sp.splitk <= 1) sp = {m_tiles * n_tiles, 1, p.nchunks};
-    static int once = 0;
-    if (!(once++)) fprintf(stderr, "[tune] tiles %d full %d S %d cps %d\n", m_tiles * n_tiles, sp.full_tiles, sp.splitk, sp.cps);
-  } else {
-    static long long last = -1;
-    const long long key = (long long)m_tiles * 1000003 + p.nchunks * 17 + n_tiles;
-    if (key != last) { last = key; fprintf(stderr, "[plan] tiles %d full %d S %d cps %d (nchunks %d)\n", m_tiles * n_tiles, sp.full_tiles, sp.splitk, sp.cps, p.nchunks); }
-  }
-#endif
   if (sp.splitk > 1 && (!workspace || ws_bytes < split_partial_bytes(sp, p.M, n_tiles, p.Cout)))
     sp = {m_tiles * n_tiles, 1, p.nchunks};   // degrade gracefully: still correct
   p.full_tiles = sp.full_tiles;
@@ -1937,7 +1846,10 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   p.y_bytes = out_extent_bytes(p);
   const size_t pbytes = split_partial_bytes(sp, p.M, n_tiles, p.Cout);
   p.partial_bytes = pbytes < 0x7ffffff0ull ? (unsigned)pbytes : 0u;
-  const bool persist = vec4 && persist_enabled() && p.y_bytes != 0 && (p.splitk == 1 || p.partial_bytes != 0);
+  // (the long tap-major 128-wide launches — C3D conv2: 54 chunks per tile — measured 1 % faster on the per-tile kernel; everything
+  //  else equal or better persistent: R3D-18 +2.9 %, R(2+1)D / S3D-G +0.3 % per step, profiles/r04/experiments_r4.txt)
+  const bool long_tm128 = !p.kmajor && bn == 128 && p.nchunks >= 48;
+  const bool persist = vec4 && persist_enabled() && !long_tm128 && p.y_bytes != 0 && (p.splitk == 1 || p.partial_bytes != 0);
   int rc = persist ? launch_persist(p, s) : launch_igemm(p, vec4, s);
   if (rc != RSP_OK) return rc;
   if (p.splitk > 1) {
@@ -1965,9 +1877,6 @@ struct Segments {
 Segments plan_segments(int Cout) {
   Segments g;
   const int full = Cout / 128 * 128, r = Cout - full;
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_SEGMENTS")) return {1, {0, 0}, {Cout, 0}};
-#endif
   if (full == 0 || r == 0 || r > 64 || tile_bn(Cout) == 160) {
     g.n = 1; g.c0[0] = 0; g.width[0] = Cout; g.c0[1] = 0; g.width[1] = 0;
   } else {
@@ -2008,9 +1917,6 @@ size_t igemm_partial_bytes(long long M, int Cout, int K) {
 }
 
 size_t igemm_partial_bytes_segment(long long M, int Cout, int K) {
-#ifdef RSP_TUNE
-  if (getenv("RSP_SPLIT")) return (size_t)16 * M * Cout * sizeof(float);   // room for any forced split
-#endif
   const int bn = tile_bn(Cout), bn_s = (bn == 160 || bn == 96) ? 128 : bn;     // scalar-gather fallback: power-of-two tiles only
   const int m_tiles = rsp_cdiv(M, 128), n_tiles = rsp_cdiv(Cout, bn), n_tiles_s = rsp_cdiv(Cout, bn_s);
   // the gather variant (hence the plan) depends on pointer alignment, unknown here: size for the larger of the two
@@ -2161,9 +2067,6 @@ static bool fill_dgrad_class_params(const rsp_conv3d_desc* d, const DgradClass& 
 
 extern "C" {
 
-#ifdef RSP_PHASE_PROBE
-void rsp_phase_probe_set(unsigned long long* dbg) { g_phase_dbg = dbg; }
-#endif
 
 size_t rsp_conv3d_packed_fwd_elems(const rsp_conv3d_desc* d) {
   if (!desc_ok(d)) return 0;
@@ -2283,7 +2186,17 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   // output addressable with 32-bit offsets: the persistent instances (launch_persist)
   const unsigned long long out_b = which == 0 ? (unsigned long long)d->N * d->Do * d->Ho * d->Wo * d->out_ld * 4ull
                                               : (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
-  if (vec4 && persist_enabled() && out_b < 0x7ffffff0ull) {
+  int kchunks = rsp_cdiv((long long)d->kT * d->kH * d->kW * d->Cin, BK);
+  if (which == 1) {      // the first non-empty stride-parity class (its launch is the one rsp_last_conv_kernel reports)
+    for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
+      const DgradClass g = dgrad_class(d, c);
+      if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+      kchunks = rsp_cdiv((long long)g.nt * g.nh * g.nw * d->Cout, BK);
+      break;
+    }
+  }
+  const bool long_tm128 = !ks && bn == 128 && kchunks >= 48;      // as in run_igemm_segment
+  if (vec4 && persist_enabled() && !long_tm128 && out_b < 0x7ffffff0ull) {
     if (ks) {
       switch (bn) {
         case 160: return "igemm_persist_kernel<128, 160, 4, 1, true, 2>";
@@ -2385,9 +2298,6 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
   // Small classes of a strided convolution share ONE launch (igemm_multi_kernel): every class on the LDS-DMA path, a single
   // column segment, and few enough tiles that separate launches would each leave most of the machine idle.
   bool multi = ncls >= 2 && ncls <= MAX_MULTI && plan_segments(d->Cin).n == 1;
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_MULTI")) multi = false;
-#endif
   long long tiles_all = 0;
   const int bn = tile_bn(d->Cin);
   for (int i = 0; i < ncls && multi; ++i) {

@@ -38,7 +38,6 @@ struct StemParams {
   int tiles_h, tiles_w, tiles;
   unsigned x_bytes, w_bytes;
   int wide;   // epilogue through LDS + 16-byte stores (Cout % 4 == 0, 16-byte aligned output rows and bias)
-  int tune;   // ablation bits, honoured only in -DRSP_TUNE builds
 };
 
 // Wide epilogue store.  A wave's 32 x 64 accumulator tile is column-per-lane (lane = output channel), so a direct store is 32
@@ -393,11 +392,7 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
       for (int e = 0; e < 16; ++e) {
         const long long addr = rowaddr[wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3)];
         const float v = addr >= 0 ? acc[j][e] : 0.f;
-#ifdef RSP_TUNE
-        if (addr >= 0 && col < p.Cout && !((p.tune & 1) && v != 12345.f)) p.y[addr + col] = v + bv;
-#else
         if (addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
-#endif
         s += v;
         ss = fmaf(v, v, ss);
       }
@@ -451,9 +446,6 @@ struct StemPlan {
 StemPlan stem_plan(const rsp_conv3d_desc* d) {
   StemPlan s;
   memset(&s, 0, sizeof s);
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_STEM")) return s;
-#endif
   if (d->Cin != 4 || d->in_ld != 4 || d->Cout > 64 || d->out_ld < d->Cout) return s;
   if (d->sW < 1 || d->sW > 2 || d->sH < 1 || d->sH > 2) return s;
   const int ntaps = d->kT * d->kH * d->kW;
@@ -500,9 +492,6 @@ StemPlan stem_plan(const rsp_conv3d_desc* d) {
   const size_t lds_res = (size_t)2 * d->kT * s.npix_r * 16 + (size_t)s.nchunks * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 +
                          128 * 8 + 2048;
   s.resident = d->kT <= 3 && lds_res <= 78 * 1024;      // two workgroups per CU at least
-#ifdef RSP_TUNE
-  if (getenv("RSP_STEM_STREAM")) s.resident = false;
-#endif
   s.lds = s.resident ? lds_res
                      : (size_t)s.FR * s.npix_r * 16 + (size_t)2 * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 + 128 * 8;
   if (s.lds > 150 * 1024) return s;
@@ -583,14 +572,8 @@ int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed
   // wide epilogue only on the streaming variant, where the idle weight ring is the staging area: in the resident kernel the
   // extra 16 KB of LDS (or the registers of a second epilogue path) cost the third workgroup per CU (C3D conv1: 1.02 -> 1.11 ms)
   p.wide = !pl.resident && d->Cout % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && (!bias || rsp_aligned16(bias));
-#ifdef RSP_TUNE
-  if (getenv("RSP_STEM_NARROW")) p.wide = 0;
-#endif
   p.x_bytes = (unsigned)((unsigned long long)d->N * d->Di * d->Hi * d->Wi * 16ull);
   p.w_bytes = (unsigned)((size_t)pl.nchunks * pl.TCH * 1024);
-#ifdef RSP_TUNE
-  { const char* e = getenv("RSP_TUNE"); p.tune = e ? atoi(e) : 0; }
-#endif
   switch (pl.G) {
     case 8: return launch_stem<8>(p, pl, s);
     case 7: return launch_stem<7>(p, pl, s);

@@ -37,7 +37,6 @@ struct WgradParams {
   FastDiv dP, dGd;                    // rows per frame (Gh * Gw), frames per sample
   int kh0, kh1;                       // k tiles [kh0, kh1) never skip ("full"); the others skip some frames ("short"): wgrad_unit_lpt
   int lpt;                            // full units first (launches of two or more rounds; a single round gains nothing and loses L2 locality)
-  int tune;
 };
 
 // Workgroup -> (slab, tile).  Every (co, k) tile of a row slab reads the slab's dy rows, and tiles of neighbouring taps read the
@@ -51,11 +50,8 @@ struct WgradParams {
 struct WUnit {
   int z, tile;
 };
-__device__ __forceinline__ WUnit wgrad_unit(int L, int nwg, int tiles, int tune) {
+__device__ __forceinline__ WUnit wgrad_unit(int L, int nwg, int tiles) {
   int u = rsp_xcd_remap(L, nwg);
-#ifdef RSP_TUNE
-  if (tune & 8192) u = L;      // A/B: the round-robin deal
-#endif
   WUnit w;
   w.z = u / tiles;
   w.tile = u - w.z * tiles;
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int l32 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const WUnit unit = wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles, p.tune);
+  const WUnit unit = wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles);
   const int tile = unit.tile;
   const int co_tile = tile / p.k_tiles, k_tile = tile - co_tile * p.k_tiles;
   const int co0 = co_tile * BM, k0 = k_tile * BN;
@@ -268,11 +264,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   int buf = 0;
   for (int rb = row_begin; rb < row_end; rb += RK) {
     const bool more = rb + RK < row_end;
-#ifdef RSP_TUNE
-    if (more && !(p.tune & 1)) load_chunk(rb + RK);
-#else
     if (more) load_chunk(rb + RK);
-#endif
     const float* a = At + buf * RK * BM + wm * WM + l32;
     const float* b = Bt + buf * RK * BN + wn * WN + l32;
 #pragma unroll
@@ -288,11 +280,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-#ifdef RSP_TUNE
-    if (more && !(p.tune & 2)) store_chunk(buf ^ 1);
-#else
     if (more) store_chunk(buf ^ 1);
-#endif
     __syncthreads();
     buf ^= 1;
   }
@@ -385,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
 
   const WUnit unit = (p.lpt && p.kh1 > p.kh0 && p.kh1 - p.kh0 < p.k_tiles)
                          ? wgrad_unit_lpt(blockIdx.x, gridDim.x, p.splitm, p.co_tiles, p.k_tiles, p.kh0, p.kh1)
-                         : wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles, p.tune);
+                         : wgrad_unit(blockIdx.x, gridDim.x, p.co_tiles * p.k_tiles);
   const int tile = unit.tile;
   const int co_tile = tile / p.k_tiles, k_tile = tile - co_tile * p.k_tiles;
   const int co0 = co_tile * BM, k0 = k_tile * BN;
@@ -498,14 +486,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
       af[s2] = *reinterpret_cast<const typename FragVec<TM>::type*>(a + (2 * s2 + h) * BM);
       bf[s2] = *reinterpret_cast<const typename FragVec<TN>::type*>(b + (2 * s2 + h) * BN);
     }
-#ifdef RSP_TUNE
-    if (!(p.tune & 512)) fetch_rows(c_fetch, slot_fetch);
-    if (more && !(p.tune & 1024)) issue(c_issue, buf ^ 1);
-#else
     fetch_rows(c_fetch, slot_fetch);
     // 2. next chunk's copies in flight under this chunk's MFMAs
     if (more) issue(c_issue, buf ^ 1);
-#endif
     beside();
     // 3. MFMAs
 #pragma unroll
@@ -516,11 +499,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FragVec<TM>::get(af[s2], i), FragVec<TN>::get(bf[s2], j), acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef RSP_TUNE
-    if (!(p.tune & 2048)) __syncthreads();
-#else
     __syncthreads();
-#endif
     buf ^= 1;
   };
   if (!p.skip_pad) {      // every chunk in turn
@@ -703,13 +682,7 @@ WPlan wplan(const rsp_conv3d_desc* d) {
     const long long lds = 2ll * RK * (w.bm + w.bn) * 4 + 1024;
     const long long slots = 256 * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);   // 128x128: 2 per CU, 64x128: 3, 64x64: 4
     double best = -1.0;
-#ifdef RSP_TUNE
-    const char* e = getenv("RSP_WUNITS");
-    if (e) sp = atoi(e) / tiles > 0 ? atoi(e) / tiles : 1;
-    for (long long c = 1; !e && c <= max_sp && c * tiles <= 8192; ++c) {
-#else
     for (long long c = 1; c <= max_sp && c * tiles <= 8192; ++c) {
-#endif
       const long long units = c * tiles, rounds = (units + slots - 1) / slots;
       const double score = (double)units / (double)(rounds * slots) - 0.004 * (double)rounds;
       if (score > best) {
@@ -759,9 +732,6 @@ WSegs wgrad_segments(const rsp_conv3d_desc* d) {
   WSegs g;
   memset(&g, 0, sizeof g);
   const int C = d->Cout;
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_SEGMENTS")) { g.n = 1; g.width[0] = C; return g; }
-#endif
   int full = C / 128 * 128, r = C - full;
   if (r > 64) { full = C; r = 0; }     // the remainder rides in one more 128-wide tile
   if (full > 0) { g.at[g.n] = 0; g.width[g.n++] = full; }
@@ -914,9 +884,6 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
   WgradParams p;
   memset(&p, 0, sizeof p);
   p.zero = zero_page;
-#ifdef RSP_TUNE
-  { const char* e = getenv("RSP_TUNE"); p.tune = e ? atoi(e) : 0; }
-#endif
   p.x = x; p.dy = dy; p.partial = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + w.rowgeom_bytes);
   p.M = d->N * d->Do * d->Ho * d->Wo;
   p.Gd = d->Do; p.Gh = d->Ho; p.Gw = d->Wo;
@@ -942,9 +909,6 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
   p.dy_bytes = (unsigned)dyb;
   bool dma = va && vb && xb < (1ull << 32) && dyb < (1ull << 32) && d->kT <= 8 && d->kH <= 8 && d->kW <= 8 &&
              (unsigned long long)p.M * sizeof(uint2) < (1ull << 32);   // row-geometry table addressed with 32-bit offsets
-#ifdef RSP_TUNE
-  if (p.tune & 128) dma = false;
-#endif
   int rc;
   if (dma) {
     RowGeomParams g;

@@ -677,9 +677,6 @@ int gate_splits(int P) {
   return s > 64 ? 64 : (s < 1 ? 1 : s);
 }
 bool mp_same333(const rsp_pool3d_desc* d) {
-#ifdef RSP_TUNE
-  if (getenv("RSP_NO_POOL333")) return false;
-#endif
   return d->kT == 3 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 1 && d->pH == 1 && d->pW == 1;
 }
 
@@ -687,9 +684,6 @@ bool mp_same333(const rsp_pool3d_desc* d) {
 // on S3D-G's nine branch pools — 1 / 2 / 3 / 4 / 7 / 14 / 28 — and lose everywhere: the kernels are bound by L1 traffic, not by
 // occupancy (28x28x192 forward 106 / 145 / 125 / 113 / 99 / 72 / 56 us; 14x14x480: 38 / 40 / 38 / 32 / 33 / 20 / 20 us).
 int mp333_seg(const rsp_pool3d_desc* d) {
-#ifdef RSP_TUNE
-  if (const char* e = getenv("RSP_POOL_SEG")) return atoi(e) < d->Wi ? atoi(e) : d->Wi;
-#endif
   return d->Wi;
 }
 

@@ -47,6 +47,7 @@ class GraphedPretextStep:
         self.graphs: Dict[Tuple, Tuple] = {}      # insertion order = least recently used first
         self.eager_steps: Dict[Tuple, int] = {}
         self.static = None
+        self.last_wait_s = 0.0
         self.pool = None                          # one memory pool for all graphs of this stepper: only one replays at a time
         # with the data-parallel collectives on, the step is issued eagerly — same kernels, same side streams (query forward, second
         # key pass, small weight gradients), RCCL on its own stream.  RSP_GRAPH_COLLECTIVES=1 captures the collectives too
@@ -95,8 +96,14 @@ class GraphedPretextStep:
             st["im_k"].copy_(im_k, non_blocking=True)
         slot = st["ring"][st["turn"] % self.RING]
         st["turn"] += 1
+        self.last_wait_s = 0.0
         if slot[1] is not None:
+            # back-pressure: the host may run at most RING steps ahead of the GPU.  The time spent here is the GPU's, not the
+            # host's: `last_wait_s` lets a caller separate it from the submission cost proper (bench.py: steps_ms.host_submit_*)
+            import time
+            t0 = time.perf_counter()
             slot[1].synchronize()
+            self.last_wait_s = time.perf_counter() - t0
         host = m._host_part(B, dev, static=(slot[0], st["dev"]))
         slot[1] = torch.cuda.Event()
         slot[1].record()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-layer conv micro-benchmark (C3D shapes at B=32 by default): TFLOP/s of fwd / dgrad / wgrad launches.
-Usage: python tools/conv_bench.py [--tune BITS] ;  with --tune it loads tools/librspnet_hip_tune.so (ablation build)."""
+Usage: python tools/conv_bench.py [--r21d | --s3dg | --r3d | --stems] [--layers a,b] [--what fwd,dgrad,wgrad]."""
 import argparse
 import os
 import sys
@@ -9,7 +9,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--tune", type=int, default=None)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--what", default="fwd,dgrad,wgrad")
@@ -18,13 +17,7 @@ ap.add_argument("--r3d", action="store_true", help="R3D-18 residual-stage conv s
 ap.add_argument("--r21d", action="store_true", help="R(2+1)D factored conv shapes (mid channels zero-padded to a multiple of 4)")
 ap.add_argument("--s3dg", action="store_true", help="S3D-G conv shapes (B=16 by default for this list)")
 ap.add_argument("--layers", default="", help="comma-separated layer names to keep")
-ap.add_argument("--no-stem-kernel", action="store_true", help="ablation build only: route stems through the implicit-GEMM kernel")
 args = ap.parse_args()
-if args.tune is not None:
-    os.environ["RSPNET_HIP_LIB"] = os.path.join(ROOT, "tools", "librspnet_hip_tune.so")
-    os.environ["RSP_TUNE"] = str(args.tune)
-if args.no_stem_kernel:
-    os.environ["RSP_NO_STEM"] = "1"
 
 import torch
 from rspnet_amd import ops
