@@ -109,6 +109,15 @@ int rsp_conv3d_wgrad(const rsp_conv3d_desc* d, const float* x, const float* dy, 
 int rsp_conv3d_wgrad_v(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, int32_t cout_valid,
                        int32_t cin_valid, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The weight-gradient kernels stream a per-row geometry table (input byte offset + padding-validity bits of each output position:
+ * a function of the geometry alone).  rsp_conv3d_wgrad / _v compute it in a pre-pass of every call; a caller that keeps one table
+ * per geometry (rsp_conv3d_rowgeom_bytes, rsp_conv3d_rowgeom: one launch, once) passes it to rsp_conv3d_wgrad_t and saves that
+ * launch — 59 per S3D-G step.  rowgeom_table may be NULL (then as rsp_conv3d_wgrad_v; dbias only with unpadded channels). */
+size_t rsp_conv3d_rowgeom_bytes(const rsp_conv3d_desc* d);
+int rsp_conv3d_rowgeom(const rsp_conv3d_desc* d, void* table, void* stream);
+int rsp_conv3d_wgrad_t(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, int32_t cout_valid,
+                       int32_t cin_valid, const void* rowgeom_table, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Name of the kernel template instance the library launches for this descriptor (which: 0 forward, 1 dgrad, 2 wgrad;
  * 16-byte aligned tensors assumed) -- lets bench.py label its roofline block with the kernel that actually dominates a
  * backbone and match it to the rocprofv3 kernel-trace row.  Static string, never NULL. */

@@ -81,6 +81,9 @@ SIGNATURES = {
     "rsp_conv3d_wgrad_workspace": (_sz, [_PD]),
     "rsp_conv3d_wgrad": (C.c_int, [_PD, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_conv3d_wgrad_v": (C.c_int, [_PD, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
+    "rsp_conv3d_rowgeom_bytes": (_sz, [_PD]),
+    "rsp_conv3d_rowgeom": (C.c_int, [_PD, _p, _p]),
+    "rsp_conv3d_wgrad_t": (C.c_int, [_PD, _p, _p, _p, _p, _i32, _i32, _p, _p, _sz, _p]),
     "rsp_conv3d_kernel_name": (C.c_char_p, [_PD, C.c_int]),
     "rsp_conv3d_executed_fraction": (C.c_double, [_PD, C.c_int]),
     "rsp_fastdiv_check": (C.c_int, [C.c_int, C.c_int]),

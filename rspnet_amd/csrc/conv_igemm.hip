@@ -1745,9 +1745,6 @@ SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, i
   if (single_buffer(m_tiles, n_tiles, bn, vec4)) wpc = 3;
   const int slots = 256 * wpc;
   SplitPlan best = {tiles, 1, nchunks};
-  static const int no_split = getenv("RSP_NO_SPLIT") ? atoi(getenv("RSP_NO_SPLIT")) : 0;      // (A/B switch for measurements, read once)
-  if (no_split == 1) return best;                                  // never split
-  if (no_split == 2 && tiles >= 256) return best;                  // split only launches of less than one workgroup per CU
   if (nchunks < 8) return best;
   const double t_chunk = 2.35e-6 * wpc * bn / 128.0, t_chunk1 = 2.7e-6 * bn / 128.0;   // measured on the 128x128 tile
   const double ovh = 3.0;   // prologue + epilogue of a unit, in chunk times
@@ -1850,6 +1847,10 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   //  else equal or better persistent: R3D-18 +2.9 %, R(2+1)D / S3D-G +0.3 % per step, profiles/r04/experiments_r4.txt)
   const bool long_tm128 = !p.kmajor && bn == 128 && p.nchunks >= 48;
   const bool persist = vec4 && persist_enabled() && !long_tm128 && p.y_bytes != 0 && (p.splitk == 1 || p.partial_bytes != 0);
+  // the persistent 64-wide tile is compiled for four waves per SIMD (121-128 VGPRs): with ONE tile buffer (24.5 KB) four workgroups
+  // share a CU on launches of at least one such round (R3D-18 +0.5 %, R(2+1)D +0.2 % per step); the per-tile 64-wide kernel, three
+  // per CU either way, lost 9 % to the extra barrier (single_buffer)
+  if (persist && bn == 64 && (long long)m_tiles * n_tiles >= 1024) p.nbuf = 1;
   int rc = persist ? launch_persist(p, s) : launch_igemm(p, vec4, s);
   if (rc != RSP_OK) return rc;
   if (p.splitk > 1) {

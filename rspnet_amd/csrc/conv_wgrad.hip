@@ -781,7 +781,8 @@ WSkip wgrad_skip_plan(const rsp_conv3d_desc* d, const WPlan& w) {
 }
 
 int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
-              size_t workspace_bytes, void* stream, bool rowgeom_ready, int cout_valid, int cin_valid);
+              size_t workspace_bytes, void* stream, bool rowgeom_ready, int cout_valid, int cin_valid, const uint2* ext_rowgeom);
+int rowgeom_fill(const rsp_conv3d_desc* d, void* table, hipStream_t s);
 
 }  // namespace
 
@@ -821,7 +822,7 @@ size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d) {
 }
 
 static int wgrad_all(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, int cout_valid,
-                     int cin_valid, void* workspace, size_t workspace_bytes, void* stream) {
+                     int cin_valid, void* workspace, size_t workspace_bytes, void* stream, const uint2* ext_rowgeom = nullptr) {
   rsp_note_reset();
   // problems over disjoint output-channel ranges; dy keeps its row pitch (out_ld), dw / dbias are contiguous per channel
   const WSegs g = wgrad_segments(d);
@@ -834,7 +835,7 @@ static int wgrad_all(const rsp_conv3d_desc* d, const float* x, const float* dy, 
     cov = cov < 0 ? 0 : (cov > a.Cout ? a.Cout : cov);
     if (cov == 0) continue;
     const int rc = wgrad_one(&a, x, dy + at, dw_ref + at * per_co, dbias ? dbias + at : nullptr, workspace, workspace_bytes, stream,
-                             i > 0, cov, cin_valid);
+                             i > 0, cov, cin_valid, ext_rowgeom);
     if (rc != RSP_OK) return rc;
   }
   return RSP_OK;
@@ -857,12 +858,45 @@ int rsp_conv3d_wgrad_v(const rsp_conv3d_desc* d, const float* x, const float* dy
   return wgrad_all(d, x, dy, dw_ref, nullptr, cout_valid, cin_valid, workspace, workspace_bytes, stream);
 }
 
+// Row-geometry table of a convolution (input byte offset + validity bits per output position; depends on the geometry only, not on
+// channels or data): a caller that keeps it per geometry saves the pre-pass launch of every weight-gradient call.
+size_t rsp_conv3d_rowgeom_bytes(const rsp_conv3d_desc* d) {
+  if (!wdesc_ok(d)) return 0;
+  return (size_t)d->N * d->Do * d->Ho * d->Wo * sizeof(uint2);
+}
+
+int rsp_conv3d_rowgeom(const rsp_conv3d_desc* d, void* table, void* stream) {
+  RSP_REQUIRE(wdesc_ok(d) && table && rsp_aligned16(table), "rsp_conv3d_rowgeom: bad argument");
+  RSP_REQUIRE(d->kT <= 8 && d->kH <= 8 && d->kW <= 8, "rsp_conv3d_rowgeom: kernel dims above 8 take the table-free path");
+  return rowgeom_fill(d, table, (hipStream_t)stream);
+}
+
+int rsp_conv3d_wgrad_t(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, int32_t cout_valid,
+                       int32_t cin_valid, const void* rowgeom_table, void* workspace, size_t workspace_bytes, void* stream) {
+  RSP_REQUIRE(wdesc_ok(d), "rsp_conv3d_wgrad_t: bad descriptor");
+  RSP_REQUIRE(x && dy && dw_ref && workspace, "rsp_conv3d_wgrad_t: null pointer");
+  RSP_REQUIRE(rsp_aligned16(workspace) && (!rowgeom_table || rsp_aligned16(rowgeom_table)), "rsp_conv3d_wgrad_t: workspace / table must be 16-byte aligned");
+  RSP_REQUIRE(cout_valid > 0 && cout_valid <= d->Cout && cin_valid > 0 && cin_valid <= d->Cin, "rsp_conv3d_wgrad_t: bad valid channel counts");
+  RSP_REQUIRE(!dbias || (cout_valid == d->Cout && cin_valid == d->Cin), "rsp_conv3d_wgrad_t: a bias gradient needs unpadded channels");
+  return wgrad_all(d, x, dy, dw_ref, dbias, cout_valid, cin_valid, workspace, workspace_bytes, stream,
+                   reinterpret_cast<const uint2*>(rowgeom_table));
+}
+
 }  // extern "C"
 
 namespace {
 
+int rowgeom_fill(const rsp_conv3d_desc* d, void* table, hipStream_t s) {
+  RowGeomParams g;
+  g.out = reinterpret_cast<uint2*>(table);
+  g.M = d->N * d->Do * d->Ho * d->Wo; g.Gd = d->Do; g.Gh = d->Ho; g.Gw = d->Wo; g.Di = d->Di; g.Hi = d->Hi; g.Wi = d->Wi; g.in_ld = d->in_ld;
+  g.sD = d->sT; g.sH = d->sH; g.sW = d->sW; g.kT = d->kT; g.kH = d->kH; g.kW = d->kW; g.pT = d->pT; g.pH = d->pH; g.pW = d->pW;
+  hipLaunchKernelGGL(rowgeom_kernel, dim3(rsp_cdiv(g.M, 256)), dim3(256), 0, s, g);
+  return rsp_check_launch("rowgeom_kernel");
+}
+
 int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* dw_ref, float* dbias, void* workspace,
-              size_t workspace_bytes, void* stream, bool rowgeom_ready, int cout_valid, int cin_valid) {
+              size_t workspace_bytes, void* stream, bool rowgeom_ready, int cout_valid, int cin_valid, const uint2* ext_rowgeom) {
   const WPlan w = wplan(d);
   if (workspace_bytes < w.partial_bytes + w.colsum_bytes + w.rowgeom_bytes) {
     rsp_set_error("rsp_conv3d_wgrad: workspace too small");
@@ -915,7 +949,9 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
     g.out = reinterpret_cast<uint2*>(workspace);
     g.M = p.M; g.Gd = p.Gd; g.Gh = p.Gh; g.Gw = p.Gw; g.Di = p.Di; g.Hi = p.Hi; g.Wi = p.Wi; g.in_ld = p.in_ld;
     g.sD = p.sD; g.sH = p.sH; g.sW = p.sW; g.kT = p.kT; g.kH = p.kH; g.kW = p.kW; g.pT = p.pT; g.pH = p.pH; g.pW = p.pW;
-    if (!rowgeom_ready) {    // the table depends on the rows only: the output-channel segments of one call share it
+    if (ext_rowgeom) {       // the caller keeps the table of this geometry (rsp_conv3d_rowgeom): nothing to compute per call
+      g.out = const_cast<uint2*>(ext_rowgeom);
+    } else if (!rowgeom_ready) {    // the table depends on the rows only: the output-channel segments of one call share it
       hipLaunchKernelGGL(rowgeom_kernel, dim3(rsp_cdiv(p.M, 256)), dim3(256), 0, s, g);
       rc = rsp_check_launch("rowgeom_kernel");
       if (rc != RSP_OK) return rc;

@@ -175,6 +175,7 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load(init_gpu=True)
         self._ws = {}
+        self._rowgeom = {}      # geometry -> row-geometry table of the weight-gradient kernels (see _rowgeom_table)
         # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name, algorithmic
         # bytes, geometry) per MFMA launch
         # group, recorded on the stream the kernels run on (torch's current stream).
@@ -288,17 +289,30 @@ class HipOps:
         dy_ld = _rows_ld(dy, "dy")                # dy may be a channel slice of a wider gradient tensor
         d, dref, _, _, _, wsb, _, names = _conv_plan(0, g, None, None if dy_ld == g.Cout else dy_ld)
         ws = self._workspace(x.device, wsb)
+        if dw_out.shape[0] > g.Cout or dw_out.shape[1] > g.Cin or (dbias_out is not None and tuple(dw_out.shape[:2]) != (g.Cout, g.Cin)):
+            raise _lib.RspError("conv_wgrad: dw_out has more channels than the geometry, or a bias gradient with padded channels")
+        table = self._rowgeom_table(g, d, dref, x.device)
         e0 = self._ev()
-        if dw_out.shape[0] != g.Cout or dw_out.shape[1] != g.Cin:
-            # the geometry carries zero-padded channels the parameter does not have: their gradients are dropped by the reduce
-            if dbias_out is not None or dw_out.shape[0] > g.Cout or dw_out.shape[1] > g.Cin:
-                raise _lib.RspError("conv_wgrad: dw_out has more channels than the geometry, or a bias gradient with padded channels")
-            _lib.check(self.lib.rsp_conv3d_wgrad_v(dref, _ptr(x), _ptr(dy), _ptr(dw_out), dw_out.shape[0], dw_out.shape[1], _ptr(ws), wsb,
-                                                   _stream()), "rsp_conv3d_wgrad_v")
-        else:
-            _lib.check(self.lib.rsp_conv3d_wgrad(dref, _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), _ptr(ws), wsb,
-                                                 _stream()), "rsp_conv3d_wgrad")
+        # (a geometry with zero-padded channels the parameter does not have: their gradients are dropped by the reduce)
+        _lib.check(self.lib.rsp_conv3d_wgrad_t(dref, _ptr(x), _ptr(dy), _ptr(dw_out), _ptr(dbias_out), dw_out.shape[0], dw_out.shape[1],
+                                               _ptr(table), _ptr(ws), wsb, _stream()), "rsp_conv3d_wgrad_t")
         self._log("conv_wgrad", g, e0, names[2])
+
+    def _rowgeom_table(self, g: ConvGeom, d, dref, dev):
+        """The weight-gradient kernels' per-row geometry table of this geometry (rsp_conv3d_rowgeom): computed once and kept — it
+        depends on the positions only, not on channels or data.  None where the table-free path runs (kernel dims above 8)."""
+        if max(g.k) > 8:
+            return None
+        key = (dev, g.N, g.Di, g.Hi, g.Wi, g.k, g.s, g.p, d.in_ld)
+        t = self._rowgeom.get(key)
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None                    # (first seen inside a capture: this call computes its own, the cache fills on the next eager step)
+            t = torch.empty(int(self.lib.rsp_conv3d_rowgeom_bytes(dref)), dtype=torch.uint8, device=dev)
+            _lib.check(self.lib.rsp_conv3d_rowgeom(dref, _ptr(t), _stream()), "rsp_conv3d_rowgeom")
+            t.record_stream(torch.cuda.current_stream(dev))
+            self._rowgeom[key] = t
+        return t
 
     # ---- batch norm -------------------------------------------------------------------------------------------
     def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,

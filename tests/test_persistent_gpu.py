@@ -1,0 +1,73 @@
+"""GPU: the persistent implicit-GEMM kernels (round 4: resident workgroups walking (tile, K-slice) units, next unit's first chunk copied
+under the last MFMAs, raw-buffer epilogue stores) produce BIT-IDENTICAL outputs to the per-tile kernels they replace — same tiles, same
+K walk, same accumulation order — for forward (+ BatchNorm partials) and input gradient over the tile widths, both K orders, strided
+classes, depth-major rows, K tails, column segments and K-split tails.  The per-tile kernels run in a child interpreter with
+RSP_NO_PERSIST=1 (the switch is read once per process).  Reference call sites: nn.Conv3d forward / backward-input of every backbone
+(models/c3d.py:21-52, models/resnet.py:48-77, models/r2plus1d_vcop.py:49-67, models/s3dg.py:36-52)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "bn32_tm": (2, 4, 12, 12, 32, 24, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "bn64_ks_depth_major": (4, 8, 28, 28, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "bn64_strided": (2, 4, 12, 12, 64, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    "bn128_segment_ktail": (3, 3, 18, 21, 8, 130, (3, 1, 7), (1, 1, 2), (1, 0, 2)),
+    "bn96_strided_ktail": (2, 3, 18, 10, 20, 96, (3, 3, 1), (2, 2, 1), (1, 1, 0)),
+    "piecewise_short_frames": (16, 4, 19, 11, 128, 32, (3, 1, 3), (1, 1, 1), (1, 0, 0)),
+    "one_chunk": (8, 3, 7, 21, 4, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    "bn160": (4, 4, 14, 14, 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "ksplit_tail": (32, 2, 7, 7, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "many_units_per_workgroup": (32, 8, 56, 56, 32, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+}
+
+
+def _child(path):
+    sys.path.insert(0, ROOT)
+    from rspnet_amd import ops
+    from rspnet_amd.ops import ConvGeom
+    be = ops.backend()
+    dev = torch.device("cuda", 0)
+    out = {}
+    for name, (N, D, H, W, cin, cout, k, s, p) in CASES.items():
+        g = ConvGeom(N, D, H, W, cin, cout, k, s, p)
+        gen = torch.Generator(device=dev).manual_seed(7)
+        x = torch.randn(N, D, H, W, cin, device=dev, generator=gen)
+        w = torch.randn(cout, cin, *k, device=dev, generator=gen) * 0.05
+        b = torch.randn(cout, device=dev, generator=gen)
+        dy = torch.randn(N, *g.out_dims, cout, device=dev, generator=gen)
+        torch.full((1 << 22,), 7.0, device=dev)                     # stale memory is recognisable
+        y, st = be.conv_fwd(g, x, be.conv_pack_fwd(g, w), b, True)
+        kf = be.lib.rsp_last_conv_kernel().decode()
+        dx = be.conv_dgrad(g, dy, w)
+        out[name] = (y.cpu(), st.cpu(), dx.cpu(), kf, be.lib.rsp_last_conv_kernel().decode())
+    torch.save(out, path)
+
+
+def test_persistent_kernels_equal_the_per_tile_kernels_bit_for_bit(tmp_path):
+    res = {}
+    for mode in ("persistent", "per_tile"):
+        env = dict(os.environ)
+        env.pop("RSP_NO_PERSIST", None)
+        if mode == "per_tile":
+            env["RSP_NO_PERSIST"] = "1"
+        f = str(tmp_path / f"{mode}.pt")
+        subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
+                                              f"import test_persistent_gpu as t; t._child({f!r})"], env=env, check=True, cwd=ROOT)
+        res[mode] = torch.load(f)
+    ran_persistent = 0
+    for name in CASES:
+        yp, sp, dp, kfp, kdp = res["persistent"][name]
+        yc, sc, dc, kfc, kdc = res["per_tile"][name]
+        assert "persist" not in kfc and "persist" not in kdc, (name, kfc, kdc)
+        ran_persistent += ("persist" in kfp) + ("persist" in kdp)
+        assert torch.equal(yp, yc), (name, "forward", kfp, float((yp - yc).abs().max()))
+        assert torch.equal(sp, sc), (name, "BatchNorm partials", kfp)
+        assert torch.equal(dp, dc), (name, "input gradient", kdp, float((dp - dc).abs().max()))
+    assert ran_persistent >= 16, ran_persistent      # (the long tap-major 128-wide launches and multi-class dgrads stay per-tile)

@@ -78,7 +78,7 @@ for arch, B in BATCH.items():
             if act > 0:
                 busy = f"{mfma[0][k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (act * 1024.0):.3f}"
         lines.append(f"{k:60s} {n:6d}  {fb / 1e6:12.2f}  {wb / 1e6:12.2f}  {(fb + wb) / 1e6:12.2f}  {busy}")
-        if any(s in k for s in ("igemm_kernel", "igemm_ks_kernel", "igemm_multi_kernel", "wgrad_dma_kernel", "wgrad_kernel", "stem_")):
+        if any(s in k for s in ("igemm_kernel", "igemm_ks_kernel", "igemm_persist_kernel", "igemm_multi_kernel", "wgrad_dma_kernel", "wgrad_kernel", "stem_")):
             ent[k] = {"launches_profiled": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                       "hbm_bytes_per_launch": fb + wb, "mfma_busy": float(busy) if busy else None,
                       "source": f"profiles/{rnd}/pmc_by_kernel_{arch}_b{B}_{tag}.txt"}
