@@ -25,6 +25,10 @@ CASES = {
     "bn160": (4, 4, 14, 14, 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     "ksplit_tail": (32, 2, 7, 7, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "many_units_per_workgroup": (32, 8, 56, 56, 32, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "ksplit_r3d_layer2": (32, 4, 14, 14, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "ksplit_s3dg_pointwise": (16, 4, 14, 14, 480, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    "ksplit_s3dg_sep": (16, 4, 14, 14, 160, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "ksplit_c3d_conv5": (32, 2, 7, 7, 512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 }
 
 
@@ -71,3 +75,28 @@ def test_persistent_kernels_equal_the_per_tile_kernels_bit_for_bit(tmp_path):
         assert torch.equal(sp, sc), (name, "BatchNorm partials", kfp)
         assert torch.equal(dp, dc), (name, "input gradient", kdp, float((dp - dc).abs().max()))
     assert ran_persistent >= 16, ran_persistent      # (the long tap-major 128-wide launches and multi-class dgrads stay per-tile)
+
+
+def test_k_split_layers_are_run_to_run_identical():
+    """K-split tail tiles (their slices summed in fixed order by splitk_reduce_vec_kernel) through the persistent kernels: 60 launches of
+    R3D-18 layers 2 / 3, an S3D-G separable unit and C3D conv5 must give the same bits every time, forward and input gradient."""
+    sys.path.insert(0, ROOT)
+    from rspnet_amd import ops
+    from rspnet_amd.ops import ConvGeom
+    be = ops.backend()
+    dev = torch.device("cuda", 0)
+    for name in ("ksplit_tail", "ksplit_s3dg_sep", "ksplit_c3d_conv5", "ksplit_r3d_layer2"):
+        N, D, H, W, cin, cout, k, s, p = CASES[name]
+        g = ConvGeom(N, D, H, W, cin, cout, k, s, p)
+        gen = torch.Generator(device=dev).manual_seed(11)
+        x = torch.randn(N, D, H, W, cin, device=dev, generator=gen)
+        w = torch.randn(cout, cin, *k, device=dev, generator=gen) * 0.05
+        dy = torch.randn(N, *g.out_dims, cout, device=dev, generator=gen)
+        wp = be.conv_pack_fwd(g, w)
+        y0, st0 = be.conv_fwd(g, x, wp, None, True)
+        dx0 = be.conv_dgrad(g, dy, w)
+        for it in range(60):
+            torch.full((1 << 20,), float(it), device=dev)            # churn the allocator: fresh workspace contents
+            y, st = be.conv_fwd(g, x, wp, None, True)
+            dx = be.conv_dgrad(g, dy, w)
+            assert torch.equal(y, y0) and torch.equal(st, st0) and torch.equal(dx, dx0), (name, it)
