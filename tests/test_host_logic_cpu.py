@@ -105,3 +105,33 @@ def test_gate_fusion_table_and_the_unfused_path(cpu_backend, monkeypatch):
         if g is not None:
             ref = grads_fused[k]
             assert float(np.abs(g - ref).max()) <= 1e-5 * max(float(np.abs(ref).max()), 1e-6), k
+
+
+def test_queue_pointer_must_be_a_multiple_of_the_global_batch():
+    """A queue pointer that is not a multiple of the enqueue size (a checkpoint saved with another batch / world size) makes the
+    reference's slice assignment fail (builder_diffspeed_diffloss.py:353-356).  The device-side enqueue of graph-captured steps would
+    silently drop the slab instead, so the pointer is validated on the host once per loaded state."""
+    import pytest
+    from model_util import make_cfg
+    from rspnet_amd.moco import ModelFactory
+    m = ModelFactory(make_cfg("c3d", 64)).build_moco_diffloss(device=torch.device("cpu")).module
+    m.queue_ptr.fill_(8)
+    m._check_queue_ptr(4)
+    assert m._ptr_checked
+    m.queue_ptr.fill_(6)
+    m._ptr_checked = False
+    with pytest.raises(ValueError, match="not a multiple of the global batch"):
+        m._check_queue_ptr(4)
+    sd = m.state_dict()
+    m._ptr_checked = True
+    m.load_state_dict(sd)                       # a loaded state is unchecked again
+    assert m._ptr_checked is False
+
+
+def test_launcher_refuses_to_start_without_a_visible_gpu(monkeypatch):
+    """pretrain's world size comes from a child interpreter's torch.cuda.device_count() (what a rank will see); zero GPUs is an
+    error, not a silent single-rank run."""
+    import pytest
+    from rspnet_amd import pretrain
+    with pytest.raises(EnvironmentError, match="no GPU is visible"):
+        pretrain.visible_gpu_count()
