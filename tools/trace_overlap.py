@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """How busy is the GPU inside a replayed step?  Reads a rocprofv3 --kernel-trace CSV of `bench.py --arch A --steps N` and reports, for the
 last steps: wall time per step, the union of kernel intervals, time with exactly 1 / 2 / >= 3 kernels in flight, and which kernels
-run ALONE longest (the serial part of the step's dependency graph).  Usage: python tools/trace_overlap.py <kernel_trace.csv> [steps]"""
+run ALONE longest.  CAVEAT (measured, r4t): under rocprofv3 --kernel-trace the dispatches of a replayed graph are SERIALISED — never two
+kernels in flight, S3D-G 60.8 ms per step instead of 40 — so this shows the serial kernel sum and the per-dispatch gap (~8 us), not
+the overlap of an unprofiled run.  Usage: python tools/trace_overlap.py <kernel_trace.csv> [steps]"""
 import collections
 import csv
 import sys
