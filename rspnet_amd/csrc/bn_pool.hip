@@ -279,6 +279,46 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p
   load_vec<VEC>(p.ss + c, sc);
   load_vec<VEC>(p.ss + d.C + c, sh);
   const bool unit = d.kT * d.kH * d.kW == 1 && d.sT == 1 && d.sH == 1 && d.sW == 1 && !(d.pT | d.pH | d.pW);   // no pooling
+  if (unit && !p.gate) {
+    // plain streaming form, four positions per trip: the loads of a trip are independent, so a thread keeps 64-128 B in flight
+    // instead of 16-32 (at full occupancy one float4 per thread is 8 MB in flight on the chip — under the ~12 MB that 6 TB/s x 2 us
+    // need), and the four are CONSECUTIVE position groups: a block touches 16 KB contiguous per trip (4.9-5.2 -> 5.4-6.0 TB/s forward, 4.4-4.9 -> 5.1-5.5 backward on the big tensors, tools/bn_bw_probe.py; torch.mul streams 6.0 here)
+    const long long step = p.ppi;                              // positions between a thread's four loads of one trip
+    const long long stride = (long long)gridDim.x * p.ppi * 4;  // ... and between trips
+    long long o = (long long)blockIdx.x * p.ppi * 4 + pl;
+    for (; o + 3 * step < p.npos; o += stride) {
+      float v[4][VEC], r[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        load_vec<VEC>(p.y + (o + u * step) * d.in_ld + c, v[u]);
+        if (p.res) load_vec<VEC>(p.res + (o + u * step) * d.res_ld + c, r[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float best[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float z = fmaf(v[u][e], sc[e], sh[e]);
+          if (p.res) z += r[u][e];
+          best[e] = p.relu ? fmaxf(z, 0.f) : z;
+        }
+        store_vec<VEC>(p.out + (o + u * step) * d.out_ld + c, best);
+      }
+    }
+    for (int u = 0; u < 4 && o < p.npos; ++u, o += step) {      // the last, partial group of four
+      float v[VEC], r[VEC], best[VEC];
+      load_vec<VEC>(p.y + o * d.in_ld + c, v);
+      if (p.res) load_vec<VEC>(p.res + o * d.res_ld + c, r);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float z = fmaf(v[e], sc[e], sh[e]);
+        if (p.res) z += r[e];
+        best[e] = p.relu ? fmaxf(z, 0.f) : z;
+      }
+      store_vec<VEC>(p.out + o * d.out_ld + c, best);
+    }
+    return;
+  }
   for (long long o = (long long)blockIdx.x * p.ppi + pl; o < p.npos; o += (long long)gridDim.x * p.ppi) {
     float best[VEC];
     if (unit) {
@@ -424,7 +464,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
     load_vec<VEC>(p.mi + c, mean);
     load_vec<VEC>(p.mi + d.C + c, invstd);
     const long long npos = (long long)d.N * d.Do * d.Ho * d.Wo;
-    for (long long op = (long long)blockIdx.x * ppi + pl; op < npos; op += (long long)gridDim.x * ppi) {
+    long long op = (long long)blockIdx.x * ppi + pl;
+    long long stride = (long long)gridDim.x * ppi;
+    if (d.kT * d.kH * d.kW == 1 && !p.gate) {
+      // no pooling, no gate: the position is its own window.  Four consecutive position groups per trip with all their loads issued
+      // first (see bn_act_pool_fwd_kernel: 16 KB contiguous per block and trip); fixed accumulation order per thread.
+      const long long step = ppi;
+      stride *= 4;
+      op = (long long)blockIdx.x * ppi * 4 + pl;
+      for (; op + 3 * step < npos; op += stride) {
+        float yv[4][VEC], r[4][VEC], g[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          load_vec<VEC>(p.y + (op + u * step) * d.in_ld + c, yv[u]);
+          if (p.res) load_vec<VEC>(p.res + (op + u * step) * d.res_ld + c, r[u]);
+          load_vec<VEC>(p.dout + (op + u * step) * d.out_ld + c, g[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float z = fmaf(yv[u][e], sc[e], sh[e]);
+            if (p.res) z += r[u][e];
+            const float zz = p.relu ? fmaxf(z, 0.f) : z;
+            const float dz = (p.relu && !(zz > 0.f)) ? 0.f : g[u][e];
+            s1[e] += dz;
+            s2[e] = fmaf(dz, (yv[u][e] - mean[e]) * invstd[e], s2[e]);
+          }
+      }
+      stride = step;                          // the last, partial group of four: one position group at a time
+    }
+    const long long op_end = (d.kT * d.kH * d.kW == 1 && !p.gate) ? min(npos, op + 4 * (long long)ppi) : npos;
+    for (; op < op_end; op += stride) {
       const int q1 = fastdiv((int)op, p.dWo), ow = (int)op - q1 * d.Wo;
       const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
       const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
@@ -587,7 +658,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p
     m1[e] = (float)(p.sums[2 * (c + e)] * invn);
     m2[e] = (float)(p.sums[2 * (c + e) + 1] * invn);
   }
-  for (long long o = (long long)blockIdx.x * p.ppi + pl; o < p.npos; o += (long long)gridDim.x * p.ppi) {
+  long long o = (long long)blockIdx.x * p.ppi + pl;
+  long long stride = (long long)gridDim.x * p.ppi;
+  long long o_end = p.npos;
+  if (nwin == 1 && !p.gate) {
+    // no pooling, no gate: four consecutive position groups per trip, loads first (see bn_act_pool_fwd_kernel)
+    const long long step = p.ppi;
+    stride *= 4;
+    o = (long long)blockIdx.x * p.ppi * 4 + pl;
+    for (; o + 3 * step < p.npos; o += stride) {
+      float yv[4][VEC], r[4][VEC], g[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        load_vec<VEC>(p.y + (o + u * step) * d.in_ld + c, yv[u]);
+        if (p.res) load_vec<VEC>(p.res + (o + u * step) * d.res_ld + c, r[u]);
+        load_vec<VEC>(p.dout + (o + u * step) * d.out_ld + c, g[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float ov[VEC], dz[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float z = fmaf(yv[u][e], sc[e], sh[e]);
+          if (p.res) z += r[u][e];
+          dz[e] = (p.relu && !(z > 0.f)) ? 0.f : g[u][e];
+          const float xhat = (yv[u][e] - mean[e]) * invstd[e];
+          ov[e] = gam[e] * invstd[e] * (dz[e] - m1[e] - xhat * m2[e]);
+        }
+        store_vec<VEC>(p.dy + (o + u * step) * d.in_ld + c, ov);
+        if (p.dres) store_vec<VEC>(p.dres + (o + u * step) * d.res_ld + c, dz);
+      }
+    }
+    stride = step;                            // the last, partial group of four: one position group at a time
+    o_end = min(p.npos, o + 4 * step);
+  }
+  for (; o < o_end; o += stride) {
     float g[VEC];
     load_vec<VEC>(p.dout + o * d.out_ld + c, g);
     if (nwin == 1) {
