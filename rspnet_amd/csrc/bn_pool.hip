@@ -267,7 +267,26 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   }
 }
 
-template <int VEC>
+// disjoint windows without padding: every window position of every output is in bounds
+__device__ __forceinline__ bool windows_tile(const rsp_pool3d_desc& d) {
+  return d.kT == d.sT && d.kH == d.sH && d.kW == d.sW && !(d.pT | d.pH | d.pW);
+}
+
+// offsets (in positions) of the NW window positions from the window's first one, scan order (kt, kh, kw)
+template <int NW>
+__device__ __forceinline__ void window_offsets(const rsp_pool3d_desc& d, long long (&off)[NW]) {
+  int kw = 0, kh = 0, kt = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    off[w] = ((long long)kt * d.Hi + kh) * d.Wi + kw;
+    if (++kw == d.kW) { kw = 0; if (++kh == d.kH) { kh = 0; ++kt; } }
+  }
+}
+
+// MODE picks the body at compile time so that each keeps its own register allocation (one kernel holding all of them ran the streaming
+// body at the 8-window body's occupancy): 0 generic windows (padding, overlap, gates), 1 no pooling and no gate (pure streaming),
+// 2 / 3 disjoint un-padded windows of 4 / 8 positions.  bn_mode() on the host applies the same conditions.
+template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p) {
   const rsp_pool3d_desc& d = p.d;
   const int t = threadIdx.x;
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p
   load_vec<VEC>(p.ss + c, sc);
   load_vec<VEC>(p.ss + d.C + c, sh);
   const bool unit = d.kT * d.kH * d.kW == 1 && d.sT == 1 && d.sH == 1 && d.sW == 1 && !(d.pT | d.pH | d.pW);   // no pooling
-  if (unit && !p.gate) {
+  if constexpr (MODE == 1) {
     // plain streaming form, four positions per trip: the loads of a trip are independent, so a thread keeps 64-128 B in flight
     // instead of 16-32 (at full occupancy one float4 per thread is 8 MB in flight on the chip — under the ~12 MB that 6 TB/s x 2 us
     // need), and the four are CONSECUTIVE position groups: a block touches 16 KB contiguous per trip (4.9-5.2 -> 5.4-6.0 TB/s forward, 4.4-4.9 -> 5.1-5.5 backward on the big tensors, tools/bn_bw_probe.py; torch.mul streams 6.0 here)
@@ -316,6 +335,44 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const PoolParams p
         best[e] = p.relu ? fmaxf(z, 0.f) : z;
       }
       store_vec<VEC>(p.out + o * d.out_ld + c, best);
+    }
+    return;
+  }
+  if constexpr (MODE == 2 || MODE == 3) {
+    // disjoint un-padded windows of 4 or 8 positions (C3D's pools): every window load of an output is issued before the first
+    // compare — 64-128 B (x2 with a residual) in flight per thread instead of one float4 behind each bounds check.  Measured
+    // (tools/bn_bw_probe.py, C3D conv1 / conv2 + pool): the backward pair 4.2-4.7 -> 5.2-5.3 TB/s, this forward kernel unchanged at 5.0-5.1
+    {
+      constexpr int NW = MODE == 2 ? 4 : 8;
+      long long off[NW];                                       // wave-uniform offsets of the window positions, scan order
+      window_offsets<NW>(d, off);
+      for (long long o = (long long)blockIdx.x * p.ppi + pl; o < p.npos; o += (long long)gridDim.x * p.ppi) {
+        const int op = (int)o;
+        const int q1 = fastdiv(op, p.dWo), ow = op - q1 * d.Wo;
+        const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
+        const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
+        const long long base = (((long long)n * d.Di + od * d.sT) * d.Hi + oh * d.sH) * d.Wi + ow * d.sW;
+        float v[NW][VEC], r[NW][VEC], g[VEC], best[VEC];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          load_vec<VEC>(p.y + (base + off[w]) * d.in_ld + c, v[w]);
+          if (p.res) load_vec<VEC>(p.res + (base + off[w]) * d.res_ld + c, r[w]);
+        }
+        if (p.gate) load_vec<VEC>(p.gate + (long long)n * d.C + c, g);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) best[e] = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float z = fmaf(v[w][e], sc[e], sh[e]);
+            if (p.res) z += r[w][e];
+            if (p.relu) z = fmaxf(z, 0.f);
+            if (p.gate) z *= g[e];
+            best[e] = fmaxf(best[e], z);
+          }
+        store_vec<VEC>(p.out + o * d.out_ld + c, best);
+      }
     }
     return;
   }
@@ -442,7 +499,7 @@ __device__ __forceinline__ void zval(const BwdParams& p, long long pos, int c, c
 }
 
 // pass 1: output-centric.  For each pooled output: arg-max (first max in scan order, like max_pool3d), dz = dout*mask.
-template <int VEC>
+template <int VEC, int MODE>      // MODE: see bn_act_pool_fwd_kernel
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
   const rsp_pool3d_desc& d = p.d;
   __shared__ float red[256][2 * VEC];
@@ -466,7 +523,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
     const long long npos = (long long)d.N * d.Do * d.Ho * d.Wo;
     long long op = (long long)blockIdx.x * ppi + pl;
     long long stride = (long long)gridDim.x * ppi;
-    if (d.kT * d.kH * d.kW == 1 && !p.gate) {
+    if constexpr (MODE == 1) {
       // no pooling, no gate: the position is its own window.  Four consecutive position groups per trip with all their loads issued
       // first (see bn_act_pool_fwd_kernel: 16 KB contiguous per block and trip); fixed accumulation order per thread.
       const long long step = ppi;
@@ -494,7 +551,46 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
       }
       stride = step;                          // the last, partial group of four: one position group at a time
     }
-    const long long op_end = (d.kT * d.kH * d.kW == 1 && !p.gate) ? min(npos, op + 4 * (long long)ppi) : npos;
+    long long op_end = MODE == 1 ? min(npos, op + 4 * (long long)ppi) : npos;
+    if constexpr (MODE == 2 || MODE == 3) {
+      // disjoint un-padded windows of 4 or 8 positions: all loads of an output first (see bn_act_pool_fwd_kernel), same scan order
+      {
+        constexpr int NW = MODE == 2 ? 4 : 8;
+        long long off[NW];
+        window_offsets<NW>(d, off);
+        for (; op < npos; op += stride) {
+          const int q1 = fastdiv((int)op, p.dWo), ow = (int)op - q1 * d.Wo;
+          const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
+          const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
+          const long long base = (((long long)n * d.Di + od * d.sT) * d.Hi + oh * d.sH) * d.Wi + ow * d.sW;
+          float yv[NW][VEC], r[NW][VEC], g[VEC], best[VEC], by[VEC];
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            load_vec<VEC>(p.y + (base + off[w]) * d.in_ld + c, yv[w]);
+            if (p.res) load_vec<VEC>(p.res + (base + off[w]) * d.res_ld + c, r[w]);
+          }
+          load_vec<VEC>(p.dout + op * d.out_ld + c, g);           // (a gated unit never pools: rsp_bn_act_pool_bwd)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; by[e] = 0.f; }
+#pragma unroll
+          for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              float z = fmaf(yv[w][e], sc[e], sh[e]);
+              if (p.res) z += r[w][e];
+              const float zz = p.relu ? fmaxf(z, 0.f) : z;
+              if (zz > best[e]) { best[e] = zz; by[e] = yv[w][e]; }
+            }
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float dz = (p.relu && !(best[e] > 0.f)) ? 0.f : g[e];
+            s1[e] += dz;
+            s2[e] = fmaf(dz, (by[e] - mean[e]) * invstd[e], s2[e]);
+          }
+        }
+      }
+      op_end = 0;
+    }
     for (; op < op_end; op += stride) {
       const int q1 = fastdiv((int)op, p.dWo), ow = (int)op - q1 * d.Wo;
       const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
@@ -635,7 +731,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
 // pass 2, output-centric fast path: windows tile the input exactly (Di % sT == 0 ...) and hold <= 8 positions, so one
 // thread owns a whole window: every y element is read once and every dy element written once (the input-centric
 // kernel above re-reads the window for every element).
-template <int VEC>
+template <int VEC, int MODE>      // MODE: see bn_act_pool_fwd_kernel (0 here: unit windows with a gate, or 2-7 positions)
 __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p) {
   const rsp_pool3d_desc& d = p.d;
   const int t = threadIdx.x;
@@ -661,7 +757,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p
   long long o = (long long)blockIdx.x * p.ppi + pl;
   long long stride = (long long)gridDim.x * p.ppi;
   long long o_end = p.npos;
-  if (nwin == 1 && !p.gate) {
+  if constexpr (MODE == 1) {
     // no pooling, no gate: four consecutive position groups per trip, loads first (see bn_act_pool_fwd_kernel)
     const long long step = p.ppi;
     stride *= 4;
@@ -692,10 +788,57 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BwdParams p
     stride = step;                            // the last, partial group of four: one position group at a time
     o_end = min(p.npos, o + 4 * step);
   }
+  if constexpr (MODE == 2 || MODE == 3) {
+    // whole windows of 4 or 8 positions (the launcher guarantees exact tiling): loads first, then arg-max, then the stores
+    {
+      constexpr int NW = MODE == 2 ? 4 : 8;
+      long long off[NW];
+      window_offsets<NW>(d, off);
+      for (; o < o_end; o += stride) {
+        const int op = (int)o;
+        const int q1 = fastdiv(op, p.dWo), ow = op - q1 * d.Wo;
+        const int q2 = fastdiv(q1, p.dHo), oh = q1 - q2 * d.Ho;
+        const int n = fastdiv(q2, p.dDo), od = q2 - n * d.Do;
+        const long long base = (((long long)n * d.Di + od * d.sT) * d.Hi + oh * d.sH) * d.Wi + ow * d.sW;
+        float yv[NW][VEC], r[NW][VEC], g[VEC], best[VEC];
+        int bi[VEC];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          load_vec<VEC>(p.y + (base + off[w]) * d.in_ld + c, yv[w]);
+          if (p.res) load_vec<VEC>(p.res + (base + off[w]) * d.res_ld + c, r[w]);
+        }
+        load_vec<VEC>(p.dout + o * d.out_ld + c, g);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float z = fmaf(yv[w][e], sc[e], sh[e]);
+            if (p.res) z += r[w][e];
+            const float v = p.relu ? fmaxf(z, 0.f) : z;
+            if (v > best[e]) { best[e] = v; bi[e] = w; }        // first maximum in scan order
+          }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          float ov[VEC], dz[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            dz[e] = (bi[e] == w && !(p.relu && !(best[e] > 0.f))) ? g[e] : 0.f;
+            const float xhat = (yv[w][e] - mean[e]) * invstd[e];
+            ov[e] = gam[e] * invstd[e] * (dz[e] - m1[e] - xhat * m2[e]);
+          }
+          store_vec<VEC>(p.dy + (base + off[w]) * d.in_ld + c, ov);
+          if (p.dres) store_vec<VEC>(p.dres + (base + off[w]) * d.res_ld + c, dz);
+        }
+      }
+    }
+    return;
+  }
   for (; o < o_end; o += stride) {
     float g[VEC];
     load_vec<VEC>(p.dout + o * d.out_ld + c, g);
-    if (nwin == 1) {
+    if (MODE == 1 || nwin == 1) {
       // no pooling: the position is its own window
       if (p.gate) gated_grad<VEC>(p, fastdiv(fastdiv(fastdiv((int)o, p.dWo), p.dHo), p.dDo), c, g);
       float yv[VEC], z[VEC], ov[VEC], dz[VEC];
@@ -767,6 +910,30 @@ bool pool_ok(const rsp_pool3d_desc* d, bool need_disjoint) {
   }
   return true;
 }
+
+// body of the three pooling-aware kernels for this window shape (their MODE template argument)
+int bn_mode(const rsp_pool3d_desc* d, bool gated) {
+  const int nwin = d->kT * d->kH * d->kW;
+  const bool unit = nwin == 1 && d->sT == 1 && d->sH == 1 && d->sW == 1 && !(d->pT | d->pH | d->pW);
+  if (unit) return gated ? 0 : 1;
+  const bool tile = d->kT == d->sT && d->kH == d->sH && d->kW == d->sW && !(d->pT | d->pH | d->pW);
+  return tile && nwin == 4 ? 2 : (tile && nwin == 8 ? 3 : 0);
+}
+
+#define RSP_BN_LAUNCH_V(K, V, mode, grid, stream, p)                                                   \
+  do {                                                                                                 \
+    switch (mode) {                                                                                    \
+      case 1: hipLaunchKernelGGL((K<V, 1>), grid, dim3(256), 0, stream, p); break;                     \
+      case 2: hipLaunchKernelGGL((K<V, 2>), grid, dim3(256), 0, stream, p); break;                     \
+      case 3: hipLaunchKernelGGL((K<V, 3>), grid, dim3(256), 0, stream, p); break;                     \
+      default: hipLaunchKernelGGL((K<V, 0>), grid, dim3(256), 0, stream, p); break;                    \
+    }                                                                                                  \
+  } while (0)
+#define RSP_BN_LAUNCH(K, vec, mode, grid, stream, p)                                                   \
+  do {                                                                                                 \
+    if (vec) RSP_BN_LAUNCH_V(K, 4, mode, grid, stream, p);                                             \
+    else RSP_BN_LAUNCH_V(K, 1, mode, grid, stream, p);                                                 \
+  } while (0)
 
 int grid_for(long long total) {
   long long b = (total + 255) / 256;
@@ -879,8 +1046,7 @@ int rsp_bn_act_pool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const flo
   const Layout L = make_layout(d, p.cg, 4);
   RSP_REQUIRE(L.npos < (1ll << 31), "rsp_bn_act_pool_fwd: more than 2^31 - 1 output positions");
   p.cgc = L.cgc; p.ppi = L.ppi; p.npos = L.npos; p.dcgc = L.dcgc; p.dWo = L.dWo; p.dHo = L.dHo; p.dDo = L.dDo;
-  if (vec) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<4>, L.grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<1>, L.grid, dim3(256), 0, (hipStream_t)stream, p);
+  RSP_BN_LAUNCH(bn_act_pool_fwd_kernel, vec, bn_mode(d, gate != nullptr), L.grid, (hipStream_t)stream, p);
   return rsp_check_launch("bn_act_pool_fwd_kernel");
 }
 
@@ -942,8 +1108,8 @@ int rsp_bn_act_pool_bwd_g(const rsp_pool3d_desc* d, const float* y, const float*
   p.cgc = L.cgc; p.ppi = L.ppi; p.npos = L.npos; p.dcgc = L.dcgc; p.dWo = L.dWo; p.dHo = L.dHo; p.dDo = L.dDo;
   p.nblocks = reduce_blocks(d, p.cg);
   dim3 rgrid(p.nblocks, rsp_cdiv(p.cg, 256));
-  if (vec) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, rgrid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, rgrid, dim3(256), 0, s, p);
+  const int mode = bn_mode(d, gate != nullptr);
+  RSP_BN_LAUNCH(bn_bwd_reduce_kernel, vec, mode, rgrid, s, p);
   int rc = rsp_check_launch("bn_bwd_reduce_kernel");
   if (rc != RSP_OK) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rsp_cdiv(d->C, FIN_CH)), dim3(1024), 0, s, p.partial, p.nblocks, d->C, c_valid, sums,
@@ -952,8 +1118,7 @@ int rsp_bn_act_pool_bwd_g(const rsp_pool3d_desc* d, const float* y, const float*
   if (rc != RSP_OK) return rc;
   const bool exact = d->Di % d->sT == 0 && d->Hi % d->sH == 0 && d->Wi % d->sW == 0 && d->kT * d->kH * d->kW <= 8;
   if (exact) {
-    if (vec) hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, L.grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, L.grid, dim3(256), 0, s, p);
+    RSP_BN_LAUNCH(bn_bwd_apply_win_kernel, vec, mode, L.grid, s, p);
     return rsp_check_launch("bn_bwd_apply_win_kernel");
   }
   const long long total = (long long)d->N * d->Di * d->Hi * d->Wi * p.cg;
