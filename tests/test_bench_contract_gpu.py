@@ -71,7 +71,7 @@ def test_bench_parity_object_replays_the_first_gpu_step():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
     p = d["parity"]
     assert p["ok"] is True and p["forward_ok"] is True and p["grad_ok"] is True, p
-    assert p["grad_floor_rel_l2"] is not None and p["grad_rel_l2"] <= 3 * p["grad_floor_rel_l2"], p
+    assert p["grad_floor_rel_l2"] is not None and p["grad_rel_l2"] <= max(3 * p["grad_floor_rel_l2"], 1e-4), p
     assert max(p["loss_rel"], p["logits_rel"], p["features_rel"], p["queue_slab_rel"]) <= 1e-3 and p["grad_rel_l2"] <= 2e-2, p
     assert "other_workloads" not in d
 
