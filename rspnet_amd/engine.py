@@ -17,7 +17,6 @@ from __future__ import annotations
 
 import contextlib
 import os
-import dataclasses
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -465,74 +464,35 @@ def _eval_scale_shift(bn, bias) -> torch.Tensor:
 
 
 def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, training: bool = True,
-                deferred: Optional[Dict[int, torch.Tensor]] = None, pair: bool = False) -> Tuple[torch.Tensor, Optional[ForwardCtx]]:
+                deferred: Optional[Dict[int, torch.Tensor]] = None) -> Tuple[torch.Tensor, Optional[ForwardCtx]]:
     """Execute `plan` on x (N,D,H,W,C).  keep=True records what backward needs.  training=True: batch-statistics BN (the
     pretext step never runs anything else: pretrain.py:225); training=False: running-statistics BN for the fine-tune /
-    validation forward (finetune.py:333-345), no backward.
-
-    pair=True: x holds TWO batches back to back along N that go through the same weights as two separate forwards would (the
-    step's two key passes, builder_diffspeed_diffloss.py:445,512).  Convolutions, pools and heads run once over both — twice the
-    rows per launch, half the launches, which is what the small late layers lack — while every BatchNorm takes its statistics
-    per batch: the first batch moves the running statistics, the second reports its moments into `deferred`, exactly as two
-    consecutive forwards with the second one deferred."""
+    validation forward (finetune.py:333-345), no backward."""
     be = _ops.backend()
     assert training or not keep, "eval-mode forward keeps nothing for backward"
-    assert not pair or (training and not keep and deferred is not None and x.shape[0] % 2 == 0), "paired forward: two training batches, nothing kept"
 
-    def halves(t):
-        """The per-batch views of a tensor whose leading dimension is N."""
-        if not pair:
-            return (t,)
-        if t is None:
-            return (None, None)
-        h = t.shape[0] // 2
-        return (t[:h], t[h:])
-
-    def finalize(bn, stats, rows, bias_d, gi=0):
+    def finalize(bn, stats, rows, bias_d):
         # deferred: {id(BatchNorm module): [2][C] buffer} — this pass reports its batch moments there and leaves the running
-        # statistics to a later rsp_bn_running_update (ops.BnEmaSet); otherwise bn_finalize moves them itself.  Of a pair, the
-        # first batch (gi = 0) moves them and the second defers.
-        bso = deferred.get(id(bn)) if (deferred is not None and (gi == 1 or not pair)) else None
+        # statistics to a later rsp_bn_running_update (ops.BnEmaSet); otherwise bn_finalize moves them itself
+        bso = deferred.get(id(bn)) if deferred is not None else None
         if bso is not None:
             return be.bn_finalize(stats, rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), None, None,
                                   batch_stats_out=bso)
         return be.bn_finalize(stats, rows, bias_d, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum),
                               bn.running_mean, bn.running_var)
 
-    def finalize_each(bn, stats_list, rows, bias_d):
-        """(mean|invstd, scale|shift) of every batch: [(mi, ss)] (one entry unless paired); rows = rows of ALL batches."""
-        return [finalize(bn, st, rows // len(stats_list), bias_d, gi) for gi, st in enumerate(stats_list)]
-
-    def conv_stats(cg, xin, wnode, bias, out=None, out_ld=None):
-        """The convolution with its BatchNorm partials per batch: (y, [stats of batch 0, ...]).  Of a pair, one launch covers both
-        batches when the boundary between them falls on a boundary of the 128-row statistics tiles; otherwise one launch each."""
-        if not pair or be.stats_split_ok(cg):
-            y, st = be.conv_fwd(cg, xin, packed.get(wnode, cg), bias, True, out=out, out_ld=out_ld)
-            if not pair:
-                return y, [st]
-            t = st.shape[0] // 2
-            return y, [st[:t], st[t:]]
-        cgh = dataclasses.replace(cg, N=cg.N // 2)
-        if out is None:
-            out = torch.empty((cg.N,) + tuple(cg.out_dims) + (cg.Cout,), dtype=torch.float32, device=xin.device)
-        sts = []
-        for xh, yh in zip(halves(xin), halves(out)):
-            sts.append(be.conv_fwd(cgh, xh, packed.get(wnode, cgh), bias, True, out=yh, out_ld=out_ld)[1])
-        return out, sts
-
     slots: Dict[int, torch.Tensor] = {plan.input_slot: x}
     ctx = ForwardCtx(packed=packed) if keep else None
-    def bn_apply(node, y, ss_list, cg_cout, N, do, ho, wo, xin):
+    def bn_apply(node, y, ss, cg_cout, N, do, ho, wo, xin):
         pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
-        pg = PoolGeom(N // len(ss_list), do, ho, wo, cg_cout, pk, ps, (0, 0, 0))
+        pg = PoolGeom(N, do, ho, wo, cg_cout, pk, ps, (0, 0, 0))
         res = slots[node.residual] if node.residual is not None else None
-        pdo, pho, pwo = pg.out_dims
         if node.into is not None:
+            pdo, pho, pwo = pg.out_dims
             out = _view(_slice_of(slots, node.into, (N, pdo, pho, pwo), xin.device), node.into, cg_cout)
+            be.bn_act_pool_fwd(pg, y, ss, res, node.relu, out=out)
         else:
-            out = slots[node.dst] = torch.empty((N, pdo, pho, pwo, cg_cout), dtype=torch.float32, device=xin.device)
-        for yh, ss, rh, oh in zip(halves(y), ss_list, halves(res), halves(out)):
-            be.bn_act_pool_fwd(pg, yh, ss, rh, node.relu, out=oh)
+            slots[node.dst] = be.bn_act_pool_fwd(pg, y, ss, res, node.relu)
         return pg, res
 
     def convbn_virtual(node, key):
@@ -553,12 +513,12 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         yv = y.view(N, do, ho, g, 2 * Cp)
         parts = []
         for c, xc in enumerate((x_e, x_o)):
-            parts.append(conv_stats(cg, xc, vs.holders[c], None, out=yv[..., c * Cp:(c + 1) * Cp], out_ld=2 * Cp)[1])
+            _, st = be.conv_fwd(cg, xc, packed.get(vs.holders[c], cg), None, True, out=yv[..., c * Cp:(c + 1) * Cp], out_ld=2 * Cp)
+            parts.append(st)
         rows = N * do * ho * 2 * g
-        fin = finalize_each(node.bn, [torch.cat(sts) for sts in zip(*parts)], rows, None)
-        pg, res, = bn_apply(node, y, [ss for _, ss in fin], Cp, N, do, ho, 2 * g, xin)
+        mi, ss = finalize(node.bn, torch.cat(parts), rows, None)
+        pg, res, = bn_apply(node, y, ss, Cp, N, do, ho, 2 * g, xin)
         if keep:
-            mi, ss = fin[0]
             ctx.saved[key] = ("vstem", x_e, x_o, y, mi, ss, cg, pg, vs)
 
     def convbn(node, key, gated=None):
@@ -576,19 +536,16 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
         if training:
             # (no shipped backbone has a conv bias on channel-padded units; if one does, the conv needs it at the padded length)
             bias_conv = bias_d if (bias_d is None or Cp == Cout) else _pad_vec(bias_d, Cp)
-            y, stats = conv_stats(cg, xin, node, bias_conv)
+            y, stats = be.conv_fwd(cg, xin, packed.get(node, cg), bias_conv, True)
             # (zero-padded output channels, Cp > Cout: the BatchNorm vectors keep their Cout entries, the kernels treat the rest
             #  as gamma = beta = 0 and leave the running statistics of the real channels alone)
-            fin = finalize_each(bn, stats, cg.rows, bias_d)
-            mi, ss = fin[0]
-            ss_list = [f[1] for f in fin]
+            mi, ss = finalize(bn, stats, cg.rows, bias_d)
         else:
             y, _ = be.conv_fwd(cg, xin, packed.get(node, cg), None, False)     # bias folded into the shift
             ss = _eval_scale_shift(bn, bias)
             mi = None
             if Cp != Cout:
                 ss = torch.cat([ss, torch.zeros((2, Cp - Cout), dtype=ss.dtype, device=ss.device)], dim=1).contiguous()
-            ss_list = [ss]
         do, ho, wo = cg.out_dims
         if gated is not None:
             # BatchNorm-apply + self-gating (+ the max-pool behind a front-end unit, when nothing is kept for a backward) in two
@@ -596,23 +553,15 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             gi, pi = gated
             gnode = plan.nodes[gi]
             pnode = plan.nodes[pi] if (pi is not None and not keep) else None
-            Nb = N // len(ss_list)
-            pg = PoolGeom(Nb, do, ho, wo, cg.Cout)
+            pg = PoolGeom(N, do, ho, wo, cg.Cout)
             out = None
             if gnode.into is not None:
                 out = _view(_slice_of(slots, gnode.into, (N, do, ho, wo), xin.device), gnode.into, cg.Cout)
-            pool = PoolGeom(Nb, do, ho, wo, cg.Cout, pnode.k, pnode.s, pnode.p) if pnode is not None else None
+            pool = PoolGeom(N, do, ho, wo, cg.Cout, pnode.k, pnode.s, pnode.p) if pnode is not None else None
             # (a backward recomputes the activation from y: nothing but the (sample, channel) means and gates is kept)
             keep_act = keep and not GATE_BWD_FUSED
-            if len(ss_list) == 1:
-                o, a, mean, gate = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, keep_act,
-                                                      pool=pool, out=out)
-            else:
-                if out is None:
-                    out = torch.empty((N,) + tuple((pool or pg).out_dims) + (cg.Cout,), dtype=torch.float32, device=xin.device)
-                for yh, ssh, oh in zip(halves(y), ss_list, halves(out)):
-                    be.bn_act_gate_fwd(pg, yh, ssh, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, False, pool=pool, out=oh)
-                o = out
+            o, a, mean, gate = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, keep_act, pool=pool,
+                                                  out=out)
             if pnode is not None:
                 slots[pnode.dst] = o
                 skipped.add(pi)
@@ -623,7 +572,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
                 ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, None)
                 ctx.saved[gi] = (a, mean, gate) if keep_act else ("fused", key, mean, gate)
             return
-        pg, res = bn_apply(node, y, ss_list, cg.Cout, N, do, ho, wo, xin)
+        pg, res = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin)
         if keep:
             ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, res)
 
@@ -641,15 +590,14 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             node._cat = _CatConv()
         node._cat.weight = wcat
         cg = ConvGeom(N, D, H, W, Cin, wcat.shape[0], ms[0].k, ms[0].s, ms[0].p)
-        y, stats = conv_stats(cg, xin, node._cat_node(), None)
+        y, stats = be.conv_fwd(cg, xin, packed.get(node._cat_node(), cg), None, True)
         do, ho, wo = cg.out_dims
         off, per = 0, []
         for m in ms:
             C = m.conv.weight.shape[0]
             bn = m.bn
-            fin = finalize_each(bn, [st[:, off:off + C] for st in stats], cg.rows, None)
-            pg, _ = bn_apply(m, y[..., off:off + C], [f[1] for f in fin], C, N, do, ho, wo, xin)
-            mi, ss = fin[0]
+            mi, ss = finalize(bn, stats[:, off:off + C], cg.rows, None)
+            pg, _ = bn_apply(m, y[..., off:off + C], ss, C, N, do, ho, wo, xin)
             per.append((off, C, mi, ss, pg))
             off += C
         if keep:

@@ -170,8 +170,6 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._ptr_checked = False             # the device-resident pointer has been validated against the enqueue size
         self.overlap_query = not os.environ.get("RSP_NO_QOVERLAP")     # (switches for A/B runs of tools/)
         self.overlap_keys = not os.environ.get("RSP_NO_KOVERLAP")
-        # both key passes as ONE forward over 2B clips (same weights; BatchNorm statistics per pass): see _key_pass_pair
-        self.pair_keys = bool(os.environ.get("RSP_PAIR_KEYS"))
         # issued eagerly (more than one rank; --no-graph) the same fork pays when the host runs far ahead of the GPU — C3D's 250 long
         # launches — and the unequal tiles of DESIGN 5d leave slots for it to fill
         self.overlap_query_eager = not os.environ.get("RSP_NO_EAGER_OVERLAP")
@@ -396,21 +394,6 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._last_k[0 if tag == "kneg" else 1] = (feats, arrival)
         return feats, a.shape[1]
 
-    def _key_pass_pair(self, ex_neg, ex_k, deferred):
-        """Both key passes (:445 k_negative, :512 k) as one forward over their 2B clips: they go through the same encoder_k, so
-        every convolution, pool and head runs once with twice the rows; BatchNorm keeps the two passes apart (statistics per
-        pass, running statistics moved in the reference's order — engine.run_forward(pair=True)).  Returns what two `_key_pass`
-        calls return: (features of the k_negative pass, features of the k pass, width of A)."""
-        for (_, handle, _), tag in ((ex_neg, "kneg"), (ex_k, "k")):
-            if handle is not None:
-                with self._comm("all_to_all_" + tag):
-                    handle.wait()
-        B = ex_neg[0].shape[0]
-        a, m, _ = self.encoder_k.forward_ndhwc(torch.cat([ex_neg[0], ex_k[0]]), keep=False, deferred=deferred, pair=True)
-        feats = torch.cat([a, m], dim=1)
-        self._last_k = [(feats[:B], ex_neg[2]), (feats[B:], ex_k[2])]
-        return feats[:B], feats[B:], a.shape[1]
-
     @staticmethod
     def _pair_rows(loc: np.ndarray, B: int, which: int) -> np.ndarray:
         """Row of global sample g of key pass `which` (0: k_negative, 1: k) in the gathered (ws, 2, B, width) feature block,
@@ -596,20 +579,17 @@ class MoCoDiffLossTwoFc(nn.Module):
             self._nbt_k += 2
             self.encoder_k._packed.refresh_now()      # (re-pack of the momentum-updated weights: before the passes fork)
             side_k = None
-            if self.pair_keys:
-                feats_neg, feats_k, dim = self._key_pass_pair(ex_neg, ex_k, deferred)
-            elif side is not None and self.overlap_keys:
+            if side is not None and self.overlap_keys:
                 main = torch.cuda.current_stream(dev)
                 side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
                 side_k.wait_stream(main)
                 with torch.cuda.stream(side_k):
                     feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
-            if not self.pair_keys:
-                feats_neg, dim = self._key_pass(ex_neg, "kneg", bump=False)
-                if side_k is None:
-                    feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
-                else:
-                    torch.cuda.current_stream(dev).wait_stream(side_k)
+            feats_neg, dim = self._key_pass(ex_neg, "kneg", bump=False)
+            if side_k is None:
+                feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
+            else:
+                torch.cuda.current_stream(dev).wait_stream(side_k)
             self._ema_k.run()
             del ex_neg, ex_k
             rank = self._dp()[0]

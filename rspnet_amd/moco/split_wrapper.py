@@ -140,12 +140,11 @@ class MultiTaskWrapper(nn.Module):
     def weights_changed(self):
         self._packed.invalidate()
 
-    def forward_ndhwc(self, x: Tensor, keep: bool, deferred=None, pair: bool = False):
+    def forward_ndhwc(self, x: Tensor, keep: bool, deferred=None):
         """x: (N,T,H,W,C).  Returns (x1, x2, ctx) — ctx is what backward_ndhwc needs (None when keep=False).  deferred: see
-        engine.run_forward (BatchNorm layers that report their batch moments instead of moving their running statistics);
-        pair: x is two batches back to back that see the encoder as two consecutive forwards would (engine.run_forward)."""
+        engine.run_forward (BatchNorm layers that report their batch moments instead of moving their running statistics)."""
         be = _ops.backend()
-        feat, ctx = run_forward(self.plan(), x, self._packed, keep, deferred=deferred, pair=pair)
+        feat, ctx = run_forward(self.plan(), x, self._packed, keep, deferred=deferred)
         self.feat = feat
         if self.fc_type == "linear":
             l1, l2 = self.fc1[2], self.fc2[2]
@@ -159,7 +158,7 @@ class MultiTaskWrapper(nn.Module):
         for hi, fc in enumerate((self.fc1, self.fc2)):
             hctx = hid = None
             if self.fc_type in ("conv", "convbn"):
-                h, hctx = run_forward(fc.plan(), feat, self._packed, keep, deferred=deferred, pair=pair)
+                h, hctx = run_forward(fc.plan(), feat, self._packed, keep, deferred=deferred)
                 pooled = be.spatial_mean_fwd(h)
                 raw = be.linear_fwd(pooled, fc.linear.weight.data, fc.linear.bias.data, False)
                 hshape = tuple(h.shape)

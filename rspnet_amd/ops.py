@@ -247,12 +247,6 @@ class HipOps:
         self._log("conv_fwd", g, e0, names[0])
         return out, stats
 
-    def stats_split_ok(self, g: ConvGeom) -> bool:
-        """Do the BatchNorm partials conv_fwd(g) returns split into those of the first and of the second half of the batch?  (The
-        tiles are 128 output rows of the implicit GEMM; the direct stem kernels tile differently and are run per half.)"""
-        names = _conv_plan(0, g, None, None)[7]
-        return g.N % 2 == 0 and not names[0].startswith("stem") and (g.rows // 2) % 128 == 0
-
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):
         _chk(dy, "dy")
         _chk(w_ref, "w_ref")

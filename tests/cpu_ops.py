@@ -40,9 +40,6 @@ class CpuOps:
             return out, stats
         return _ndhwc(y0), stats
 
-    def stats_split_ok(self, g: ConvGeom) -> bool:
-        return False                 # (one statistics "tile" for the whole batch here: a paired forward convolves per batch)
-
     def conv_dgrad(self, g: ConvGeom, dy, w_ref):
         x_shape = (g.N, g.Cin, g.Di, g.Hi, g.Wi)
         dx = torch.nn.grad.conv3d_input(x_shape, w_ref, _ncdhw(dy).contiguous(), stride=g.s, padding=g.p)
