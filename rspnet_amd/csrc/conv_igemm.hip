@@ -2421,6 +2421,7 @@ int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Co
       j.ntaps = d->kT * d->kH * d->kW;
       j.total = (long long)rsp_stem_packed_elems(d);
       j.blocks = (int32_t)((j.total + 4095) / 4096);
+      rsp_stem_note_packed(w_packed, Cin_src <= 3);     // (the re-pack zero-fills channel 3: its k-step is skipped)
       return 1;
     }
     PackParams pk;

@@ -19,6 +19,9 @@
 // workgroup; rows outside the image contribute zeros).
 #include "conv_stem.h"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace {
 
 struct StemParams {
@@ -41,32 +44,60 @@ struct StemParams {
 };
 
 // Wide epilogue store.  A wave's 32 x 64 accumulator tile is column-per-lane (lane = output channel), so a direct store is 32
-// four-byte stores per lane, each wave-instruction touching two 128-byte half rows; the vmcnt(0) hipcc places in front of the
-// next patch's first LDS read then waits for all of them (SQ_WAIT_ANY 46 % in round 1).  Here each 32 x 32 half goes through a
-// 4 KB wave-private LDS square ([row][col], conflict-free both ways) and leaves as four 16-byte stores per lane — eight rows x
-// 128 contiguous bytes per wave-instruction, a quarter of the store instructions.  Needs Cout % 4 == 0 and 16-byte aligned rows.
-__device__ __forceinline__ void stem_store_wide(const StemParams& p, const floatx16 (&acc)[2], float* stage /* wave-private 4 KB */,
-                                                const long long* rowaddr /* [128] */, int wave, int lane) {
+// four-byte stores per lane, each wave-instruction touching two 128-byte half rows.  Here the tile goes through a 2 KB
+// wave-private LDS stage ([16 rows][32 cols], conflict-free both ways) in four rounds and leaves as two 16-byte stores per lane
+// and round — eight rows x 128 contiguous bytes per wave-instruction, a quarter of the store instructions.  Needs Cout % 4 == 0
+// and 16-byte aligned rows.
+//
+// The bias comes in REGISTERS, loaded and waited for once per kernel (StemBias): a bias load whose first use sits inside the
+// `if (row valid)` around a store makes hipcc put `s_waitcnt vmcnt(0)` in front of EVERY store (the skip path has not waited, so
+// after each merge the load counts as pending again) — and vmcnt(0) also waits for the previous store's acknowledgement: the
+// stores went out one at a time, ~0.2 us each, 6 of the 10 us a C3D conv1 patch took (ISA: /tmp listing in experiments_r4.txt).
+struct StemBias {
+  floatx4 w[2];   // wide form: channels 32 j + 4 (lane & 7) .. + 3
+  float n[2];     // narrow form: channel 32 j + (lane & 31)
+};
+
+__device__ __forceinline__ StemBias stem_bias(const float* __restrict__ bias, int Cout, bool wide, int lane) {
+  StemBias b;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    b.w[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    b.n[j] = 0.f;
+    const int cw = 32 * j + 4 * (lane & 7), cn = 32 * j + (lane & 31);
+    if (bias && wide && cw < Cout) b.w[j] = *reinterpret_cast<const floatx4*>(bias + cw);
+    if (bias && !wide && cn < Cout) b.n[j] = bias[cn];
+  }
+  // the loads are consumed HERE, outside any branch
+  asm volatile("" : "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.n[0]), "+v"(b.n[1]));
+  return b;
+}
+
+__device__ __forceinline__ void stem_store_wide(const StemParams& p, const floatx16 (&acc)[2], float* stage /* wave-private 2 KB */,
+                                                const long long* rowaddr /* [128] */, int wave, int lane, const StemBias& b) {
   const int l32 = lane & 31, h = lane >> 5;
   const int q = lane & 7, rbase = lane >> 3;   // read side: 8 lanes per row, 4 channels each
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) stage[((e >> 2) * 8 + h * 4 + (e & 3)) * 32 + l32] = acc[j][e];
     const int col = 32 * j + 4 * q;
-    floatx4 bv = floatx4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && col < p.Cout) bv = *reinterpret_cast<const floatx4*>(p.bias + col);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = rbase + 8 * i;
-      const floatx4 v = *reinterpret_cast<const floatx4*>(stage + r * 32 + 4 * q);
-      const long long addr = rowaddr[wave * 32 + r];
-      if (addr >= 0 && col < p.Cout) *reinterpret_cast<floatx4*>(p.y + addr + col) = v + bv;
+    for (int r = 0; r < 2; ++r) {              // accumulator elements 8r .. 8r+7 = tile rows 16r .. 16r+15
+#pragma unroll
+      for (int e = 0; e < 8; ++e) stage[((e >> 2) * 8 + h * 4 + (e & 3)) * 32 + l32] = acc[j][8 * r + e];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rl = rbase + 8 * i;
+        const floatx4 v = *reinterpret_cast<const floatx4*>(stage + rl * 32 + 4 * q);
+        const long long addr = rowaddr[wave * 32 + 16 * r + rl];
+        if (addr >= 0 && col < p.Cout) *reinterpret_cast<floatx4*>(p.y + addr + col) = v + b.w[j];
+      }
     }
   }
 }
 
-template <int G>
+// NS = k-steps (input channels) per tap: 4, or 3 when the filters were packed from three real input channels (RGB padded to 4 for
+// 16-byte pixels: channel 3 is zero on both operands, so its k-step — a quarter of the MFMAs — is not issued; rsp_stem_note_packed).
+template <int G, int NS>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   constexpr int TCH = 2 * G;            // taps per weight chunk
   constexpr int BU = TCH * 64;          // 16-byte units per weight chunk
@@ -92,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   const int n = q0 / p.Do;
   const int TW = 1 << p.tw_shift, TH = 128 >> p.tw_shift;
   const int h0 = hb * TH, w0 = wb * TW;
+  const StemBias bias = stem_bias(p.bias, p.Cout, p.wide != 0, lane);
 
   const int khw = p.kH * p.kW;
   for (int i = t; i < p.nchunks * TCH; i += 256) {
@@ -189,11 +221,11 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
       const int fh = frame_hi(c + 1);
       while (loaded < fh) load_frame(++loaded);
     }
-    // 3. 4 k-steps (channels) x 2 column tiles per tap pair
+    // 3. NS k-steps (channels) x 2 column tiles per tap pair
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][s], bf[g][j][s], acc[j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -211,11 +243,11 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
   }
   __syncthreads();
   float* red = Bs;   // [4 waves][64][2]; the weight buffers are idle now
-  if (p.wide) stem_store_wide(p, acc, Bs + 512 + wave * 1024, rowaddr, wave, lane);   // behind the 2 KB of `red`
+  if (p.wide) stem_store_wide(p, acc, Bs + 512 + wave * 512, rowaddr, wave, lane, bias);   // behind the 2 KB of `red`
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = 32 * j + l32;
-    const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+    const float bv = bias.n[j];
     float s = 0.f, ss = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -253,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 // the patches with stride gridDim.x; the halo of the NEXT patch is copied (LDS-DMA) into the other halo buffer while the last
 // tap chunk of the current patch is on the matrix pipe, so a patch costs neither a weight copy nor an exposed copy latency
 // (PMC before: 46 % of the wave time parked on s_waitcnt / s_barrier).
-template <int G>
+template <int G, bool WIDE, int NS>
 __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams p) {
   constexpr int TCH = 2 * G;
   constexpr int BU = TCH * 64;
@@ -342,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
   // GEMM row of this lane's A operand: m = 32*wave + l32 -> (hy, wx) inside the patch
   const int m = wave * 32 + l32;
   const int rowoff = (((m >> p.tw_shift) * p.sH) * p.WTL + (m & (TW - 1))) * 16;
+  const StemBias bias = stem_bias(p.bias, p.Cout, WIDE, lane);
 
   int cur = 0;
   if ((int)blockIdx.x < p.tiles) issue_halo(blockIdx.x, 0);
@@ -368,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][s], bf[g][j][s], acc[j], 0, 0, 0);
     }
@@ -383,16 +416,19 @@ __global__ __launch_bounds__(256, 2) void stem_resident_kernel(const StemParams 
       rowaddr[t] = (ho < p.Ho && wo < p.Wo) ? ((((long long)n * p.Do + to) * p.Ho + ho) * p.Wo + wo) * p.out_ld : -1;
     }
     __syncthreads();
+    // wide form: staged through this patch's halo buffer — every wave is past its last operand read (the barrier above), and
+    // the next copy into THIS buffer is issued behind the next patch's top barrier
+    if (WIDE) stem_store_wide(p, acc, halo + cur * hsz + wave * 512, rowaddr, wave, lane, bias);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = 32 * j + l32;
-      const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+      const float bv = bias.n[j];
       float s = 0.f, ss = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const long long addr = rowaddr[wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3)];
         const float v = addr >= 0 ? acc[j][e] : 0.f;
-        if (addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
+        if (!WIDE && addr >= 0 && col < p.Cout) p.y[addr + col] = v + bv;
         s += v;
         ss = fmaf(v, v, ss);
       }
@@ -439,6 +475,7 @@ struct StemPlan {
   bool ok;
   int G, TCH, nchunks, tw_shift, HT, WT, WTh, WTL, npix, npix_r, FR, tiles_h, tiles_w;
   bool resident;      // stem_resident_kernel: weights + two halos fit in LDS
+  bool wide_ok;       // 16-byte epilogue stores possible (channel count / pitch; pointer alignment is checked at launch)
   long long tiles;
   size_t lds;
 };
@@ -495,34 +532,51 @@ StemPlan stem_plan(const rsp_conv3d_desc* d) {
   s.lds = s.resident ? lds_res
                      : (size_t)s.FR * s.npix_r * 16 + (size_t)2 * s.TCH * 1024 + (size_t)s.nchunks * s.TCH * 4 + 128 * 8;
   if (s.lds > 150 * 1024) return s;
+  // (the resident kernel stages the wide stores through a halo buffer: 4 waves x 2 KB)
+  // ... and with 16 taps per chunk its wide form needs 178 VGPRs — two waves per SIMD instead of three)
+  s.wide_ok = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && (!s.resident || ((size_t)d->kT * s.npix_r * 16 >= 8192 && s.G != 8));
   s.ok = true;
   return s;
 }
 
-template <int G>
+// Packed stem weights whose source filters had three input channels (noted by the re-pack entry points: the layout is private to
+// the library, so every producer of such a buffer passes through one of them).  Keyed by the packed buffer's address.
+std::mutex g_three_mu;
+std::unordered_map<const void*, bool> g_three;
+
+bool stem_three_channels(const void* w_packed) {
+  std::lock_guard<std::mutex> lk(g_three_mu);
+  auto it = g_three.find(w_packed);
+  return it != g_three.end() && it->second;
+}
+
+template <int G, int NS>
 int launch_stem(const StemParams& p, const StemPlan& pl, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<G, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
     attr_set = true;
   }
   if (pl.resident) {
     static bool attr_set_r = false;
     if (!attr_set_r) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_resident_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_resident_kernel<G, true, NS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_resident_kernel<G, false, NS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr_set_r = true;
     }
     long long per_cu = (160 * 1024) / (long long)pl.lds;
     per_cu = per_cu > 3 ? 3 : per_cu;                       // <= 170 VGPRs: three waves per SIMD
     const long long grid = pl.tiles < 256 * per_cu ? pl.tiles : 256 * per_cu;
-    rsp_note_kernel("stem_resident_kernel<%d>", G);
-    hipLaunchKernelGGL((stem_resident_kernel<G>), dim3((unsigned)grid), dim3(256), pl.lds, s, p);
+    rsp_note_kernel(p.wide ? "stem_resident_kernel<%d, true, %d>" : "stem_resident_kernel<%d, false, %d>", G, NS);
+    if (p.wide) hipLaunchKernelGGL((stem_resident_kernel<G, true, NS>), dim3((unsigned)grid), dim3(256), pl.lds, s, p);
+    else hipLaunchKernelGGL((stem_resident_kernel<G, false, NS>), dim3((unsigned)grid), dim3(256), pl.lds, s, p);
     return rsp_check_launch("stem_resident_kernel");
   }
-  rsp_note_kernel("stem_kernel<%d>", G);
-  hipLaunchKernelGGL((stem_kernel<G>), dim3((unsigned)pl.tiles), dim3(256), pl.lds, s, p);
+  rsp_note_kernel("stem_kernel<%d, %d>", G, NS);
+  hipLaunchKernelGGL((stem_kernel<G, NS>), dim3((unsigned)pl.tiles), dim3(256), pl.lds, s, p);
   return rsp_check_launch("stem_kernel");
 }
 
@@ -532,10 +586,19 @@ bool rsp_stem_applicable(const rsp_conv3d_desc* d) { return stem_plan(d).ok; }
 
 int rsp_stem_tiles(const rsp_conv3d_desc* d) { return (int)stem_plan(d).tiles; }
 
+// (the three-channel instance: what the engine's re-pack produces for every RGB stem; a four-channel source runs <..., 4>)
 const char* rsp_stem_kernel_name(const rsp_conv3d_desc* d) {
   const StemPlan pl = stem_plan(d);
-  if (pl.resident) return pl.G == 8 ? "stem_resident_kernel<8>" : (pl.G == 7 ? "stem_resident_kernel<7>" : "stem_resident_kernel<5>");
-  return pl.G == 8 ? "stem_kernel<8>" : (pl.G == 7 ? "stem_kernel<7>" : "stem_kernel<5>");
+  if (pl.resident && pl.wide_ok)
+    return pl.G == 8 ? "stem_resident_kernel<8, true, 3>" : (pl.G == 7 ? "stem_resident_kernel<7, true, 3>" : "stem_resident_kernel<5, true, 3>");
+  if (pl.resident)
+    return pl.G == 8 ? "stem_resident_kernel<8, false, 3>" : (pl.G == 7 ? "stem_resident_kernel<7, false, 3>" : "stem_resident_kernel<5, false, 3>");
+  return pl.G == 8 ? "stem_kernel<8, 3>" : (pl.G == 7 ? "stem_kernel<7, 3>" : "stem_kernel<5, 3>");
+}
+
+void rsp_stem_note_packed(const void* w_packed, bool three_channels) {
+  std::lock_guard<std::mutex> lk(g_three_mu);
+  g_three[w_packed] = three_channels;
 }
 
 size_t rsp_stem_packed_elems(const rsp_conv3d_desc* d) {
@@ -547,6 +610,7 @@ int rsp_stem_pack(const rsp_conv3d_desc* d, const float* w_ref, float* w_packed,
   const StemPlan pl = stem_plan(d);
   const long long total = (long long)pl.nchunks * pl.TCH * 256;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  rsp_stem_note_packed(w_packed, false);      // this entry point is handed four-channel filters
   hipLaunchKernelGGL(stem_pack_kernel, dim3(blocks), dim3(256), 0, s, w_ref, w_packed, d->Cout, d->kT, d->kH, d->kW,
                      d->kT * d->kH * d->kW, total);
   return rsp_check_launch("stem_pack_kernel");
@@ -569,14 +633,21 @@ int rsp_stem_fwd(const rsp_conv3d_desc* d, const float* x, const float* w_packed
   p.npix = pl.npix; p.npix_r = pl.npix_r; p.FR = pl.FR;
   p.ntaps = d->kT * d->kH * d->kW; p.nchunks = pl.nchunks;
   p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles = (int)pl.tiles;
-  // wide epilogue only on the streaming variant, where the idle weight ring is the staging area: in the resident kernel the
-  // extra 16 KB of LDS (or the registers of a second epilogue path) cost the third workgroup per CU (C3D conv1: 1.02 -> 1.11 ms)
-  p.wide = !pl.resident && d->Cout % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && (!bias || rsp_aligned16(bias));
+  // wide epilogue: staged through the idle weight ring (streaming variant) or through the patch's own halo buffer (resident
+  // variant — a stage of its own cost the third workgroup per CU: C3D conv1 1.02 -> 1.11 ms)
+  p.wide = pl.wide_ok && rsp_aligned16(y) && (!bias || rsp_aligned16(bias));
   p.x_bytes = (unsigned)((unsigned long long)d->N * d->Di * d->Hi * d->Wi * 16ull);
   p.w_bytes = (unsigned)((size_t)pl.nchunks * pl.TCH * 1024);
+  if (stem_three_channels(w_packed)) {
+    switch (pl.G) {
+      case 8: return launch_stem<8, 3>(p, pl, s);
+      case 7: return launch_stem<7, 3>(p, pl, s);
+      default: return launch_stem<5, 3>(p, pl, s);
+    }
+  }
   switch (pl.G) {
-    case 8: return launch_stem<8>(p, pl, s);
-    case 7: return launch_stem<7>(p, pl, s);
-    default: return launch_stem<5>(p, pl, s);
+    case 8: return launch_stem<8, 4>(p, pl, s);
+    case 7: return launch_stem<7, 4>(p, pl, s);
+    default: return launch_stem<5, 4>(p, pl, s);
   }
 }

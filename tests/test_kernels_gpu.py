@@ -554,7 +554,13 @@ def test_reported_kernel_name_is_the_kernel_that_ran(hip, case):
     want = [lib.rsp_conv3d_kernel_name(C.byref(d), which).decode() for which in (0, 1, 2)]
     x = torch.randn(N, D, H, W, cin, device=DEV)
     w = torch.randn(cout, cin, *k, device=DEV) * 0.05
-    y, _ = hip.conv_fwd(g, x, hip.conv_pack_fwd(g, w), None, True)
+    if cin == 4:       # an RGB stem: packed from its three real channels, as the engine's re-pack does (the name is that instance)
+        ps0 = hip.pack_set([(g, 0, w[:, :3].contiguous())])
+        ps0.run()
+        wp = ps0.packed[0]
+    else:
+        wp = hip.conv_pack_fwd(g, w)
+    y, _ = hip.conv_fwd(g, x, wp, None, True)
     assert lib.rsp_last_conv_kernel().decode() == want[0], ("fwd", want[0])
     dy = torch.randn_like(y)
     if cin > 4:
@@ -564,6 +570,28 @@ def test_reported_kernel_name_is_the_kernel_that_ran(hip, case):
         assert lib.rsp_last_conv_kernel().decode() == want[1], ("dgrad", want[1])
     hip.conv_wgrad(g, x, dy, torch.empty_like(w))
     assert lib.rsp_last_conv_kernel().decode() == want[2], ("wgrad", want[2])
+
+
+@pytest.mark.parametrize("case", [c for c in NAME_CASES if c[4] == 4 and c[6] != (7, 7, 7)], ids=lambda c: f"k{c[6]}s{c[7]}")
+def test_stem_skips_the_padding_channel_of_rgb_filters(hip, case):
+    """Filters re-packed from three input channels run the stem kernels' three-k-step instance (the zero fourth channel of the
+    16-byte pixels is not multiplied); the result is that of the four-channel instance on zero-padded filters."""
+    N, D, H, W, cin, cout, k, s, p = case
+    N = 2
+    g = ConvGeom(N, D, H, W, cin, cout, k, s, p)
+    x = torch.randn(N, D, H, W, cin, device=DEV)
+    x[..., 3] = 0
+    w = torch.randn(cout, cin, *k, device=DEV) * 0.05
+    w[:, 3] = 0
+    bias = torch.randn(cout, device=DEV)
+    ps = hip.pack_set([(g, 0, w[:, :3].contiguous())])
+    ps.run()
+    y3, st3 = hip.conv_fwd(g, x, ps.packed[0], bias, True)
+    name3 = hip.lib.rsp_last_conv_kernel().decode()
+    y4, st4 = hip.conv_fwd(g, x, hip.conv_pack_fwd(g, w), bias, True)
+    name4 = hip.lib.rsp_last_conv_kernel().decode()
+    assert name3.startswith("stem_") and name3.endswith(", 3>") and name4.endswith(", 4>"), (name3, name4)
+    assert torch.equal(y3, y4) and torch.equal(st3, st4)
 
 
 def test_packed_weights_are_shared_across_input_geometries(hip):
