@@ -1097,13 +1097,24 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
     // rows of this lane: local row = wm*WM + h*4 + (group offset gb + k); rows at or beyond `lim` lie outside the M rows
     const int lim = vp.M - q.m0 - (wm * WM + h * 4);
     const int pw_lim = pw_split - (wm * WM + h * 4);      // piecewise: local rows from pw_split on belong to the second run
+    // The bias of every column block is loaded — and waited for, once — before the first store.  Loaded block by block between the
+    // stores, each load's `s_waitcnt vmcnt(0)` also waited for the acknowledgement of the 32 stores in front of it (loads and
+    // stores share the counter): one drain per column block, four per tile in the 160-wide instance.
+    float bvs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = q.n0 + wn * WN + j * 32 + l32;
+      bvs[j] = (vp.bias && !q.is_partial && col < vp.Cout) ? vp.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bvs[j]));
     auto store_tile = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;      // 0 linear, 1 piecewise (two linear runs), 2 per-row table
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = q.n0 + wn * WN + j * 32 + l32;
         const bool cok = col < vp.Cout;
-        const float bv = (vp.bias && !q.is_partial && cok) ? vp.bias[col] : 0.f;
+        const float bv = bvs[j];
         // offset of (local row wm*WM + h*4 + k, this column), k = 0..3; the row groups (i, g4) add a SCALAR offset
         unsigned vo[4];
 #pragma unroll
@@ -1134,9 +1145,7 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
           }
       }
     };
-    if (table) store_tile(std::integral_constant<int, 2>{});
-    else if (piecewise) store_tile(std::integral_constant<int, 1>{});
-    else store_tile(std::integral_constant<int, 0>{});
+    // statistics first: their barrier then waits for the (already landed) prefetch only, not for the tile's 64 stores per wave
     if (vp.stat && !q.is_partial) {
       constexpr int SB = BM / 128;
       constexpr int WPB = WAVES_M / SB;
@@ -1177,6 +1186,9 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
       }
       // (the next unit's statistics go through `red` again: its writers are behind that unit's K-loop barriers)
     }
+    if (table) store_tile(std::integral_constant<int, 2>{});
+    else if (piecewise) store_tile(std::integral_constant<int, 1>{});
+    else store_tile(std::integral_constant<int, 0>{});
   };
 
   // ---- the unit loop ------------------------------------------------------------------------------------------------------------
