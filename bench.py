@@ -58,9 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=32, help="clips per CPU-baseline step (BASELINE config 1: 32)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps after one warm-up step")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="run the step as one replayed HIP graph (rspnet_amd/graph_step.py; N=1 only; auto = on).  What it buys is "
-                         "concurrency between the step's independent passes: S3D-G's small launches, and — since the kernels skip "
-                         "padded taps and tiles differ in length (DESIGN.md 5d) — also C3D's long ones (96.9 -> 94.0 ms)")
+                    help="the step as one replayed HIP graph (rspnet_amd/graph_step.py; N=1 only).  auto: only when the host cannot "
+                         "issue the step fast enough (measured in the warm-up: S3D-G's 1 800 launches) — replayed, a step the host "
+                         "keeps ahead of is 0.5-2.4 %% slower than issued eagerly with its side streams; on: always; off: never")
     ap.add_argument("--no-other-workloads", dest="other_workloads", action="store_false",
                     help="skip BASELINE configs 3-5 (R3D-18, R(2+1)D, S3D-G) that the default N=1 C3D run appends")
     ap.add_argument("--other-steps", type=int, default=30)
@@ -353,7 +353,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     stepper = None
     if use_graph:
         from rspnet_amd.graph_step import GraphedPretextStep
-        stepper = GraphedPretextStep(model, crit, opt, warmup=2)
+        stepper = GraphedPretextStep(model, crit, opt, warmup=2, issue="graph" if args.graph == "on" else "auto")
 
     def eager_step():
         out, tgt, rl, rt = model(im_q, im_k)
@@ -444,7 +444,8 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         fence()
         res["eager_ms_per_step"] = (time.perf_counter() - te) / args.eager_steps * 1e3
     if stepper is not None and not graphed:
-        res["graph_fallback"] = stepper.fallback_reason or "not captured within the warm-up steps"
+        why = stepper.fallback_reason or "not captured within the warm-up steps"
+        res["issue_policy" if why.startswith("issued eagerly by policy") else "graph_fallback"] = why
     roof_steps = steps
     if cuda:
         # roofline pass: the same step issued eagerly ON ONE STREAM with a HIP-event pair around every convolution launch — the
@@ -628,8 +629,8 @@ def run_rank(args):
                        "global_batch": B * ws, "parallelism": f"dp{ws}"},
             "final_loss": round(m["final_loss"], 5),
         }
-        res["config"]["step_issue"] = ("one replayed HIP graph (rspnet_amd/graph_step.py)" if m["graph"] else
-                                       "eager launches (independent passes on side streams)") + \
+        res["config"]["step_issue"] = ("one replayed HIP graph (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)"
+                                       if m["graph"] else "eager launches (independent passes on side streams)") + \
             "; roofline numbers from a one-stream eager pass of the same step outside the timed region"
         if m["collectives"]:
             res["config"]["collectives"] = ("RCCL (nccl backend): clip all-to-all x2, fused key all-gather x1, bucketed gradient "
@@ -639,7 +640,7 @@ def run_rank(args):
             res["issued_eagerly"] = {"ms_per_step": round(m["eager_ms_per_step"], 3),
                                      "clips_per_s": round(ws * B / m["eager_ms_per_step"] * 1e3, 2), "steps": args.eager_steps,
                                      "note": "same step, eager launches with the same side streams: how N > 1 ranks issue it"}
-        for k in ("steps_ms", "comm_ms", "roofline", "hbm_kernels", "graph_fallback"):
+        for k in ("steps_ms", "comm_ms", "roofline", "hbm_kernels", "graph_fallback", "issue_policy"):
             if k in m:
                 res[k] = m[k]
     # BASELINE.json configs 3-5 on the same box (N=1, default run only): the other three backbones at their own batch / clip
@@ -669,7 +670,8 @@ def run_rank(args):
                                 "dominant_kernel_frac": rf["frac"], "dominant_kernel_share_of_step": rf["share_of_step"],
                                 "final_loss": od["final_loss"],
                                 "step_issue": od["config"]["step_issue"]
-                                + (f" (graph capture fell back: {od['graph_fallback']})" if "graph_fallback" in od else "")}
+                                + (f" (graph capture fell back: {od['graph_fallback']})" if "graph_fallback" in od else "")
+                                + (f" ({od['issue_policy']})" if "issue_policy" in od else "")}
             except Exception as e:      # noqa: BLE001 - reported in the line, never fatal for the headline
                 others[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}
         res["other_workloads"] = others

@@ -21,6 +21,13 @@ logits, losses, backward, SGD, enqueue (pointer read and advanced on the device:
 
 Single rank by default (the collectives of the data-parallel path are issued eagerly, with the same side streams); any failure to
 capture falls back to the eager loop with a logged warning — the result is the same either way, kernel for kernel.
+
+WHEN the graph is used (`issue="auto"`): only for a step the host cannot issue fast enough.  A replayed graph removes Python and
+the launch calls, but its nodes reach the GPU with more dependency bookkeeping than a stream's in-order launches: replayed, the
+same step is 0.5-2.4 % SLOWER than issued eagerly with its side streams (C3D 347.7 vs 352.2 clips/s, R3D-18 1251 vs 1281, R(2+1)D 428
+vs 431, S3D-G 404 vs 406; profiles/r04/experiments_r4.txt) — as long as the host keeps ahead.  The last eager warm-up step of a
+configuration is therefore measured: host time to issue it against GPU time to run it.  Below HOST_BOUND (half) the configuration
+stays eager; above it (S3D-G: 38 of 39 ms — any slower host and the GPU would wait for Python) it is captured.
 """
 from __future__ import annotations
 
@@ -36,8 +43,13 @@ log = logging.getLogger(__name__)
 class GraphedPretextStep:
     RING = 8
     MAX_GRAPHS = 4      # configurations kept (diff_speed has at most three entries; a new learning rate retires the old graphs)
+    HOST_BOUND = 0.5    # issue="auto": capture a configuration whose eager issue takes more than this share of its GPU time
 
-    def __init__(self, model, criterion, optimizer, warmup: int = 2):
+    def __init__(self, model, criterion, optimizer, warmup: int = 2, issue: str = "auto"):
+        if issue not in ("auto", "graph"):
+            raise ValueError("GraphedPretextStep: issue is 'auto' (graph only when the host is the limiter) or 'graph' (always)")
+        self.issue = issue
+        self.eager_keys: Dict[Tuple, str] = {}    # configurations that stay eager under issue="auto", with the measurement
         self.wrapped = model
         self.model = getattr(model, "module", model)
         self.criterion, self.optimizer = criterion, optimizer
@@ -113,8 +125,12 @@ class GraphedPretextStep:
             # the first steps of a configuration run eagerly (lazy initialisation inside the library, allocator pools, the
             # optimizer's momentum buffers, packed-weight sets), then the configuration is captured
             done = self.eager_steps.get(key, 0)
+            if key in self.eager_keys:
+                return self._eager(st["im_q"], st["im_k"], host)[:5]
             if done < self.warmup:
                 self.eager_steps[key] = done + 1
+                if done == self.warmup - 1 and self.issue == "auto":
+                    return self._measured_eager(key, host)[:5]
                 return self._eager(st["im_q"], st["im_k"], host)[:5]
             entry = self._capture(key, host)
             if entry is None:
@@ -122,6 +138,26 @@ class GraphedPretextStep:
         self.graphs[key] = self.graphs.pop(key)         # most recently used last
         entry[0].replay()
         return entry[1]
+
+    def _measured_eager(self, key, host):
+        """The last eager warm-up step of a configuration, timed on both sides (empty queue at its start): does the host keep ahead?"""
+        import time
+        st = self.static
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        t0 = time.perf_counter()
+        out = self._eager(st["im_q"], st["im_k"], host)
+        host_ms = (time.perf_counter() - t0) * 1e3
+        e1.record()
+        e1.synchronize()
+        gpu_ms = e0.elapsed_time(e1)
+        if host_ms <= self.HOST_BOUND * gpu_ms:
+            self.eager_keys[key] = (f"issued eagerly by policy: the host issues this step in {host_ms:.1f} ms of the {gpu_ms:.1f} ms it runs "
+                                    f"(a replayed graph pays off above {self.HOST_BOUND:.0%})")
+            self.fallback_reason = self.eager_keys[key]
+            log.info("rspnet_amd: pretext step (speed %s) %s", key[0], self.eager_keys[key])
+        return out
 
     def _capture(self, key, host):
         from . import ops as _ops

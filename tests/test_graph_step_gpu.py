@@ -38,7 +38,7 @@ def test_graphed_step_equals_eager_step(arch, B, HW):
         torch.cuda.manual_seed(7)
         random.seed(7)
         wrapped, crit, opt = _build(arch, K)
-        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2) if mode == "graph" else None
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2, issue="graph") if mode == "graph" else None
         trace = []
         for im_q, im_k in clips:
             if stepper is None:
@@ -76,7 +76,7 @@ def test_one_graph_per_speed_and_learning_rate():
         torch.cuda.manual_seed(11)
         random.seed(11)
         wrapped, crit, opt = _build(arch, K, speeds=(2, 1))
-        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=1) if mode == "graph" else None
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=1, issue="graph") if mode == "graph" else None
         if stepper is not None:
             stepper.MAX_GRAPHS = 3               # 2 speeds x 2 learning rates = 4 configurations: one graph must be retired
         losses, speeds = [], []
@@ -104,3 +104,26 @@ def test_one_graph_per_speed_and_learning_rate():
         assert torch.equal(a, b), (i, float(a), float(b))
     for k in se:
         assert torch.equal(se[k], sg[k]), k
+
+
+def test_issue_policy_graphs_only_the_host_bound_step():
+    """issue="auto": the last eager warm-up step is timed on both sides; a step the host issues well inside its GPU time stays
+    eager (full-size C3D: ~4 ms of ~92), a step the host cannot keep ahead of is captured (the same model on 32x32 crops: its GPU
+    time is a fraction of the Python time)."""
+    from rspnet_amd.graph_step import GraphedPretextStep
+    for B, HW, expect_graph in ((32, 112, False), (2, 32, True)):
+        torch.manual_seed(7)
+        random.seed(7)
+        wrapped, crit, opt = _build("c3d", 64)
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2)
+        im_q, im_k = (torch.randn(B, 3, 32, HW, HW, device=DEV) for _ in range(2))
+        for _ in range(4):
+            loss = stepper(im_q, im_k)[0]
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        if expect_graph:
+            assert len(stepper.graphs) == 1 and not stepper.eager_keys, stepper.eager_keys
+        else:
+            assert not stepper.graphs and len(stepper.eager_keys) == 1 and "by policy" in stepper.fallback_reason
+        del stepper, wrapped, crit, opt
+        torch.cuda.empty_cache()

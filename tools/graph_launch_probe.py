@@ -24,7 +24,7 @@ crit = Loss(margin=2.0, A=1.0, M=1.0)
 opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.05, momentum=0.9, weight_decay=1e-4)
 im_q = torch.randn(B, 3, 32, hw, hw, device=dev)
 im_k = torch.randn(B, 3, 32, hw, hw, device=dev)
-stepper = GraphedPretextStep(model, crit, opt)
+stepper = GraphedPretextStep(model, crit, opt, issue="graph")
 for _ in range(6):
     stepper(im_q, im_k)
 torch.cuda.synchronize()
