@@ -1760,10 +1760,14 @@ SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, i
   if (nchunks < 8) return best;
   const double t_chunk = 2.35e-6 * wpc * bn / 128.0, t_chunk1 = 2.7e-6 * bn / 128.0;   // measured on the 128x128 tile
   const double ovh = 3.0;   // prologue + epilogue of a unit, in chunk times
+  // The matrix pipe is the CU's: with more than one unit per CU the time is (units on the fullest CU) x (a unit's chunks), whatever
+  // the number of co-resident workgroups — 294 tiles on 256 CUs take two tile times (38 CUs hold two), and a K split that leaves
+  // every CU three or four shorter units is faster (S3D-G's 14x14 layers: tools/small_launch_probe.py).  (Until round 4 this was
+  // quantised by SLOTS: 588 units counted as two rounds of 512.)
   auto round_time = [&](long long units, int chunks) {
     if (units <= 0) return 0.0;
     if (units <= 256) return (chunks + ovh) * t_chunk1;            // one workgroup per CU: no sharing of the matrix pipe
-    return (double)rsp_cdiv(units, slots) * (chunks + ovh) * t_chunk;
+    return (double)rsp_cdiv(units, 256) * (chunks + ovh) * (t_chunk / wpc);
   };
   int full = tiles / slots * slots;
   full -= full % n_tiles;
