@@ -267,11 +267,6 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   }
 }
 
-// disjoint windows without padding: every window position of every output is in bounds
-__device__ __forceinline__ bool windows_tile(const rsp_pool3d_desc& d) {
-  return d.kT == d.sT && d.kH == d.sH && d.kW == d.sW && !(d.pT | d.pH | d.pW);
-}
-
 // offsets (in positions) of the NW window positions from the window's first one, scan order (kt, kh, kw)
 template <int NW>
 __device__ __forceinline__ void window_offsets(const rsp_pool3d_desc& d, long long (&off)[NW]) {
