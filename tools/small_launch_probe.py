@@ -20,6 +20,11 @@ CASES = [   # name, N, D, H, W, Cin, Cout, k, s, p
     ("s3dg_3b.b1 sp", 16, 8, 28, 28, 96, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("r3d_l3 3x3x3", 32, 4, 14, 14, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ("r3d_l4 3x3x3", 32, 2, 7, 7, 512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # exactly 1 / 2 / 3 / 6 tiles of 128x128 per CU, K = 1152 (36 chunks): time per chunk against the workgroups sharing a CU
+    ("256 tiles", 16, 4, 16, 32, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("512 tiles", 16, 8, 16, 32, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("768 tiles", 16, 12, 16, 32, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("1536 tiles", 16, 24, 16, 32, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ]
 for name, N, D, H, W, ci, co, k, s, p in CASES:
     g = ConvGeom(N, D, H, W, ci, co, k, s, p)
