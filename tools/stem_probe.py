@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 g = ConvGeom(32, 16, 112, 112, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), Cin_alg=3)
 x = torch.randn(32, 16, 112, 112, 4, device=dev)
 x[..., 3] = 0
-w = torch.randn(64, 4, 3, 3, 3, device=dev) * 0.1
+w = torch.randn(64, 3, 3, 3, 3, device=dev) * 0.1      # RGB filters: the three-k-step instance
 bias = torch.randn(64, device=dev)
 ps = be.pack_set([(g, 0, w)])
 ps.run()
