@@ -85,7 +85,9 @@ int rsp_conv3d_dgrad_packed(const rsp_conv3d_desc* d, const float* dy, const flo
  * buffers do not move — uploads the array, and replays it with ONE launch per step and encoder.
  *   rsp_conv3d_pack_jobs: fills (host memory) the jobs that re-pack w_ref (reference layout (Cout_src, Cin_src, kT, kH, kW)) into
  *     w_packed for descriptor d; d->Cout / d->Cin may exceed the source dims, the excess is zero (channel padding, e.g. the
- *     3 -> 4 channel stems).  which = 0: forward layout (1 job, rsp_conv3d_packed_fwd_elems floats); which = 1: all dgrad
+ *     3 -> 4 channel stems; for those the library notes, per w_packed address, that the filters have three real input channels, and
+ *     rsp_conv3d_fwd on that buffer skips the zero fourth channel's multiply-adds).  which = 0: forward layout (1 job,
+ *     rsp_conv3d_packed_fwd_elems floats); which = 1: all dgrad
  *     stride-class layouts (<= sT*sH*sW jobs, rsp_conv3d_packed_dgrad_elems floats).  Returns the number of jobs or RSP_E*.
  *   rsp_pack_run: executes n_jobs jobs stored in DEVICE memory; max_blocks = the largest `blocks` field among them (grid.x). */
 typedef struct rsp_pack_job {
