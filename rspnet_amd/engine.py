@@ -315,7 +315,7 @@ class BranchStreams:
     #  a second matrix kernel fills the ragged ends of the launches — C3D 93.7 -> 92.9 ms with conv3a / conv4 included;
     # R(2+1)D's 266-GFLOP weight gradients stream 1.3 GB each and stay in line (77.9 -> 80.2 ms beside the input gradient)
     MID_WGRAD_FLOPS = float(os.environ.get("RSP_WGRAD_MID_GFLOP", "400")) * 1e9
-    MID_WGRAD_BYTES = 450e6
+    MID_WGRAD_BYTES = float(os.environ.get("RSP_WGRAD_MID_MB", "450")) * 1e6
     EAGER_TASKS = not os.environ.get("RSP_NO_EAGER_OVERLAP")
 
     def __init__(self, x: torch.Tensor):
