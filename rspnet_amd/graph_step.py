@@ -56,6 +56,10 @@ class GraphedPretextStep:
         # at least two eager steps: the packed-weight sets an encoder builds during its first step are merged into one batched
         # set (a host-to-device copy of the job table) when its second step re-packs them
         self.warmup = max(2, int(warmup))
+        if issue == "auto":
+            # ... and the step that is MEASURED must be an ordinary one: the third (the second still merges the packed-weight sets;
+            # on a cold box its host time once tipped a 74 ms R(2+1)D step over the threshold)
+            self.warmup = max(3, self.warmup)
         self.graphs: Dict[Tuple, Tuple] = {}      # insertion order = least recently used first
         self.eager_steps: Dict[Tuple, int] = {}
         self.static = None
