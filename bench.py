@@ -163,6 +163,38 @@ def host_cpu():
     return model, max(1, min(len(pairs) or avail, avail))
 
 
+def rank_cpu_set(local_rank: int, local_ws: int):
+    """The logical CPUs rank `local_rank` of `local_ws` ranks on this node keeps to itself: the CPUs this process may use, ordered
+    by (package, physical core, hyper-thread), cut into `local_ws` contiguous slices of whole physical cores — eight interpreters
+    plus their RCCL proxy threads on shared cores is the first-run hazard of a multi-GPU job (pretrain.py:278-283 spawns one
+    process per GPU and leaves placement to the OS).  Ranks 0..ws/2-1 land on the first package, the rest on the second, which is
+    how the GPUs of an 8 x MI355X node hang off its two sockets."""
+    avail = sorted(os.sched_getaffinity(0))
+    if local_ws <= 1 or len(avail) < local_ws:
+        return None
+
+    def topo(cpu):
+        base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+        try:
+            with open(base + "physical_package_id") as f:
+                pkg = int(f.read())
+            with open(base + "core_id") as f:
+                core = int(f.read())
+            return pkg, core
+        except (OSError, ValueError):
+            return 0, cpu
+
+    cores = {}
+    for c in avail:
+        cores.setdefault(topo(c), []).append(c)
+    phys = [cores[k] for k in sorted(cores)]
+    per = len(phys) // local_ws
+    if per < 1:
+        return None
+    mine = phys[local_rank * per:(local_rank + 1) * per]
+    return sorted(c for grp in mine for c in grp)
+
+
 def _fingerprint(state, im_q, im_k, first):
     """Cheap identity of what the replayed step consumes (the bench's state and clips are seeded: the same numbers on every box)."""
     import torch
@@ -349,7 +381,8 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     im_q = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
     im_k = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
 
-    use_graph = cuda and (not coll or os.environ.get("RSP_GRAPH_COLLECTIVES")) and args.graph in ("on", "auto")
+    # with the collectives on (N > 1, --force-dp) the stepper replays the step as HIP-graph SEGMENTS between its collective points
+    use_graph = cuda and args.graph in ("on", "auto")
     stepper = None
     if use_graph:
         from rspnet_amd.graph_step import GraphedPretextStep
@@ -406,7 +439,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     graphed = stepper is not None and not stepper.disabled and len(stepper.graphs) > 0
     # (per-launch events are not recorded in the timed region: a replayed graph has none, and the eager step runs its independent
     #  passes on side streams, where a launch's interval also holds its neighbours' time — see the roofline pass below)
-    if coll and not graphed:
+    if coll:
         inner.comm_log = {}
     marks, host, hbm, waits = [], [], [], []
     if cuda:
@@ -432,7 +465,15 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     final_loss = float(loss.detach())
     step_ms = dt / steps * 1e3
     res = {"clips_per_s": ws * B * steps / dt, "ms_per_step": step_ms, "final_loss": final_loss, "K": K, "lr": lr, "B": B,
-           "hw": hw, "graph": bool(graphed), "collectives": coll}
+           "hw": hw, "graph": bool(graphed), "collectives": coll,
+           "issue_mode": ("graph_segments" if stepper.mode == "segments" else "graph") if graphed else "eager"}
+    if cuda:
+        # worst rank's host time to issue one step (Python + launches + collective calls, without the stepper's back-pressure wait):
+        # the number that says whether a rank is host-bound
+        hs = torch.tensor([_pct([h - w for h, w in zip(host, waits)], 0.5)], dtype=torch.float64, device=dev)
+        if ws > 1:
+            dist.all_reduce(hs, op=dist.ReduceOp.MAX)
+        res["host_submit_p50_max_over_ranks"] = round(float(hs.item()), 3)
     if graphed and args.eager_steps > 0:
         # the same step issued eagerly with its side streams — how a run with more than one rank issues it (RCCL collectives are
         # not captured): the N = 1 point of a scaling curve in the N > 1 issue mode
@@ -583,6 +624,13 @@ def run_rank(args):
     cpu_selftest = args.selftest_cpu
     if cpu_selftest and args.selftest_hang_rank == rank:
         time.sleep(3600)                                    # launcher-deadline self-test: this rank never joins the group
+    # each rank's host threads (this interpreter, RCCL's proxy threads, gloo) stay on the rank's own cores: set BEFORE the first
+    # GPU / process-group call, which is where those threads are created
+    cpus = None
+    if ws > 1 and hasattr(os, "sched_setaffinity") and not os.environ.get("RSP_NO_PIN"):
+        cpus = rank_cpu_set(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", ws)))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
     if cpu_selftest:
         dev = torch.device("cpu")
         torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(ws, 1) // 2))
@@ -611,6 +659,20 @@ def run_rank(args):
         from cpu_ops import CpuOps                     # TEST backend: exercises launcher + host logic only
         ops.set_backend(CpuOps())
 
+    # who is in the job: world size AND the number of distinct devices behind the ranks (two ranks on one GPU would still "scale")
+    rccl_ranks = None
+    if ws > 1 or args.force_dp:
+        if cpu_selftest:
+            ident = f"cpu-process-{os.getpid()}"
+        else:
+            pr = torch.cuda.get_device_properties(dev)
+            ident = str(getattr(pr, "uuid", None) or (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", local_rank),
+                                                      getattr(pr, "pci_device_id", 0)))
+        idents = [None] * ws
+        dist.all_gather_object(idents, (ident, len(cpus) if cpus else len(os.sched_getaffinity(0))))
+        rccl_ranks = {"world_size": ws, "distinct_devices": len({i for i, _ in idents}), "backend": dist.get_backend(),
+                      "host_cpus_per_rank": [n for _, n in idents], "pinned": bool(cpus)}
+
     B, hw, base_lr = ARCHS[args.arch]
     B = args.batch or B
     hw = args.hw or hw
@@ -629,9 +691,17 @@ def run_rank(args):
                        "global_batch": B * ws, "parallelism": f"dp{ws}"},
             "final_loss": round(m["final_loss"], 5),
         }
-        res["config"]["step_issue"] = ("one replayed HIP graph (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)"
-                                       if m["graph"] else "eager launches (independent passes on side streams)") + \
+        res["config"]["step_issue"] = {
+            "graph": "one replayed HIP graph (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
+            "graph_segments": "four replayed HIP-graph segments between the step's collective points, RCCL calls issued eagerly in "
+                              "between (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
+            "eager": "eager launches (independent passes on side streams)"}[m["issue_mode"]] + \
             "; roofline numbers from a one-stream eager pass of the same step outside the timed region"
+        res["step_issue_mode"] = m["issue_mode"]
+        if rccl_ranks is not None:
+            res["rccl_ranks"] = rccl_ranks
+        if "host_submit_p50_max_over_ranks" in m:
+            res["host_submit_p50_max_over_ranks"] = m["host_submit_p50_max_over_ranks"]
         if m["collectives"]:
             res["config"]["collectives"] = ("RCCL (nccl backend): clip all-to-all x2, fused key all-gather x1, bucketed gradient "
                                             "all-reduce from inside backward, gloo side group for the step's random draws"
@@ -648,18 +718,32 @@ def run_rank(args):
     # interpreter of this file (fresh process, started and waited for — never exec'ed into): whatever happens there — an
     # out-of-memory kill, a runtime crash inside a graph capture — cannot take the headline line down with it.
     if ws == 1 and not cpu_selftest and args.other_workloads and args.arch == "c3d" and not args.batch and not args.hw:
+        def child(arch, extra, steps, warmup):
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--arch", arch, "--steps", str(steps), "--warmup", str(warmup),
+                   "--queue", str(args.queue), "--graph", args.graph, "--no-cpu-baseline", "--no-other-workloads"] + extra
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr.strip()[-300:]}")
+            return json.loads(lines[-1])
+
+        def dp_child(arch, plain_value):
+            """The data-parallel path itself on this one GPU: a child run with the real RCCL group of one rank and every collective
+            of the N > 1 step forced on (what the 2/4/8-GPU runs execute, minus the wires), in the issue mode N > 1 ranks use."""
+            try:
+                od = child(arch, ["--force-dp", "--eager-steps", "0"], args.other_steps, args.other_warmup)
+                return {"clips_per_s": round(od["value"], 2), "ms_per_step": od["ms_per_step"], "steps": od["steps"],
+                        "comm_ms": od.get("comm_ms"), "collectives": od["config"].get("collectives"),
+                        "step_issue_mode": od.get("step_issue_mode"), "step_issue": od["config"]["step_issue"],
+                        "host_submit_p50": (od.get("steps_ms") or {}).get("host_submit_p50"), "rccl_ranks": od.get("rccl_ranks"),
+                        "final_loss": od["final_loss"], "vs_this_line": round(od["value"] / plain_value, 4)}
+            except Exception as e:      # noqa: BLE001
+                return {"error": f"{type(e).__name__}: {e}"[:400]}
+
         others = {}
         for arch in ("resnet18", "r2plus1d-vcop", "s3dg"):
-            oB, ohw, _ = ARCHS[arch]
-            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--arch", arch, "--steps", str(args.other_steps),
-                   "--warmup", str(args.other_warmup), "--queue", str(args.queue), "--graph", args.graph, "--no-cpu-baseline",
-                   "--no-other-workloads"]
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-                lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-                if r.returncode != 0 or not lines:
-                    raise RuntimeError(f"rc {r.returncode}: {r.stderr.strip()[-300:]}")
-                od = json.loads(lines[-1])
+                od = child(arch, [], args.other_steps, args.other_warmup)
                 rf = od["roofline"]
                 others[arch] = {"workload": od["config"]["workload"], "clips_per_s": round(od["value"], 2),
                                 "ms_per_step": od["ms_per_step"], "steps": od["steps"], "warmup": od["warmup"],
@@ -668,29 +752,22 @@ def run_rank(args):
                                 "conv_launches_frac": rf["all_conv_launches"]["frac"],
                                 "conv_ms_per_step": rf["all_conv_launches"]["ms_per_step"], "dominant_kernel": rf["kernel"],
                                 "dominant_kernel_frac": rf["frac"], "dominant_kernel_share_of_step": rf["share_of_step"],
-                                "final_loss": od["final_loss"],
+                                "final_loss": od["final_loss"], "step_issue_mode": od.get("step_issue_mode"),
                                 "step_issue": od["config"]["step_issue"]
                                 + (f" (graph capture fell back: {od['graph_fallback']})" if "graph_fallback" in od else "")
                                 + (f" ({od['issue_policy']})" if "issue_policy" in od else "")}
+                # ... and the same backbone the way N > 1 ranks run it (the N = 1 point of ITS scaling curve, same issue mode)
+                others[arch]["dp_path_at_one_rank"] = dp_child(arch, od["value"])
             except Exception as e:      # noqa: BLE001 - reported in the line, never fatal for the headline
                 others[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}
         res["other_workloads"] = others
-        # ... and the data-parallel path itself on this one GPU: a child run with the real RCCL group of one rank and every
-        # collective of the N > 1 step forced on (what the 2/4/8-GPU runs execute, minus the wires)
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-dp", "--steps", str(args.other_steps), "--warmup",
-               str(args.other_warmup), "--queue", str(args.queue), "--no-cpu-baseline", "--no-other-workloads"]
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-            if r.returncode != 0 or not lines:
-                raise RuntimeError(f"rc {r.returncode}: {r.stderr.strip()[-300:]}")
-            od = json.loads(lines[-1])
-            res["dp_path_at_one_rank"] = {"clips_per_s": round(od["value"], 2), "ms_per_step": od["ms_per_step"], "steps": od["steps"],
-                                          "comm_ms": od.get("comm_ms"), "collectives": od["config"].get("collectives"),
-                                          "step_issue": od["config"]["step_issue"], "final_loss": od["final_loss"],
-                                          "vs_this_line": round(od["value"] / res["value"], 4)}
-        except Exception as e:      # noqa: BLE001
-            res["dp_path_at_one_rank"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        res["dp_path_at_one_rank"] = dp_child("c3d", res["value"])
+        # the N = 1 number in the issue mode the N > 1 points of a scaling curve use: efficiency is never computed across modes
+        dp1 = res["dp_path_at_one_rank"]
+        if "error" not in dp1:
+            res["n1_same_mode"] = {"clips_per_s": dp1["clips_per_s"], "step_issue_mode": dp1["step_issue_mode"],
+                                   "note": "this workload at one rank with every data-parallel collective on (RCCL group of one rank), "
+                                           "issued the way ranks of an N > 1 job issue it: the N = 1 point to divide N > 1 values by"}
     if rank == 0:
         if want_cpu:
             try:

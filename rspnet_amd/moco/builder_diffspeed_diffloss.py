@@ -184,6 +184,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         self.comm_log = None                  # set to {} to collect per-collective stall times (see _comm)
         self._pending = []
         self._q_version = None
+        self._defer_reduce = False            # True: backward leaves the gradient all-reduce to `_reduce_gradients` (segmented replay)
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
 
     def _dp(self):
@@ -467,6 +468,9 @@ class MoCoDiffLossTwoFc(nn.Module):
             self._ptr_host = None
             return
         if self._ptr_host is None:
+            # same validation as the device-pointer path (stricter than the reference, which fails only at the step whose slab no
+            # longer fits, :353-356 — a misaligned pointer always reaches that step): both issue modes refuse the same checkpoints
+            self._check_queue_ptr(n)
             self._ptr_host = int(self.queue_ptr)
         ptr = self._ptr_host
         _ops.backend().queue_enqueue(self.queue, ptr, keys_all.contiguous())
@@ -481,6 +485,12 @@ class MoCoDiffLossTwoFc(nn.Module):
         backward), then gradients are averaged as DDP does (moco/__init__.py:49-53)."""
         flat = self._flat
         _, ws, coll = self._dp()
+        if self._defer_reduce:
+            # segmented replay (rspnet_amd/graph_step.py): the backward is one captured graph; `_reduce_gradients` /
+            # `_scale_gradients` follow it
+            self.encoder_q.backward_ndhwc(ectx, dqA, dqM, flat.grad_of, None)
+            flat.attach_grads()
+            return
         buckets = flat.buckets(BUCKET_FLOATS) if coll else []
         handed_out, launched, handles = set(), set(), []
 
@@ -510,6 +520,25 @@ class MoCoDiffLossTwoFc(nn.Module):
         if ws > 1:
             flat.g_flat.mul_(1.0 / ws)
         flat.attach_grads()
+
+    @torch.no_grad()
+    def _reduce_gradients(self):
+        """The gradient all-reduce of a step whose backward ran with `_defer_reduce`: the same 32 MiB buckets, issued back to back
+        after the backward (a replayed graph cannot launch them from inside)."""
+        flat = self._flat
+        if not self._dp()[2]:
+            return
+        handles = [dist.all_reduce(flat.g_flat[s:e], async_op=True) for s, e, _ in flat.buckets(BUCKET_FLOATS)]
+        with self._comm("allreduce_wait"):
+            for h in handles:
+                h.wait()
+
+    @torch.no_grad()
+    def _scale_gradients(self):
+        """... and DDP's average (moco/__init__.py:49-53)."""
+        ws = self._dp()[1]
+        if ws > 1:
+            self._flat.g_flat.mul_(1.0 / ws)
 
     # ---- forward ------------------------------------------------------------------------------------------------------
     def _host_part(self, B: int, dev, static=None):
@@ -541,13 +570,26 @@ class MoCoDiffLossTwoFc(nn.Module):
         return self._device_part(im_q, im_k, self._host_part(im_q.shape[0], im_q.device))
 
     def _device_part(self, im_q: Tensor, im_k: Tensor, host):
-        """The step's device work under the host decisions of `_host_part` (one function, so that it can be captured whole)."""
+        """The step's device work under the host decisions of `_host_part`: its phases back to back, the collectives between them
+        issued asynchronously (the second clip exchange runs under the first key pass, the key all-gather under the tail of the
+        query forward).  rspnet_amd/graph_step.py replays the same phases as HIP graphs with the collectives in between."""
+        st = self._phase_top(im_q, im_k, host)
+        self._phase_exchange(st, host, wait=False)
+        self._phase_passes(st, join_query=False)
+        self._phase_gather(st)
+        return self._phase_logits(st)
+
+    # ---- the step in phases: device work between the collective points -------------------------------------------------------
+    def _phase_top(self, im_q: Tensor, im_k: Tensor, host):
+        """Momentum update (:337-343), _diff_speed (:421-447) and the three clip gathers: the send buffers of both shuffle-BN
+        exchanges (each clip has exactly one destination rank) and the query clips.  Returns the step's state dict."""
         be = _ops.backend()
         self._prepare()
         dev = im_q.device
         B, C, T, H, W = im_q.shape
         im_q, im_k = im_q.contiguous(), im_k.contiguous()
         self._last_k = [None, None]          # (k_negative pass, k pass)
+        _, _, coll = self._dp()
         with torch.no_grad():
             self._momentum_update_key_encoder()
             # _diff_speed (:421-447)
@@ -561,55 +603,107 @@ class MoCoDiffLossTwoFc(nn.Module):
             step_q = torch.full((B,), speed, dtype=torch.int32, device=dev)
             step_q.index_fill_(0, random_indices[:n1], 1)               # s1 rows play q,k at normal speed
             step_kn = (1 + speed) - step_q if speed != 1 else step_q.clone()   # k_negative swaps the speeds
-            plan1, plan2 = host["plans"]
             src1, loc1, src2, loc2 = host["idx"]
-            # both shuffle-BN exchanges and the query clips are issued up front (one all-to-all each at > 1 rank: the second
-            # one overlaps the first key pass); the key passes keep the reference's order (k_negative first, :445, then k, :512)
-            ex_neg = self._shuffle_exchange(im_k, step_kn, T_real, plan1, src1)
-            ex_k = self._shuffle_exchange(im_k, step_q, T_real, plan2, src2)
+            cpad = max(C, INPUT_CHANNEL_PAD)
+            # the key passes keep the reference's order (k_negative first, :445, then k, :512)
+            xs_neg = be.clip_gather(im_k, src1, step_kn[src1.long()].contiguous(), T_real, cpad)
+            xs_k = be.clip_gather(im_k, src2, step_q[src2.long()].contiguous(), T_real, cpad)
             src = torch.arange(B, dtype=torch.int32, device=dev)
-            x_q = be.clip_gather(im_q, src, step_q, T_real, max(C, INPUT_CHANNEL_PAD))
+            x_q = be.clip_gather(im_q, src, step_q, T_real, cpad)
             self._nbt_q += 1
-            # The query encoder's forward does not depend on the key passes (other weights, other BatchNorm buffers) before the
-            # logits: it is forked onto its own stream and runs beside them — the small late layers of either pass leave most of
-            # the machine idle on their own.  (Captured into a HIP graph, rspnet_amd/graph_step.py, or issued eagerly; any world size.)
-            side = None
-            if self.overlap_query and dev.type == "cuda" and (torch.cuda.is_current_stream_capturing() or self.overlap_query_eager):
-                main = torch.cuda.current_stream(dev)
-                side = self._query_stream = self._query_stream or torch.cuda.Stream(device=dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._q_pre = self.encoder_q.forward_ndhwc(x_q, keep=True)
-            # The two key passes (k_negative first, :445; then k, :512) go through the same encoder_k.  The second one defers its
-            # running-statistics update (_deferred_k), so it is forked onto its own stream beside the first (and beside the query
-            # forward); the deferred update is applied after both, in the reference's order.  Neither pass holds a collective of
-            # its own beyond the wait for its clips: the features of both travel in one all-gather after the join.
-            deferred = self._deferred_k()
             self._nbt_k += 2
             self.encoder_k._packed.refresh_now()      # (re-pack of the momentum-updated weights: before the passes fork)
-            side_k = None
-            if side is not None and self.overlap_keys:
-                main = torch.cuda.current_stream(dev)
-                side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
-                side_k.wait_stream(main)
-                with torch.cuda.stream(side_k):
-                    feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
-            feats_neg, dim = self._key_pass(ex_neg, "kneg", bump=False)
-            if side_k is None:
+            st = {"B": B, "dev": dev, "x_q": x_q, "send": (xs_neg, xs_k), "loc": (loc1, loc2), "handles": [None, None],
+                  "arrival": [np.arange(B), np.arange(B)],
+                  # with the collectives on, the clips arrive in buffers of their own (every rank receives exactly B clips)
+                  "recv": (torch.empty_like(xs_neg), torch.empty_like(xs_k)) if coll else (xs_neg, xs_k)}
+        return st
+
+    @torch.no_grad()
+    def _phase_exchange(self, st, host, wait: bool):
+        """Shuffle-BN's sample exchange (:361-387): ONE all-to-all per key pass over the already sub-sampled clips.  Both are
+        started back to back — the permutations are known at the top of the step — so the second one runs over xGMI under the
+        first key pass's convolutions.  wait=False: the key passes wait for their clips themselves (`_key_pass`)."""
+        _, _, coll = self._dp()
+        for i, plan in enumerate(host["plans"]):
+            _, _, in_splits, out_splits, arrival = plan
+            st["arrival"][i] = arrival
+            if coll:
+                st["handles"][i] = dist.all_to_all_single(st["recv"][i], st["send"][i], out_splits, in_splits, async_op=True)
+        if wait:
+            for i, tag in enumerate(("kneg", "k")):
+                h, st["handles"][i] = st["handles"][i], None
+                if h is not None:
+                    with self._comm("all_to_all_" + tag):
+                        h.wait()
+
+    @torch.no_grad()
+    def _phase_passes(self, st, join_query: bool):
+        """The three forward passes: query encoder (kept for backward), k_negative and k through encoder_k."""
+        dev = st["dev"]
+        # The query encoder's forward does not depend on the key passes (other weights, other BatchNorm buffers) before the
+        # logits: it is forked onto its own stream and runs beside them — the small late layers of either pass leave most of
+        # the machine idle on their own.  (Captured into a HIP graph, rspnet_amd/graph_step.py, or issued eagerly; any world size.)
+        side = None
+        if self.overlap_query and dev.type == "cuda" and (torch.cuda.is_current_stream_capturing() or self.overlap_query_eager):
+            main = torch.cuda.current_stream(dev)
+            side = self._query_stream = self._query_stream or torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._q_pre = self.encoder_q.forward_ndhwc(st["x_q"], keep=True)
+        # The two key passes (k_negative first, :445; then k, :512) go through the same encoder_k.  The second one defers its
+        # running-statistics update (_deferred_k), so it is forked onto its own stream beside the first (and beside the query
+        # forward); the deferred update is applied after both, in the reference's order.  Neither pass holds a collective of
+        # its own beyond the wait for its clips: the features of both travel in one all-gather after the join.
+        deferred = self._deferred_k()
+        ex_neg = (st["recv"][0], st["handles"][0], st["arrival"][0])
+        ex_k = (st["recv"][1], st["handles"][1], st["arrival"][1])
+        st["handles"] = [None, None]
+        side_k = None
+        if side is not None and self.overlap_keys:
+            main = torch.cuda.current_stream(dev)
+            side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
+            side_k.wait_stream(main)
+            with torch.cuda.stream(side_k):
                 feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
-            else:
-                torch.cuda.current_stream(dev).wait_stream(side_k)
-            self._ema_k.run()
-            del ex_neg, ex_k
+        feats_neg, dim = self._key_pass(ex_neg, "kneg", bump=False)
+        if side_k is None:
+            feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
+        else:
+            torch.cuda.current_stream(dev).wait_stream(side_k)
+        self._ema_k.run()
+        _, ws, coll = self._dp()
+        mine = torch.stack([feats_neg, feats_k])                    # (2, B, width)
+        st["dim"], st["mine"], st["side"] = dim, mine, side
+        st["gathered"] = (torch.empty((ws * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device) if coll else mine)
+        if join_query and side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            st["side"] = None
+
+    @torch.no_grad()
+    def _phase_gather(self, st):
+        """ONE all-gather per step carries the fused (A | M) features of BOTH key passes: it serves the two un-shuffles
+        (:389-406, twice) and the queue's key all-gather (:348) — five small collectives in the reference."""
+        if self._dp()[2]:
+            with self._comm("all_gather_keys"):
+                dist.all_gather_into_tensor(st["gathered"], st["mine"])
+
+    def _phase_logits(self, st):
+        """Un-shuffle (:389-406), the five logits (:521-538) as the autograd node of the query encoder, enqueue (:345-359)."""
+        be = _ops.backend()
+        B, dev, dim = st["B"], st["dev"], st["dim"]
+        with torch.no_grad():
             rank = self._dp()[0]
-            kneg_all, k_all = self._gather_keys(feats_neg, feats_k, loc1, loc2)
+            flat = st["gathered"].view(-1, st["mine"].shape[2])
+            kneg_all, k_all = be.rows_gather(flat, st["loc"][0]), be.rows_gather(flat, st["loc"][1])
             k_mine, kneg_mine = k_all[rank * B:(rank + 1) * B], kneg_all[rank * B:(rank + 1) * B]
             k_A, k_M = k_mine[:, :dim].contiguous(), k_mine[:, dim:].contiguous()
             kneg_A, kneg_M = kneg_mine[:, :dim].contiguous(), kneg_mine[:, dim:].contiguous()
-            if side is not None:
-                torch.cuda.current_stream(dev).wait_stream(side)
+            if st["side"] is not None:
+                torch.cuda.current_stream(dev).wait_stream(st["side"])
+                st["side"] = None
 
-        l1, l2, lp, ln = _PretextFn.apply(self, x_q, (k_A, k_M, kneg_A, kneg_M), *self._q_params)
+        l1, l2, lp, ln = _PretextFn.apply(self, st["x_q"], (k_A, k_M, kneg_A, kneg_M), *self._q_params)
 
         labels_A = torch.zeros(B, dtype=torch.long, device=dev)
         labels_M = torch.ones_like(labels_A)

@@ -67,3 +67,85 @@ def forced_worker(rank, backend, arch, seed, port, out_path, graph=False):
                    "side_group": groups[-1] if groups else None}, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def segmented_worker(rank, arch, B, HW, port, out_path, steps=7):
+    """One RCCL rank with every collective forced on: `steps` consecutive steps of two identically initialised models — one
+    driven by the eager data-parallel loop body (bucketed all-reduce from inside backward), one by GraphedPretextStep, which at
+    collectives-on replays the step as HIP-graph SEGMENTS between the collective points — must leave bit-identical losses, logits,
+    parameters, queue and pointer (tests/test_graph_step_gpu.py's check for the N > 1 issue mode)."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import random
+    import torch
+    import torch.distributed as dist
+    from golden_util import load_spec
+    from model_util import make_cfg
+    from oracle import portable as P
+    from rspnet_amd import ops
+    from rspnet_amd.graph_step import GraphedPretextStep
+    from rspnet_amd.moco import Loss, ModelFactory
+    from rspnet_amd.optim import SGD
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["RSP_FORCE_COLLECTIVES"] = "1"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    assert ops.backend().name == "hip"
+    K = 64
+    calls = collections.Counter()
+    for name in ("all_to_all_single", "all_gather_into_tensor", "all_reduce"):
+        def make(name, fn):
+            def spy(*a, **k):
+                calls[name] += 1
+                return fn(*a, **k)
+            return spy
+        setattr(dist, name, make(name, getattr(dist, name)))
+    clips = [tuple(torch.from_numpy(c).to(dev) for c in P.clips(10 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
+    results, info = [], {}
+    for mode in ("eager", "segments"):
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        random.seed(7)
+        wrapped = ModelFactory(make_cfg(arch, K)).build_moco_diffloss(device=dev)
+        spec = dict(load_spec(arch))
+        spec["queue"] = ((128, K), "float32")
+        wrapped.module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.fill_state(spec, 3).items()})
+        wrapped.train()
+        assert wrapped.module._dp()[2], "collectives must be on"
+        crit = Loss(margin=2.0, A=1.0, M=1.0)
+        opt = SGD(wrapped.parameters(), lr=0.05, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=False)
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2, issue="graph") if mode == "segments" else None
+        trace = []
+        before = dict(calls)
+        for im_q, im_k in clips:
+            if stepper is None:
+                out, tgt, rl, rt = wrapped(im_q, im_k)
+                loss, la, lm = crit(out, tgt, rl, rt)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            else:
+                loss, la, lm, out, rl = stepper(im_q, im_k)
+            trace.append((loss.detach().clone(), out[0].detach().clone(), rl[0].detach().clone()))
+        torch.cuda.synchronize()
+        info[mode] = {k: calls[k] - before.get(k, 0) for k in calls}
+        if stepper is not None:
+            assert stepper.mode == "segments" and not stepper.disabled, stepper.fallback_reason
+            assert len(stepper.graphs) == 1
+            seq = next(iter(stepper.graphs.values()))[3]
+            info["graph_segments"] = sum(1 for g, _ in seq if g is not None)
+            info["collective_points"] = sum(1 for g, _ in seq if g is None)
+        results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
+    (te, se), (tg, sg) = results
+    for i, ((l0, o0, r0), (l1, o1, r1)) in enumerate(zip(te, tg)):
+        assert torch.equal(l0, l1) and torch.equal(o0, o1) and torch.equal(r0, r1), (arch, "step", i, float(l0), float(l1))
+    assert int(sg["queue_ptr"]) == int(se["queue_ptr"]) == (steps * B) % K
+    for k in se:
+        assert torch.equal(se[k], sg[k]), (arch, k)
+    with open(out_path, "w") as f:
+        json.dump(info, f)
+    dist.barrier()
+    dist.destroy_process_group()

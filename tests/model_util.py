@@ -45,8 +45,11 @@ class ReplayRNG:
         torch.randperm, random.choice = self._rp, self._ch
 
 
-def run_model_step(arch, meta, inputs, rank, device, optimizer="fused"):
-    """One teacher-forced step of rspnet_amd on `device`.  Returns (out dict, post state dict, momentum_post dict)."""
+def run_model_step(arch, meta, inputs, rank, device, optimizer="fused", issue="eager"):
+    """One teacher-forced step of rspnet_amd on `device`.  Returns (out dict, post state dict, momentum_post dict).
+    issue="segments": the step cut at its collective points as rspnet_amd/graph_step.py replays it at more than one rank
+    (GraphedPretextStep._segments: device segments and collectives alternately, gradient all-reduce after the whole backward) —
+    here every segment is issued eagerly, so the cut itself is what is tested (any device, any op backend)."""
     from rspnet_amd.optim import SGD
     state, mom, clips, perms_B, sh = inputs
     wrapped = ModelFactory(make_cfg(meta.get("arch", arch), meta["K"], fc_type=meta.get("fc_type", "linear"), m=meta["m"],
@@ -67,13 +70,32 @@ def run_model_step(arch, meta, inputs, rank, device, optimizer="fused"):
     crit = Loss(margin=meta["margin"], A=meta["A"], M=meta["M"])
     im_q = torch.from_numpy(clips[rank][0]).to(device)
     im_k = torch.from_numpy(clips[rank][1]).to(device)
-    with ReplayRNG([perms_B[rank], sh[0], sh[1]], meta["speed"]):
-        out, tgt, rl, rt = wrapped(im_q, im_k)
-    loss, loss_A, loss_M = crit(out, tgt, rl, rt)
-    opt.zero_grad()
-    loss.backward()
-    grads = {names[id(p)]: (None if p.grad is None else p.grad.detach().cpu().numpy().copy()) for p in params}
-    opt.step()
+    if issue == "segments":
+        from rspnet_amd.graph_step import GraphedPretextStep
+        stepper = GraphedPretextStep(wrapped, crit, opt)
+        segs, box = stepper._segments(im_q, im_k)
+        assert [k for k, _ in segs] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"]
+        model._defer_reduce = True
+        try:
+            with ReplayRNG([perms_B[rank], sh[0], sh[1]], meta["speed"]):
+                host = model._host_part(im_q.shape[0], device)
+                for _, fn in segs[:-1]:
+                    fn(host)
+        finally:
+            model._defer_reduce = False
+        loss, loss_A, loss_M, out, rl = box["outs"]
+        tgt, rt = torch.zeros(im_q.shape[0], dtype=torch.long), torch.ones(im_q.shape[0], dtype=torch.long)
+        model._scale_gradients()                      # (first half of the last segment; the gradients are read between the two)
+        grads = {names[id(p)]: (None if p.grad is None else p.grad.detach().cpu().numpy().copy()) for p in params}
+        opt.step()
+    else:
+        with ReplayRNG([perms_B[rank], sh[0], sh[1]], meta["speed"]):
+            out, tgt, rl, rt = wrapped(im_q, im_k)
+        loss, loss_A, loss_M = crit(out, tgt, rl, rt)
+        opt.zero_grad()
+        loss.backward()
+        grads = {names[id(p)]: (None if p.grad is None else p.grad.detach().cpu().numpy().copy()) for p in params}
+        opt.step()
     if device.type == "cuda":
         torch.cuda.synchronize()
     q_A, q_M = model._last_q

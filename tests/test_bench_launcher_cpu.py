@@ -35,6 +35,41 @@ def test_bench_self_launches_two_ranks():
     assert all(v >= 0 for v in cm.values())
 
 
+def test_bench_self_launches_eight_ranks():
+    """The driver's last point of the 1/2/4/8 curve, launcher and host logic end to end over gloo: eight interpreters, uneven clip
+    all-to-all splits among eight peers, the key all-gather / un-shuffle map, the global queue (8 x 2 keys per step) — and the
+    line says who was in the job: world size, distinct members, the step-issue mode, every rank's CPU share."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"] + TINY, capture_output=True, text=True, timeout=900, cwd=ROOT, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 16
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
+    rr = d["rccl_ranks"]
+    assert rr["world_size"] == 8 and rr["distinct_devices"] == 8 and rr["backend"] == "gloo" and len(rr["host_cpus_per_rank"]) == 8
+    assert d["step_issue_mode"] == "eager"             # (no HIP graphs on the CPU self-test)
+    assert {"all_to_all_kneg", "all_to_all_k", "all_gather_keys", "allreduce_wait"} <= set(d["comm_ms"])
+    import math
+    assert math.isfinite(d["final_loss"])
+
+
+def test_rank_cpu_sets_are_disjoint_whole_cores():
+    """bench.py pins each rank's host threads to its own physical cores before the first GPU call (rank_cpu_set)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n = len(os.sched_getaffinity(0))
+    for ws in (2, 4, 8):
+        sets = [bench.rank_cpu_set(r, ws) for r in range(ws)]
+        if sets[0] is None:
+            assert all(s is None for s in sets)        # fewer physical cores than ranks: no pinning at all, on every rank alike
+            continue
+        assert all(s for s in sets)
+        flat = [c for s in sets for c in s]
+        assert len(flat) == len(set(flat)) <= n and len({len(s) for s in sets}) == 1
+    assert bench.rank_cpu_set(0, 1) is None
+
+
 def test_bench_under_external_launcher_env():
     """WORLD_SIZE already set (python -m torch.distributed.run ...): the process is a rank, no second level of spawning."""
     env = _env()

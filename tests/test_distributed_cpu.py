@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, ws, arch, seed, port, tmp):
+def _worker(rank, ws, arch, seed, port, tmp, issue="eager"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
@@ -29,7 +29,7 @@ def _worker(rank, ws, arch, seed, port, tmp):
     ops.set_backend(CpuOps())
     z, meta = load_case(arch, ws, seed)
     spec, inputs = build_inputs(arch, meta)
-    res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, torch.device("cpu"), "fused")
+    res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, torch.device("cpu"), "fused", issue=issue)
     errs = compare_to_golden(z, rank, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=grad_tol(arch))
     wkey, worst = worst_grad_err(z, rank, grads)
     assert worst <= grad_tol(arch), (wkey, worst)
@@ -47,6 +47,17 @@ def test_two_rank_step_matches_golden(arch, seed):
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, arch, seed, _free_port(), tmp), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
+
+
+def test_two_rank_step_in_segments_matches_golden():
+    """The same 2-rank fixture with the step cut at its collective points, as rspnet_amd/graph_step.py replays it at more than
+    one rank: top | all-to-all x2 | three forward passes | all-gather | logits + losses + whole backward | all-reduce | average +
+    SGD (GraphedPretextStep._segments; each device segment is one HIP graph on the GPU, issued eagerly here)."""
+    from oracle.ref_harness import _free_port
+    arch, _, seed = cases_for("c3d", 2)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, arch, seed, _free_port(), tmp, "segments"), nprocs=2, join=True)
         assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
 
 

@@ -107,7 +107,7 @@ def test_one_graph_per_speed_and_learning_rate():
 
 
 def test_issue_policy_graphs_only_the_host_bound_step():
-    """issue="auto": the last eager warm-up step is timed on both sides; a step the host issues well inside its GPU time stays
+    """issue="auto": the last three eager warm-up steps are timed on both sides (median host share); a step the host issues well inside its GPU time stays
     eager (full-size C3D: ~4 ms of ~92), a step the host cannot keep ahead of is captured (the same model on 32x32 crops: its GPU
     time is a fraction of the Python time)."""
     from rspnet_amd.graph_step import GraphedPretextStep
@@ -117,7 +117,7 @@ def test_issue_policy_graphs_only_the_host_bound_step():
         wrapped, crit, opt = _build("c3d", 64)
         stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2)
         im_q, im_k = (torch.randn(B, 3, 32, HW, HW, device=DEV) for _ in range(2))
-        for _ in range(4):
+        for _ in range(7):                     # 5 eager warm-up steps (the last three measured on both sides), then the decision holds
             loss = stepper(im_q, im_k)[0]
         torch.cuda.synchronize()
         assert torch.isfinite(loss)

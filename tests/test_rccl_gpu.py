@@ -72,3 +72,23 @@ def test_rccl_one_rank_forced_collectives_match_the_fixture(arch):
     print("\n", arch, rep)
     assert rep["side_group"] == "gloo"
     assert rep["calls"]["all_to_all_single"] == 2 and rep["calls"]["all_gather_into_tensor"] == 1 and rep["calls"]["all_reduce"] >= 2
+
+
+@pytest.mark.parametrize("arch,B,HW", [("c3d", 4, 32), ("s3dg", 4, 64)])
+def test_rccl_one_rank_segmented_replay_equals_the_eager_dp_step(arch, B, HW):
+    """The N > 1 issue mode that is not Python-bound: with the collectives on, GraphedPretextStep replays the
+    step as four HIP graphs between its collective points (RCCL calls issued eagerly in between) — bit-identical to the eager
+    data-parallel loop over seven steps, two of them eager warm-ups.  See forced_dp_util.segmented_worker."""
+    import json
+    from forced_dp_util import segmented_worker
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "ok.json")
+        mp.spawn(segmented_worker, args=(arch, B, HW, _free_port(), out), nprocs=1, join=True)
+        with open(out) as f:
+            rep = json.load(f)
+    print("\n", arch, rep)
+    assert rep["graph_segments"] == 4 and rep["collective_points"] == 3
+    # every step of either loop issues its 2 clip all-to-alls and its 1 key all-gather
+    for mode in ("eager", "segments"):
+        assert rep[mode]["all_to_all_single"] == 2 * 7 and rep[mode]["all_gather_into_tensor"] == 7 and rep[mode]["all_reduce"] >= 7
