@@ -344,13 +344,18 @@ def load_traffic(arch, B, kernel):
     (profiles/traffic.json, written by tools/summarize_profiles.py) — STATIC: counters cannot be collected inside a bench run."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
-        return None, None, None
+        return None, None, None, None
     with open(tpath) as f:
         t = json.load(f)
-    ent = t.get(f"{arch}_b{B}", {}).get(kernel)
+    arch_ent = t.get(f"{arch}_b{B}", {})
+    ent = arch_ent.get(kernel)
     if ent is None:
-        return None, None, None
-    return round(ent["hbm_bytes_per_launch"] / 1e9, 4), ent.get("mfma_busy"), ent.get("source")
+        return None, None, None, None
+    # the counters belong to the build they were collected on: stale when the kernel sources have changed since
+    from rspnet_amd import _lib
+    built = (arch_ent.get("_build") or {}).get("csrc_sha256")
+    stale = {"traffic_stale": built != _lib.source_hash(), "profiled_csrc_sha256": built, "profiled_commit": (arch_ent.get("_build") or {}).get("commit")}
+    return round(ent["hbm_bytes_per_launch"] / 1e9, 4), ent.get("mfma_busy"), ent.get("source"), stale
 
 
 def _pct(xs, q):
@@ -387,6 +392,12 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     if use_graph:
         from rspnet_amd.graph_step import GraphedPretextStep
         stepper = GraphedPretextStep(model, crit, opt, warmup=2, issue="graph" if args.graph == "on" else "auto")
+        # the synthetic clips live in the stepper's static clip buffers (resident in HBM before the timed region, as everywhere in
+        # this file): a replayed step then reads them in place instead of copying 2 x B clips per step
+        bq, bk = stepper.clip_buffers(im_q, im_k)
+        bq.copy_(im_q)
+        bk.copy_(im_k)
+        im_q, im_k = bq, bk
 
     def eager_step():
         out, tgt, rl, rt = model(im_q, im_k)
@@ -442,6 +453,8 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     if coll:
         inner.comm_log = {}
     marks, host, hbm, waits = [], [], [], []
+    if graphed and stepper.mode != "whole":
+        stepper.segment_host_ms = {}
     if cuda:
         marks.append(torch.cuda.Event(enable_timing=True))
         marks[0].record()
@@ -456,24 +469,38 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
             marks[-1].record()
     fence()
     dt = time.perf_counter() - t0
+    seg_host = None
+    if stepper is not None and stepper.segment_host_ms is not None:
+        seg_host, stepper.segment_host_ms = stepper.segment_host_ms, None
     log = []
     comm, inner.comm_log = inner.comm_log, None
+    final_loss = float(loss.detach())
+    # what issuing ONE step costs the host when nothing holds it up: the queue is empty at the start of each sample (inside the
+    # timed loop a call also waits whenever the hardware queue is full — GPU time, not submission cost)
+    idle_issue = []
+    if cuda:
+        for _ in range(5):
+            fence()
+            h0 = time.perf_counter()
+            step()
+            idle_issue.append((time.perf_counter() - h0) * 1e3)
+        fence()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if ws > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    final_loss = float(loss.detach())
     step_ms = dt / steps * 1e3
     res = {"clips_per_s": ws * B * steps / dt, "ms_per_step": step_ms, "final_loss": final_loss, "K": K, "lr": lr, "B": B,
            "hw": hw, "graph": bool(graphed), "collectives": coll,
-           "issue_mode": ("graph_segments" if stepper.mode == "segments" else "graph") if graphed else "eager"}
+           "issue_mode": {"whole": "graph", "segments": "graph_segments", "lanes": "graph_lanes"}[stepper.mode] if graphed else "eager"}
     if cuda:
         # worst rank's host time to issue one step (Python + launches + collective calls, without the stepper's back-pressure wait):
         # the number that says whether a rank is host-bound
-        hs = torch.tensor([_pct([h - w for h, w in zip(host, waits)], 0.5)], dtype=torch.float64, device=dev)
+        hs = torch.tensor([_pct([h - w for h, w in zip(host, waits)], 0.5), _pct(idle_issue, 0.5)], dtype=torch.float64, device=dev)
         if ws > 1:
             dist.all_reduce(hs, op=dist.ReduceOp.MAX)
-        res["host_submit_p50_max_over_ranks"] = round(float(hs.item()), 3)
+        res["host_submit_p50_max_over_ranks"] = round(float(hs[0].item()), 3)
+        res["host_issue_idle_gpu_p50_max_over_ranks"] = round(float(hs[1].item()), 3)
     if graphed and args.eager_steps > 0:
         # the same step issued eagerly with its side streams — how a run with more than one rank issues it (RCCL collectives are
         # not captured): the N = 1 point of a scaling curve in the N > 1 issue mode
@@ -514,9 +541,14 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
                            "host_enqueue_p50": round(_pct(host, 0.5), 3), "host_enqueue_max": round(max(host), 3),
                            "host_submit_p50": round(_pct([h - w for h, w in zip(host, waits)], 0.5), 3),
                            "host_backpressure_p50": round(_pct(waits, 0.5), 3),
+                           "host_issue_idle_gpu_p50": round(_pct(idle_issue, 0.5), 3) if idle_issue else None,
                            "note": "GPU-side step intervals (HIP events on the launch stream at step boundaries); host_enqueue = host "
-                                   "time per step() call = host_submit (Python + graph launch) + host_backpressure (the stepper lets the "
-                                   "host run at most 8 steps ahead: waiting there is GPU time, not submission cost)"}
+                                   "time per step() call = host_submit (Python + launches, INCLUDING waits inside the runtime when the "
+                                   "hardware queue is full) + host_backpressure (the stepper lets the host run at most 8 steps ahead: "
+                                   "waiting there is GPU time, not submission cost); host_issue_idle_gpu = the same call with an empty "
+                                   "queue (device synchronised before each of 5 samples): what the host itself needs per step"}
+        if seg_host:
+            res["steps_ms"]["segment_host_p50"] = {k: round(_pct(v, 0.5), 3) for k, v in seg_host.items()}
     if comm:
         # per-rank stall of the compute stream behind each collective, ms per step (this rank)
         cm = {}
@@ -545,7 +577,7 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         achieved = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
         executed = dexec / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
         fx_all = sum(v[4] for v in per_kernel.values())
-        traffic, busy, traffic_src = load_traffic(arch, B, dom)
+        traffic, busy, traffic_src, stale = load_traffic(arch, B, dom)
         alg_gb = dbytes / max(dn, 1) / 1e9
         whole = flops / roof_steps / (step_ms * 1e-3) / 1e12
         res["roofline"] = {
@@ -558,6 +590,9 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
             "mfma_busy": busy, "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of this kernel in the committed "
                                                  "PMC pass (static, see traffic_source)",
             "traffic": traffic, "traffic_static": True,
+            # a static look-up keyed on the kernel name: stale when rspnet_amd/csrc has changed since the PMC passes were collected
+            "traffic_stale": None if stale is None else stale["traffic_stale"],
+            "traffic_build": stale,
             "traffic_unit": "GB of L2-miss (fabric) traffic per launch: PMC FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache "
                             "hits (MI355X_MICROARCH.md), so an upper bound of the HBM bytes",
             "flop_count": "algorithmic: 2 x MACs of the convolution INCLUDING the taps that fall into the zero padding (SURVEY.md 8d); "
@@ -695,13 +730,16 @@ def run_rank(args):
             "graph": "one replayed HIP graph (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
             "graph_segments": "four replayed HIP-graph segments between the step's collective points, RCCL calls issued eagerly in "
                               "between (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
+            "graph_lanes": "seven replayed LINEAR HIP graphs — the three forward passes side by side on three streams — with the step's "
+                           "collective points between graphs (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
             "eager": "eager launches (independent passes on side streams)"}[m["issue_mode"]] + \
             "; roofline numbers from a one-stream eager pass of the same step outside the timed region"
         res["step_issue_mode"] = m["issue_mode"]
         if rccl_ranks is not None:
             res["rccl_ranks"] = rccl_ranks
-        if "host_submit_p50_max_over_ranks" in m:
-            res["host_submit_p50_max_over_ranks"] = m["host_submit_p50_max_over_ranks"]
+        for k in ("host_submit_p50_max_over_ranks", "host_issue_idle_gpu_p50_max_over_ranks"):
+            if k in m:
+                res[k] = m[k]
         if m["collectives"]:
             res["config"]["collectives"] = ("RCCL (nccl backend): clip all-to-all x2, fused key all-gather x1, bucketed gradient "
                                             "all-reduce from inside backward, gloo side group for the step's random draws"
@@ -735,7 +773,9 @@ def run_rank(args):
                 return {"clips_per_s": round(od["value"], 2), "ms_per_step": od["ms_per_step"], "steps": od["steps"],
                         "comm_ms": od.get("comm_ms"), "collectives": od["config"].get("collectives"),
                         "step_issue_mode": od.get("step_issue_mode"), "step_issue": od["config"]["step_issue"],
-                        "host_submit_p50": (od.get("steps_ms") or {}).get("host_submit_p50"), "rccl_ranks": od.get("rccl_ranks"),
+                        "host_submit_p50": (od.get("steps_ms") or {}).get("host_submit_p50"),
+                        "host_issue_idle_gpu_p50": (od.get("steps_ms") or {}).get("host_issue_idle_gpu_p50"),
+                        "segment_host_p50": (od.get("steps_ms") or {}).get("segment_host_p50"), "rccl_ranks": od.get("rccl_ranks"),
                         "final_loss": od["final_loss"], "vs_this_line": round(od["value"] / plain_value, 4)}
             except Exception as e:      # noqa: BLE001
                 return {"error": f"{type(e).__name__}: {e}"[:400]}

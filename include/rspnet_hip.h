@@ -89,7 +89,10 @@ int rsp_conv3d_dgrad_packed(const rsp_conv3d_desc* d, const float* dy, const flo
  *     rsp_conv3d_fwd on that buffer skips the zero fourth channel's multiply-adds).  which = 0: forward layout (1 job,
  *     rsp_conv3d_packed_fwd_elems floats); which = 1: all dgrad
  *     stride-class layouts (<= sT*sH*sW jobs, rsp_conv3d_packed_dgrad_elems floats).  Returns the number of jobs or RSP_E*.
- *   rsp_pack_run: executes n_jobs jobs stored in DEVICE memory; max_blocks = the largest `blocks` field among them (grid.x). */
+ *   rsp_pack_run: executes n_jobs jobs stored in DEVICE memory; max_blocks = the largest `blocks` field among them (grid.x).
+ *   rsp_conv3d_pack_forget: the owner of a packed buffer calls this before releasing it: the library drops what it noted about
+ *     that address (the three-channel mark of a stem), so that an unrelated buffer which later lands on the same address never
+ *     inherits it (an unmarked stem buffer runs all four channel steps: always correct). */
 typedef struct rsp_pack_job {
   const void* src;
   void* dst;
@@ -101,6 +104,7 @@ typedef struct rsp_pack_job {
 int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Cout_src, int32_t Cin_src, const float* w_ref,
                              float* w_packed, rsp_pack_job* jobs, int32_t max_jobs);
 int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, int32_t max_blocks, void* stream);
+void rsp_conv3d_pack_forget(const void* w_packed);
 
 /* wgrad: dw (reference layout, overwritten) = sum over positions of dy ⊗ im2col(x); dbias (nullable) = sum dy. */
 size_t rsp_conv3d_wgrad_workspace(const rsp_conv3d_desc* d);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "rsp_conv3d_dgrad_packed": (C.c_int, [_PD, _p, _p, _p, _p, _sz, _p]),
     "rsp_conv3d_pack_jobs": (_i32, [_PD, _i32, _i32, _i32, _p, _p, _p, _i32]),
     "rsp_pack_run": (C.c_int, [_p, _i32, _i32, _p]),
+    "rsp_conv3d_pack_forget": (None, [_p]),
     "rsp_conv3d_wgrad_workspace": (_sz, [_PD]),
     "rsp_conv3d_wgrad": (C.c_int, [_PD, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_conv3d_wgrad_v": (C.c_int, [_PD, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
@@ -190,3 +191,19 @@ def check(rc: int, what: str):
     if rc != 0:
         lib = load()
         raise RspError(f"{what} failed: {lib.rsp_strerror(rc).decode()} ({lib.rsp_last_error().decode()})")
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources the library is built from (rspnet_amd/csrc/*.hip, *.h and include/*.h, names and
+    contents): ties committed profile summaries (profiles/traffic.json) to the build they were measured on."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h"))
+                   + glob.glob(os.path.join(os.path.dirname(here), "include", "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()

@@ -2465,6 +2465,8 @@ int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Co
   return n;
 }
 
+void rsp_conv3d_pack_forget(const void* w_packed) { rsp_stem_forget_packed(w_packed); }
+
 int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, int32_t max_blocks, void* stream) {
   RSP_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_blocks > 0, "rsp_pack_run: bad argument");
   hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)max_blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);

@@ -14,5 +14,6 @@ const char* rsp_stem_kernel_name(const rsp_conv3d_desc* d);   // template instan
 // the re-pack entry points record whether the filters behind a packed stem weight had three input channels (RGB): rsp_stem_fwd
 // then skips the zero fourth channel's k-step
 void rsp_stem_note_packed(const void* w_packed, bool three_channels);
+void rsp_stem_forget_packed(const void* w_packed);
 const char* rsp_wgrad_kernel_name(const rsp_conv3d_desc* d);
 double rsp_wgrad_executed_fraction(const rsp_conv3d_desc* d);      // (conv_wgrad.hip) share of the row chunks its walk executes  // (conv_wgrad.hip) template instance rsp_conv3d_wgrad launches

@@ -540,7 +540,8 @@ StemPlan stem_plan(const rsp_conv3d_desc* d) {
 }
 
 // Packed stem weights whose source filters had three input channels (noted by the re-pack entry points: the layout is private to
-// the library, so every producer of such a buffer passes through one of them).  Keyed by the packed buffer's address.
+// the library, so every producer of such a buffer passes through one of them).  Keyed by the packed buffer's address; the owner
+// of the buffer withdraws the mark before it releases the memory (rsp_conv3d_pack_forget), so a recycled address starts unmarked.
 std::mutex g_three_mu;
 std::unordered_map<const void*, bool> g_three;
 
@@ -598,7 +599,13 @@ const char* rsp_stem_kernel_name(const rsp_conv3d_desc* d) {
 
 void rsp_stem_note_packed(const void* w_packed, bool three_channels) {
   std::lock_guard<std::mutex> lk(g_three_mu);
-  g_three[w_packed] = three_channels;
+  if (three_channels) g_three[w_packed] = true;
+  else g_three.erase(w_packed);                 // (unmarked = four channel steps: only marks are kept)
+}
+
+void rsp_stem_forget_packed(const void* w_packed) {
+  std::lock_guard<std::mutex> lk(g_three_mu);
+  g_three.erase(w_packed);
 }
 
 size_t rsp_stem_packed_elems(const rsp_conv3d_desc* d) {

@@ -317,6 +317,9 @@ class BranchStreams:
     MID_WGRAD_FLOPS = float(os.environ.get("RSP_WGRAD_MID_GFLOP", "400")) * 1e9
     MID_WGRAD_BYTES = float(os.environ.get("RSP_WGRAD_MID_MB", "450")) * 1e6
     EAGER_TASKS = not os.environ.get("RSP_NO_EAGER_OVERLAP")
+    # a list while rspnet_amd/graph_step.py captures a piece of the backward as a LINEAR graph: side tasks are not run but collected
+    # there as (fn, keepalive) — the stepper captures them as a graph of their own and replays it on the weight-gradient lane
+    deferred = None
 
     def __init__(self, x: torch.Tensor):
         self.dev = x.device
@@ -351,6 +354,9 @@ class BranchStreams:
         its own leaves most of the machine idle — on a task stream beside the trunk (R3D-18 +1.2 %, R(2+1)D +1.1 %).  Only from
         the trunk (flat forks); one task outstanding, the previous one is joined first.  `keepalive`: the tensors it reads,
         held until the join so that the graph's memory pool does not hand their blocks out again underneath it."""
+        if BranchStreams.deferred is not None:
+            BranchStreams.deferred.append((fn, keepalive))
+            return
         cur = torch.cuda.current_stream(self.dev) if self.on else None
         if cur is None or cur.cuda_stream != self.origin_h:
             return fn()
@@ -655,7 +661,22 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
 
 def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, after_param_grads=None,
                  want_input_grad: bool = False, packed: Optional[PackedWeights] = None):
-    """Backward through the plan.  `grad_of(param)` returns the (pre-allocated, flat-buffer) gradient view to
+    """Backward through the plan in one go: see run_backward_iter."""
+    it = run_backward_iter(plan, ctx, dfeat, grad_of, after_param_grads, want_input_grad, packed)
+    try:
+        while True:
+            next(it)
+    except StopIteration as done:
+        return done.value
+
+
+def run_backward_iter(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, after_param_grads=None,
+                      want_input_grad: bool = False, packed: Optional[PackedWeights] = None):
+    """Generator form of the backward: yields the index of each plan node once its kernels have been issued, so that a caller can
+    cut the backward into pieces (rspnet_amd/graph_step.py captures each piece as a linear HIP graph and runs the weight gradients
+    that `BranchStreams.deferred` collected beside the next piece); the generator's return value is run_backward's.
+
+    Backward through the plan.  `grad_of(param)` returns the (pre-allocated, flat-buffer) gradient view to
     fill for a parameter, or None to skip it.  `after_param_grads(node_index, grads_ready)` is called once a node's parameter
     gradients have been ISSUED (used to launch bucketed all-reduces overlapped with the rest of backward); a weight gradient may
     still be running on the side-task stream then — the hook issues whatever reads gradients inside `with grads_ready():`, a
@@ -809,5 +830,6 @@ def run_backward(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of, afte
     for ni in range(len(plan.nodes) - 1, -1, -1):
         node = plan.nodes[ni]
         branches.run(node, lambda: run_node(ni, node))
+        yield ni
     branches.finish()
     return dslots.get(plan.input_slot) if want_input_grad else None

@@ -19,22 +19,28 @@ pinned buffer and copied to a static device buffer before the replay.  Everythin
 graph: momentum update, the device-side randperm of _diff_speed (graph-safe Philox offsets), both key passes, query forward,
 logits, losses, backward, SGD, enqueue (pointer read and advanced on the device: rsp_queue_enqueue_dev).
 
-With the data-parallel collectives on (more than one rank, or `force_collectives`) the step is replayed in SEGMENTS: RCCL calls
-cannot be captured into the step graph on this stack (hipStreamEndCapture segfaults, profiles/r04/experiments_r4.txt), and the step
-has exactly four collective points — the two clip all-to-alls at the top, the fused key all-gather after the three forward passes,
-the gradient all-reduce after the backward.  The device work BETWEEN them is captured as four graphs
+HOW the step is captured (`mode`, default "lanes").  Measured on this stack (tools/chain_gap_probe.py, profiles/r05): a LINEAR graph
+— every node depends on the previous one — is handed to the GPU in one piece: 0.3 us of host per node, 1.5 us from one kernel of
+a dependent chain to the next.  A graph with parallel branches (streams forked inside the capture) is issued node by node by the
+runtime: 3.2 us of host per node and 6-9 us per chain link — S3D-G's 1 800-node step cost 5-6 ms of host per replay and every one of
+its BatchNorm chains (reduce -> finalize -> apply -> ...) paid the longer link.  So the step is cut into graphs that are each a
+plain chain, and the concurrency lives BETWEEN graphs, on streams the stepper orders with events:
 
-    top      momentum update, _diff_speed, the three clip gathers                   -> all-to-all x2   (eager, RCCL)
-    passes   query forward | k_negative pass | k pass on three forked streams       -> all-gather      (eager, RCCL)
-    tail     un-shuffle, logits, losses, enqueue, the whole backward                -> all-reduce      (eager, RCCL, 32 MiB buckets)
-    update   DDP's 1/ws average, SGD
+    main lane   top (momentum update, _diff_speed, the three clip gathers)              [clip all-to-all x2: eager RCCL calls]
+    main | q | k   key_kneg | query | key_k   three linear graphs replayed side by side on three streams
+    main lane   keys_join (deferred BatchNorm statistics, feature stack)                [key all-gather]
+    main lane   tail (un-shuffle, logits, losses, enqueue, the whole backward)          [gradient all-reduce, 32 MiB buckets]
+    main lane   update (DDP's 1/ws average, SGD)
 
-and the host issues four replays and four-plus collective calls per step instead of 250-2 000 launches (S3D-G eagerly: 38.9 ms of
-host time per 39.5 ms step with ONE interpreter on an idle host; eight ranks on one node share that host).  What the segments give
-up against the eager data-parallel step: the second clip exchange no longer hides under the first key pass and the bucket
-all-reduces no longer start inside the backward — a fraction of a millisecond each over xGMI, the price of not being
-Python-bound.  The same `issue="auto"` policy picks between the two.  Any failure to capture falls back to the eager loop with a
-logged warning — the result is the same either way, kernel for kernel.
+The collective points of the data-parallel step fall between graphs, so the SAME schedule serves one rank and N > 1 (RCCL calls
+cannot be captured on this stack: hipStreamEndCapture segfaults, profiles/r04/experiments_r4.txt); with one rank and no process
+group the collective slots are empty.  Each lane's graphs share a memory pool (they replay in capture order), different lanes have
+different pools.  What the lanes give up against the forked capture: weight gradients no longer run beside the input gradient inside
+the backward (engine.BranchStreams is off in a linear capture).  What the data-parallel step gives up against eager issue: the
+second clip exchange no longer hides under the first key pass and the bucket all-reduces no longer start inside the backward — a
+fraction of a millisecond each over xGMI, the price of not being Python-bound.  mode "segments": four graphs between
+the collective points with the forks inside (round 5's first version); "whole": one graph, forks inside (rounds 2-4; N = 1 only).
+Any failure to capture falls back to the eager loop with a logged warning — the result is the same either way, kernel for kernel.
 
 WHEN the graph is used (`issue="auto"`): only for a step the host cannot issue fast enough.  A replayed graph removes Python and
 the launch calls, but its nodes reach the GPU with more dependency bookkeeping than a stream's in-order launches: replayed, the
@@ -58,6 +64,8 @@ class GraphedPretextStep:
     RING = 8
     MAX_GRAPHS = 4      # configurations kept (diff_speed has at most three entries; a new learning rate retires the old graphs)
     HOST_BOUND = 0.5    # issue="auto": capture a configuration whose eager issue takes more than this share of its GPU time
+    HOST_BOUND_DP = 0.25  # ... with the data-parallel collectives on: N interpreters (and their RCCL proxy threads) share one host
+    DEFAULT_MODE = "lanes"
     MAX_KEYS = 64       # bookkeeping entries kept per dictionary (a per-iteration LR schedule would otherwise grow them without bound)
 
     def __init__(self, model, criterion, optimizer, warmup: int = 2, issue: str = "auto"):
@@ -82,15 +90,21 @@ class GraphedPretextStep:
         self.samples: Dict[Tuple, list] = {}      # issue="auto": (host ms, GPU ms) of the measured warm-up steps of a configuration
         self.static = None
         self.last_wait_s = 0.0
-        self.pool = None                          # one memory pool for all graphs of this stepper: only one replays at a time
-        # With the data-parallel collectives on, the step is replayed as SEGMENTS between the collective points (module docstring).
-        # RSP_GRAPH_COLLECTIVES=1 captures the collectives into one whole-step graph instead (exercised at one rank with
-        # force_collectives; never the default), RSP_NO_SEGMENTS=1 issues the data-parallel step eagerly as rounds 1-4 did (A/B).
+        self.segment_host_ms = None               # {} to collect host time per segment of the segmented replay
+        # How the captured step is laid out (module docstring).  RSP_GRAPH_MODE = whole | segments | lanes overrides the default for
+        # A/B runs; "whole" with the collectives on captures the RCCL calls too (RSP_GRAPH_COLLECTIVES=1 of round 4: exercised at one
+        # rank, never the default); RSP_NO_SEGMENTS=1 issues the data-parallel step eagerly as rounds 1-4 did.
         import os
         coll = bool(self.model._dp()[2])
-        self.mode = "segments" if (coll and not os.environ.get("RSP_GRAPH_COLLECTIVES")) else "whole"
+        self.mode = os.environ.get("RSP_GRAPH_MODE") or ("whole" if (os.environ.get("RSP_GRAPH_COLLECTIVES") and coll) else self.DEFAULT_MODE)
+        if self.mode not in ("whole", "segments", "lanes"):
+            raise ValueError(f"RSP_GRAPH_MODE={self.mode}: whole, segments or lanes")
+        if coll and self.mode == "whole" and not os.environ.get("RSP_GRAPH_COLLECTIVES"):
+            self.mode = "segments"                # (RCCL calls are not captured: hipStreamEndCapture segfaults on this stack)
         self.disabled = coll and bool(os.environ.get("RSP_NO_SEGMENTS")) and not os.environ.get("RSP_GRAPH_COLLECTIVES")
         self.fallback_reason = "data-parallel collectives on, RSP_NO_SEGMENTS (issued eagerly)" if self.disabled else None
+        self.lane_streams = {}                    # lane name -> side stream ("main" = the caller's current stream)
+        self.pools = {}                           # lane name -> memory pool of that lane's graphs
 
     # ---- the five statements ------------------------------------------------------------------------------------------------
     def _eager(self, im_q, im_k, host):
@@ -102,10 +116,29 @@ class GraphedPretextStep:
         return loss, loss_A, loss_M, out, rl, tgt, rt
 
     def _segments(self, im_q, im_k):
-        """The same five statements cut at the collective points: [(kind, fn(host))] with kind 'graph' (device work: captured once,
+        """The five statements cut at the collective points: [(kind, fn(host))] with kind 'graph' (device work: captured once,
         replayed) or 'eager' (a collective: issued every step with that step's split lists).  `box` carries the step's state
-        between them — static buffers of the graphs' memory pool once captured."""
+        between them — static buffers of the graphs' memory pool once captured.  (The "segments" schedule without its lane
+        annotations: tests issue these eagerly, one after the other, on any device.)"""
+        ops, box = self._schedule(im_q, im_k, "segments")
+        return [("graph" if op[0] == "g" else "eager", op[-1]) for op in list(ops) if op[0] in ("g", "e")], box
+
+    def _schedule(self, im_q, im_k, mode):
+        """The step as a sequence of operations over `box`, the state they share (an iterable: the "lanes" schedule is a generator
+        whose later operations depend on what capturing the earlier ones found — how many pieces the backward is cut into):
+            ("g", lane, name, fn)   device work, captured once as ONE graph and replayed on the lane's stream
+            ("e", lane, name, fn)   host-issued work on the lane's stream every step: a collective with that step's split lists
+            ("fork", lane)          the lane's stream waits for the main stream
+            ("join", lane)          the main stream waits for the lane's stream
+        mode "whole": one graph, the three passes and the weight-gradient tasks forked INSIDE the capture; "segments": the same
+        cut at the collective points; "lanes": every graph a LINEAR chain — the three forward passes as three graphs replayed side
+        by side on streams of their own, the backward as a chain of pieces on the main lane with the weight gradients of each
+        piece as a graph on the "w" lane beside the next piece."""
         m, box = self.model, {}
+
+        def whole(host):
+            loss, loss_A, loss_M, out, rl, _, _ = self._eager(im_q, im_k, host)
+            box["outs"] = (loss, loss_A, loss_M, out, rl)
 
         def top(host):
             box["st"] = m._phase_top(im_q, im_k, host)
@@ -134,8 +167,116 @@ class GraphedPretextStep:
             m._scale_gradients()
             self.optimizer.step()
 
-        return [("graph", top), ("eager", exchange), ("graph", passes), ("eager", gather), ("graph", tail), ("eager", reduce),
-                ("graph", update)], box
+        if mode == "whole":
+            return [("g", "main", "step", whole)], box
+        if mode == "segments":
+            return [("g", "main", "top", top), ("e", "main", "all_to_all", exchange), ("g", "main", "passes", passes),
+                    ("e", "main", "all_gather", gather), ("g", "main", "tail", tail), ("e", "main", "all_reduce", reduce),
+                    ("g", "main", "update", update)], box
+        return self._lanes(box, top, gather, tail, update), box
+
+    # Plan nodes per piece of the backward (lanes mode) when weight gradients are set aside for the "w" lane; 0 (default): they stay
+    # in line and the backward is cut only where a gradient bucket completes.  Measured (profiles/r05/experiments_r5.txt): every extra
+    # graph costs ~50 us on the GPU side — R3D-18 1 259 clips/s with the backward as one graph, 1 235 with 8-node pieces + "w" lane,
+    # S3D-G 402 vs 398 — more than the weight gradients gain beside the input gradients.  RSP_BWD_PIECE for sweeps.
+    import os as _os
+    BACKWARD_PIECE = int(_os.environ.get("RSP_BWD_PIECE", "0"))
+
+    def _lanes(self, box, top, gather, tail, update):
+        """The "lanes" schedule (see `_schedule`), a generator consumed by `_capture`."""
+        from .engine import BranchStreams
+        from .moco.builder_diffspeed_diffloss import BUCKET_FLOATS
+        m = self.model
+
+        def exchange(host):
+            # both clip all-to-alls start here; the main stream waits for the k_negative clips only, the k clips are awaited on the
+            # k lane: the second exchange runs over xGMI under the first key pass, as in the eager data-parallel step
+            m._phase_exchange(box["st"], host, wait="first")
+            m._last_draw = (m._last_draw[0], host["speed"]) + tuple(host["sh"])
+
+        yield ("g", "main", "top", top)
+        yield ("fork", "q")
+        yield ("g", "q", "query", lambda host: m._pass_query(box["st"]))
+        yield ("e", "main", "all_to_all", exchange)
+        yield ("fork", "k")
+        yield ("e", "k", "all_to_all_k", lambda host: m._wait_exchange(box["st"], 1))
+        yield ("g", "k", "key_k", lambda host: m._pass_key(box["st"], 1))
+        yield ("g", "main", "key_kneg", lambda host: m._pass_key(box["st"], 0))
+        yield ("join", "k")
+        yield ("g", "main", "keys_join", lambda host: m._passes_join(box["st"]))
+        yield ("e", "main", "all_gather", gather)
+        yield ("join", "q")
+        yield ("g", "main", "tail", tail)      # ... up to the gradient of the query features (`_defer_backward`)
+        # the encoder's backward: pieces of the node chain on the main lane; the weight gradients a piece set aside
+        # (engine.BranchStreams.deferred) as one graph on the "w" lane, beside the next piece; a gradient bucket whose last
+        # parameter has been issued is all-reduced from the "w" lane's stream — behind everything that writes into it
+        coll = bool(m._dp()[2])
+        buckets = m._flat.buckets(BUCKET_FLOATS) if coll else []
+        bw = {"it": None, "done": False, "tasks": [], "keep": [], "handed": set(), "launched": set(), "handles": []}
+        box["backward"] = bw
+
+        def piece(host):
+            if bw["it"] is None:
+                bw["it"] = m._backward_iter()
+            BranchStreams.deferred = bw["tasks"] if self.BACKWARD_PIECE > 0 else None
+            try:
+                n = 0
+                for handed in bw["it"]:
+                    bw["handed"] = handed
+                    n += 1
+                    ready = any(bi not in bw["launched"] and all(pid in handed for pid in ids) for bi, (_, _, ids) in enumerate(buckets))
+                    if ready or (self.BACKWARD_PIECE > 0 and n >= self.BACKWARD_PIECE and bw["tasks"]):
+                        return
+                bw["done"] = True
+            finally:
+                BranchStreams.deferred = None
+
+        def wgrads(host):
+            for fn, keep in bw["tasks"]:
+                fn()
+                # the operands stay alive until the whole backward has been captured: the main lane's later pieces must not be
+                # handed their memory while this graph may still be reading it
+                bw["keep"].append(keep)
+            del bw["tasks"][:]
+
+        def reducer(s, e):
+            def fn(host):
+                bw["handles"].append(dist.all_reduce(m._flat.g_flat[s:e], async_op=True))
+            return fn
+
+        def reduce_wait(host):
+            hs, bw["handles"] = bw["handles"], []
+            if hs:
+                with m._comm("allreduce_wait"):
+                    for h in hs:
+                        h.wait()
+
+        j = 0
+        while not bw["done"]:
+            yield ("g", "main", f"backward{j}", piece)
+            forked = False
+            if bw["tasks"]:
+                yield ("fork", "w")
+                forked = True
+                yield ("g", "w", f"wgrad{j}", wgrads)
+            for bi, (s, e, ids) in enumerate(buckets):
+                if bi not in bw["launched"] and all(pid in bw["handed"] for pid in ids):
+                    bw["launched"].add(bi)
+                    if not forked:
+                        yield ("fork", "w")
+                        forked = True
+                    yield ("e", "w", f"all_reduce{bi}", reducer(s, e))
+            j += 1
+        for bi, (s, e, ids) in enumerate(buckets):
+            if bi not in bw["launched"]:
+                bw["launched"].add(bi)
+                yield ("fork", "w")
+                yield ("e", "w", f"all_reduce{bi}", reducer(s, e))
+        yield ("join", "w")
+        yield ("e", "main", "all_reduce_wait", reduce_wait)
+        yield ("g", "main", "update", update)
+        del bw["keep"][:]
+        bw["it"] = None
 
     def _config(self, im_q, host):
         return (host["speed"], tuple(im_q.shape))
@@ -205,20 +346,50 @@ class GraphedPretextStep:
         else:
             self._static_clips(im_q, im_k)
         self.graphs[key] = self.graphs.pop(key)         # most recently used last
-        if entry[3] is None:
-            entry[0].replay()
-        else:
-            for g, fn in entry[3]:
-                if g is not None:
-                    g.replay()
-                else:
-                    fn(host)
+        self._replay(entry[3], host)
         return entry[1]
+
+    def _replay(self, seq, host):
+        """Run a captured schedule (see `_schedule`): graphs replayed on their lanes' streams, collectives issued in between."""
+        dev = self.static["dev"].device
+        prof = self.segment_host_ms
+        if prof is not None:
+            import time
+        for op in seq:
+            t0 = time.perf_counter() if prof is not None else 0.0
+            kind = op[0]
+            if kind == "g":
+                if op[1] == "main":
+                    op[3].replay()
+                else:
+                    with torch.cuda.stream(self.lane_streams[op[1]]):
+                        op[3].replay()
+            elif kind == "e":
+                if op[1] == "main":
+                    op[3](host)
+                else:
+                    with torch.cuda.stream(self.lane_streams[op[1]]):
+                        op[3](host)
+            elif kind == "fork":
+                self.lane_streams[op[1]].wait_stream(torch.cuda.current_stream(dev))
+            else:
+                torch.cuda.current_stream(dev).wait_stream(self.lane_streams[op[1]])
+            if prof is not None and kind in ("g", "e"):
+                # (measurement: where the host's time of a replayed step goes — set `segment_host_ms = {}` to collect)
+                prof.setdefault(("graph:" if kind == "g" else "rccl:") + op[2], []).append((time.perf_counter() - t0) * 1e3)
+
+    def clip_buffers(self, like_q, like_k):
+        """The static clip tensors the captured graphs read (allocated on first use, shaped like the arguments).  A data path that
+        writes its batches straight into them (a GPU augmentation with `out=`, synthetic clips) and passes them to `__call__` skips
+        the per-step copy a replayed graph otherwise needs (2 x 154 MB for C3D's 32 clips: 0.5 % of an R3D-18 step)."""
+        if getattr(self, "_clip_bufs", None) is None:
+            self._clip_bufs = (torch.empty_like(like_q), torch.empty_like(like_k))
+        return self._clip_bufs
 
     def _static_clips(self, im_q, im_k):
         st = self.static
         if st["im_q"] is None:
-            st["im_q"], st["im_k"] = torch.empty_like(im_q), torch.empty_like(im_k)
+            st["im_q"], st["im_k"] = self.clip_buffers(im_q, im_k)
         if im_q.data_ptr() != st["im_q"].data_ptr():
             st["im_q"].copy_(im_q, non_blocking=True)
         if im_k.data_ptr() != st["im_k"].data_ptr():
@@ -245,9 +416,10 @@ class GraphedPretextStep:
             shares = sorted(h / max(g, 1e-6) for h, g in got)
             share = shares[len(shares) // 2]
             h_med, g_med = sorted(h for h, _ in got)[len(got) // 2], sorted(g for _, g in got)[len(got) // 2]
-            if share <= self.HOST_BOUND:
+            bound = self.HOST_BOUND_DP if self.model._dp()[2] else self.HOST_BOUND
+            if share <= bound:
                 self.eager_keys[cfg] = (f"issued eagerly by policy: the host issues this step in {h_med:.1f} ms of the {g_med:.1f} ms it runs "
-                                        f"(median of {len(got)} measured warm-up steps; a replayed graph pays off above {self.HOST_BOUND:.0%})")
+                                        f"(median of {len(got)} measured warm-up steps; a replayed graph pays off above {bound:.0%})")
                 self._cap(self.eager_keys, self.MAX_KEYS)
                 self.fallback_reason = self.eager_keys[cfg]
                 log.info("rspnet_amd: pretext step (speed %s) %s", cfg[0], self.eager_keys[cfg])
@@ -265,42 +437,49 @@ class GraphedPretextStep:
             from .engine import BranchStreams
             while len(self.graphs) >= self.MAX_GRAPHS:      # (the scheduler changes the learning rate every epoch: old graphs go)
                 self.graphs.pop(next(iter(self.graphs)))
-            if self.pool is None:
-                self.pool = torch.cuda.graph_pool_handle()
             dev = st["dev"].device
-            if self.mode == "whole":
-                g = torch.cuda.CUDAGraph()
-                try:
-                    with torch.cuda.graph(g, pool=self.pool):
-                        BranchStreams.origin = torch.cuda.current_stream(dev).cuda_stream
-                        loss, loss_A, loss_M, out, rl, _, _ = self._eager(st["im_q"], st["im_k"], host)
-                finally:
-                    BranchStreams.origin = None
-                outs, seq = (loss, loss_A, loss_M, out, rl), None
-            else:
-                # one graph per device segment, captured in step order into ONE pool (they replay in that order, never side by
-                # side); the collectives between them are not executed now — nothing is, a capture only records — the replay
-                # below runs the step this capture stands for
-                segs, box = self._segments(st["im_q"], st["im_k"])
-                seq, g = [], None
-                m._defer_reduce = True
-                try:
-                    for kind, fn in segs:
-                        if kind == "eager":
-                            seq.append((None, fn))
-                            continue
-                        sg = torch.cuda.CUDAGraph()
-                        try:
-                            with torch.cuda.graph(sg, pool=self.pool):
-                                BranchStreams.origin = torch.cuda.current_stream(dev).cuda_stream
-                                fn(host)
-                        finally:
-                            BranchStreams.origin = None
-                        seq.append((sg, None))
-                finally:
-                    m._defer_reduce = False
-                outs = box["outs"]
-                st.setdefault("boxes", []).append(box)       # the segments' shared state: static buffers of the pool
+            # With a process group alive, its watchdog thread polls the events of finished collectives at any time; under the default
+            # "global" capture mode such a query from ANOTHER thread while this one captures is an error that takes the process down
+            # (hipErrorStreamCaptureUnsupported raised inside the watchdog: seen on the first --graph on run of round 5).  "thread_local"
+            # restricts only the capturing thread.
+            cmode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            # Graphs are captured in step order, each into the memory pool of its LANE: graphs of one lane replay in capture order
+            # and never side by side, so they share a pool (a later graph re-uses what an earlier one freed); graphs of different
+            # lanes run concurrently and must not.  A tensor that crosses lanes (the query clips, the kept activations) lives in its
+            # producer's pool until its last consumer's capture drops it.  The collectives between the graphs are not executed now —
+            # nothing is, a capture only records — the replay below runs the step this capture stands for.
+            ops, box = self._schedule(st["im_q"], st["im_k"], self.mode)
+            seq = []
+            m._defer_reduce = self.mode != "whole"
+            m._defer_backward = self.mode == "lanes"
+            try:
+                for op in ops:
+                    lane = op[1]
+                    if lane != "main" and lane not in self.lane_streams:
+                        self.lane_streams[lane] = torch.cuda.Stream(device=dev)
+                    if op[0] != "g":
+                        seq.append(op)
+                        continue
+                    _, lane, name, fn = op
+                    if lane not in self.pools:
+                        self.pools[lane] = torch.cuda.graph_pool_handle()
+                    sg = torch.cuda.CUDAGraph()
+                    try:
+                        with torch.cuda.graph(sg, pool=self.pools[lane], capture_error_mode=cmode):
+                            # forks INSIDE a capture (query / key passes, weight-gradient tasks: engine.BranchStreams) only where the
+                            # schedule wants them: a graph with parallel branches is issued node by node by the runtime (3.2 us of
+                            # host per node, 6-9 us per chain link; a linear graph: 0.3 us and 1.5 us, tools/chain_gap_probe.py)
+                            # (origin None: engine.BranchStreams keeps every node on the capturing stream)
+                            BranchStreams.origin = torch.cuda.current_stream(dev).cuda_stream if self.mode != "lanes" else None
+                            fn(host)
+                    finally:
+                        BranchStreams.origin = None
+                    seq.append(("g", lane, name, sg))
+            finally:
+                m._defer_reduce = m._defer_backward = False
+                m._pending_bwd = None
+            outs = box["outs"]
+            g = None
             # Everything the graph's kernels address that was allocated OUTSIDE the capture must outlive the graph: a later
             # configuration may rebuild a packed-weight set, and the superseded buffers — still baked into this graph's kernel
             # arguments — would be freed.  (The library's scratch buffers come from the graph's own pool: ops.HipOps._workspace.)
@@ -309,10 +488,10 @@ class GraphedPretextStep:
             keep = [list(m.encoder_q._packed._sets), list(m.encoder_k._packed._sets), m._flat,
                     getattr(m._flat, "m_flat", None), getattr(m, "_nbt_q", None), getattr(m, "_nbt_k", None), st,
                     m._ema_k, m._ema_map, list(m.encoder_q._packed._virtual.values()), list(m.encoder_k._packed._virtual.values())]
+            keep.append(box)                             # the graphs' shared state: static buffers of the pools
             self.graphs[key] = (g, outs, keep, seq)
-            log.info("rspnet_amd: pretext step captured as %s (speed %s, clips %s)",
-                     "a HIP graph" if seq is None else f"{sum(1 for s in seq if s[0] is not None)} HIP-graph segments between its collectives",
-                     key[0], key[1])
+            log.info("rspnet_amd: pretext step captured as %d HIP graph(s), mode %s (speed %s, clips %s)",
+                     sum(1 for o in seq if o[0] == "g"), self.mode, key[0], key[1])
             # the capture itself executed nothing: run the step it stands for
             return self.graphs[key]
         except Exception as e:      # noqa: BLE001 - whatever refuses the capture, the eager loop still works

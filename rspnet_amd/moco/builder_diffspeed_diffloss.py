@@ -134,7 +134,11 @@ class _PretextFn(torch.autograd.Function):
         B, K = k_A.shape[0], queue.shape[1]
         dqA, dqM = be.logits_bwd(z(dl1, (B, K + 1)), z(dl2, (B, K + 1)), z(dlp, (B, 1)), z(dln, (B, 1)), k_A, k_M,
                                  kneg_A, kneg_M, queue, 1.0 / model.T)
-        model._backward_encoder_q(ctx.ectx, dqA, dqM)
+        if model._defer_backward:
+            # rspnet_amd/graph_step.py runs the encoder's backward itself, in pieces (`_backward_iter`)
+            model._pending_bwd = (ctx.ectx, dqA, dqM)
+        else:
+            model._backward_encoder_q(ctx.ectx, dqA, dqM)
         ctx.ectx = None
         return (None, None, None) + (None,) * len(model._q_params)
 
@@ -185,6 +189,8 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._pending = []
         self._q_version = None
         self._defer_reduce = False            # True: backward leaves the gradient all-reduce to `_reduce_gradients` (segmented replay)
+        self._defer_backward = False          # True: loss.backward() stops at the query features; `_backward_iter` runs the encoder's part
+        self._pending_bwd = None
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
 
     def _dp(self):
@@ -522,6 +528,25 @@ class MoCoDiffLossTwoFc(nn.Module):
         flat.attach_grads()
 
     @torch.no_grad()
+    def _backward_iter(self):
+        """The query encoder's backward as a generator (after a `loss.backward()` under `_defer_backward`): yields, after each plan
+        node, the set of parameter ids whose gradient kernels have been ISSUED so far — inline, or handed to
+        engine.BranchStreams.deferred.  The caller cuts the backward into graphs there and starts a gradient bucket's all-reduce
+        once all of its parameters are in the set (rspnet_amd/graph_step.py)."""
+        ectx, dqA, dqM = self._pending_bwd
+        self._pending_bwd = None
+        flat = self._flat
+        handed_out = set()
+
+        def grad_of(p):
+            handed_out.add(id(p))
+            return flat.grad_of(p)
+
+        for _ in self.encoder_q.backward_ndhwc_iter(ectx, dqA, dqM, grad_of, None):
+            yield handed_out
+        flat.attach_grads()
+
+    @torch.no_grad()
     def _reduce_gradients(self):
         """The gradient all-reduce of a step whose backward ran with `_defer_reduce`: the same 32 MiB buckets, issued back to back
         after the backward (a replayed graph cannot launch them from inside)."""
@@ -614,16 +639,18 @@ class MoCoDiffLossTwoFc(nn.Module):
             self._nbt_k += 2
             self.encoder_k._packed.refresh_now()      # (re-pack of the momentum-updated weights: before the passes fork)
             st = {"B": B, "dev": dev, "x_q": x_q, "send": (xs_neg, xs_k), "loc": (loc1, loc2), "handles": [None, None],
+                  "feats": [None, None], "deferred": self._deferred_k(),
                   "arrival": [np.arange(B), np.arange(B)],
                   # with the collectives on, the clips arrive in buffers of their own (every rank receives exactly B clips)
                   "recv": (torch.empty_like(xs_neg), torch.empty_like(xs_k)) if coll else (xs_neg, xs_k)}
         return st
 
     @torch.no_grad()
-    def _phase_exchange(self, st, host, wait: bool):
+    def _phase_exchange(self, st, host, wait):
         """Shuffle-BN's sample exchange (:361-387): ONE all-to-all per key pass over the already sub-sampled clips.  Both are
         started back to back — the permutations are known at the top of the step — so the second one runs over xGMI under the
-        first key pass's convolutions.  wait=False: the key passes wait for their clips themselves (`_key_pass`)."""
+        first key pass's convolutions.  wait=False: the key passes wait for their clips themselves (`_key_pass`); True: the current
+        stream waits for both; "first": for the k_negative clips only (`_wait_exchange(st, 1)` follows on the k pass's stream)."""
         _, _, coll = self._dp()
         for i, plan in enumerate(host["plans"]):
             _, _, in_splits, out_splits, arrival = plan
@@ -631,15 +658,21 @@ class MoCoDiffLossTwoFc(nn.Module):
             if coll:
                 st["handles"][i] = dist.all_to_all_single(st["recv"][i], st["send"][i], out_splits, in_splits, async_op=True)
         if wait:
-            for i, tag in enumerate(("kneg", "k")):
-                h, st["handles"][i] = st["handles"][i], None
-                if h is not None:
-                    with self._comm("all_to_all_" + tag):
-                        h.wait()
+            self._wait_exchange(st, 0)
+            if wait != "first":
+                self._wait_exchange(st, 1)
+
+    def _wait_exchange(self, st, i: int):
+        """The current stream waits for the clips of key pass i (0: k_negative, 1: k)."""
+        h, st["handles"][i] = st["handles"][i], None
+        if h is not None:
+            with self._comm("all_to_all_" + ("k" if i else "kneg")):
+                h.wait()
 
     @torch.no_grad()
     def _phase_passes(self, st, join_query: bool):
-        """The three forward passes: query encoder (kept for backward), k_negative and k through encoder_k."""
+        """The three forward passes: query encoder (kept for backward), k_negative and k through encoder_k — forked onto streams of
+        their own where that pays (inside a capture, or issued eagerly with the host far ahead)."""
         dev = st["dev"]
         # The query encoder's forward does not depend on the key passes (other weights, other BatchNorm buffers) before the
         # logits: it is forked onto its own stream and runs beside them — the small late layers of either pass leave most of
@@ -650,35 +683,56 @@ class MoCoDiffLossTwoFc(nn.Module):
             side = self._query_stream = self._query_stream or torch.cuda.Stream(device=dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._q_pre = self.encoder_q.forward_ndhwc(st["x_q"], keep=True)
+                self._pass_query(st)
         # The two key passes (k_negative first, :445; then k, :512) go through the same encoder_k.  The second one defers its
         # running-statistics update (_deferred_k), so it is forked onto its own stream beside the first (and beside the query
         # forward); the deferred update is applied after both, in the reference's order.  Neither pass holds a collective of
         # its own beyond the wait for its clips: the features of both travel in one all-gather after the join.
-        deferred = self._deferred_k()
-        ex_neg = (st["recv"][0], st["handles"][0], st["arrival"][0])
-        ex_k = (st["recv"][1], st["handles"][1], st["arrival"][1])
-        st["handles"] = [None, None]
         side_k = None
         if side is not None and self.overlap_keys:
             main = torch.cuda.current_stream(dev)
             side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
             side_k.wait_stream(main)
             with torch.cuda.stream(side_k):
-                feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
-        feats_neg, dim = self._key_pass(ex_neg, "kneg", bump=False)
+                self._pass_key(st, 1)
+        self._pass_key(st, 0)
         if side_k is None:
-            feats_k, _ = self._key_pass(ex_k, "k", deferred=deferred, bump=False)
+            self._pass_key(st, 1)
         else:
             torch.cuda.current_stream(dev).wait_stream(side_k)
-        self._ema_k.run()
-        _, ws, coll = self._dp()
-        mine = torch.stack([feats_neg, feats_k])                    # (2, B, width)
-        st["dim"], st["mine"], st["side"] = dim, mine, side
-        st["gathered"] = (torch.empty((ws * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device) if coll else mine)
-        if join_query and side is not None:
+        self._passes_join(st)
+        st["side"] = side
+        if side is None:
+            self._pass_query(st)
+        elif join_query:
             torch.cuda.current_stream(dev).wait_stream(side)
             st["side"] = None
+
+    # the pieces of `_phase_passes`, each a plain kernel sequence on the current stream (rspnet_amd/graph_step.py captures each as a
+    # LINEAR graph and replays the three passes side by side on streams of its own)
+    @torch.no_grad()
+    def _pass_query(self, st):
+        self._q_pre = self.encoder_q.forward_ndhwc(st["x_q"], keep=True)
+
+    @torch.no_grad()
+    def _pass_key(self, st, which: int):
+        """which = 0: k_negative (first in the reference, :445: moves encoder_k's running statistics itself); 1: k (:512: reports
+        its batch moments to the deferred set, applied by `_passes_join` after both)."""
+        ex = (st["recv"][which], st["handles"][which], st["arrival"][which])
+        st["handles"][which] = None
+        feats, dim = self._key_pass(ex, "k" if which else "kneg", deferred=st["deferred"] if which else None, bump=False)
+        st["feats"][which] = feats
+        st["dim"] = dim
+
+    @torch.no_grad()
+    def _passes_join(self, st):
+        self._ema_k.run()
+        _, ws, coll = self._dp()
+        mine = torch.stack(st["feats"])                             # (2, B, width): k_negative, k
+        st["feats"] = [None, None]
+        st["mine"] = mine
+        st["gathered"] = (torch.empty((ws * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device) if coll else mine)
+        st.setdefault("side", None)
 
     @torch.no_grad()
     def _phase_gather(self, st):

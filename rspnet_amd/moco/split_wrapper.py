@@ -18,7 +18,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops as _ops
-from ..engine import INPUT_CHANNEL_PAD, ConvBN, ConvBias, PackedWeights, Plan, run_backward, run_forward
+from ..engine import INPUT_CHANNEL_PAD, ConvBN, ConvBias, PackedWeights, Plan, run_backward, run_backward_iter, run_forward
 
 FC_TYPES = ("linear", "mlp", "conv", "convbn", "speednet")
 
@@ -178,6 +178,12 @@ class MultiTaskWrapper(nn.Module):
         return outs[0], outs[1], ctx
 
     def backward_ndhwc(self, ctx, d1: Tensor, d2: Tensor, grad_of, after_param_grads=None):
+        for _ in self.backward_ndhwc_iter(ctx, d1, d2, grad_of, after_param_grads):
+            pass
+
+    def backward_ndhwc_iter(self, ctx, d1: Tensor, d2: Tensor, grad_of, after_param_grads=None):
+        """Generator: the head's backward, then the backbone's node by node (engine.run_backward_iter); yields plan node indices
+        (-1 after the head)."""
         be = _ops.backend()
         if self.fc_type == "linear":
             l1, l2 = self.fc1[2], self.fc2[2]
@@ -206,7 +212,8 @@ class MultiTaskWrapper(nn.Module):
                 dfeat = be.spatial_mean_bwd(dpooled_feat, ctx.feat_shape)
         if after_param_grads is not None:
             after_param_grads(-1, None)
-        run_backward(self.plan(), ctx, dfeat, grad_of, after_param_grads)
+        yield -1
+        yield from run_backward_iter(self.plan(), ctx, dfeat, grad_of, after_param_grads)
 
     def _to_ndhwc(self, x: Tensor) -> Tensor:
         be = _ops.backend()

@@ -8,6 +8,7 @@ tensors and the built ``librspnet_hip.so`` and raises otherwise.  ``set_backend`
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -110,6 +111,7 @@ def _pack_signature(g: "ConvGeom", which: int, cout_src: int, cin_src: int):
     d = g.desc()
     buf = (_lib.PackJob * 64)()
     cnt = lib.rsp_conv3d_pack_jobs(C.byref(d), which, cout_src, cin_src, C.c_void_p(1 << 20), C.c_void_p(1 << 30), buf, 64)
+    lib.rsp_conv3d_pack_forget(C.c_void_p(1 << 30))      # (a probe with dummy pointers: nothing to remember about that address)
     if cnt < 0:
         _lib.check(cnt, "rsp_conv3d_pack_jobs")
     n = (lib.rsp_conv3d_packed_dgrad_elems if which else lib.rsp_conv3d_packed_fwd_elems)(C.byref(d))
@@ -175,7 +177,11 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load(init_gpu=True)
         self._ws = {}
-        self._rowgeom = {}      # geometry -> row-geometry table of the weight-gradient kernels (see _rowgeom_table)
+        # geometry -> [row-geometry table of the weight-gradient kernels, event behind its fill | None, raw handle of the fill
+        # stream, pinned by a captured graph?] (see _rowgeom_table), least recently used first
+        self._rowgeom = collections.OrderedDict()
+        self._rowgeom_bytes = 0
+        self._rowgeom_streams = {}      # raw handle -> stream object of every stream a table was handed to (for eviction)
         # bench.py sets this to a list to collect (kind, algorithmic_flops, start_event, end_event, kernel name, algorithmic
         # bytes, geometry) per MFMA launch
         # group, recorded on the stream the kernels run on (torch's current stream).
@@ -298,21 +304,61 @@ class HipOps:
                                                _ptr(table), _ptr(ws), wsb, _stream()), "rsp_conv3d_wgrad_t")
         self._log("conv_wgrad", g, e0, names[2])
 
+    ROWGEOM_MAX_TABLES = 128
+    ROWGEOM_MAX_BYTES = 2 << 30
+
     def _rowgeom_table(self, g: ConvGeom, d, dref, dev):
         """The weight-gradient kernels' per-row geometry table of this geometry (rsp_conv3d_rowgeom): computed once and kept — it
-        depends on the positions only, not on channels or data.  None where the table-free path runs (kernel dims above 8)."""
+        depends on the positions only, not on channels or data.  None where the table-free path runs (kernel dims above 8).
+
+        The table is filled on the stream that first needs it (often the engine's side-task stream) and then handed to weight
+        gradients on ANY stream: the fill's event travels with the entry, and a caller on another stream waits for it until it has
+        completed once.  The cache is bounded (count and bytes, least recently used first; ~8 bytes per output position, 50 MB for
+        C3D's conv1): an evicted table is released behind every stream a table was ever handed to; tables baked into a captured
+        graph's kernel arguments are never evicted."""
         if max(g.k) > 8:
             return None
         key = (dev, g.N, g.Di, g.Hi, g.Wi, g.k, g.s, g.p, d.in_ld)
-        t = self._rowgeom.get(key)
-        if t is None:
-            if torch.cuda.is_current_stream_capturing():
+        ent = self._rowgeom.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
+        here = _stream().value
+        if ent is None:
+            if capturing:
                 return None                    # (first seen inside a capture: this call computes its own, the cache fills on the next eager step)
-            t = torch.empty(int(self.lib.rsp_conv3d_rowgeom_bytes(dref)), dtype=torch.uint8, device=dev)
+            nbytes = int(self.lib.rsp_conv3d_rowgeom_bytes(dref))
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(self.lib.rsp_conv3d_rowgeom(dref, _ptr(t), _stream()), "rsp_conv3d_rowgeom")
-            t.record_stream(torch.cuda.current_stream(dev))
-            self._rowgeom[key] = t
-        return t
+            ev = torch.cuda.Event()
+            ev.record()
+            ent = self._rowgeom[key] = [t, ev, here, False]
+            self._rowgeom_bytes += nbytes
+            self._rowgeom_evict(dev)
+        else:
+            self._rowgeom.move_to_end(key)
+            if ent[1] is not None and not capturing:      # (a capture starts behind a device-wide synchronize; event queries are illegal inside)
+                if ent[1].query():
+                    ent[1] = None              # the fill is complete: visible to every stream from now on
+                elif here != ent[2]:
+                    torch.cuda.current_stream(dev).wait_event(ent[1])
+            if capturing:
+                ent[3] = True
+        if here not in self._rowgeom_streams and not capturing:
+            self._rowgeom_streams[here] = torch.cuda.current_stream(dev)
+        return ent[0]
+
+    def _rowgeom_evict(self, dev):
+        if len(self._rowgeom) <= self.ROWGEOM_MAX_TABLES and self._rowgeom_bytes <= self.ROWGEOM_MAX_BYTES:
+            return
+        for key in list(self._rowgeom)[:-1]:           # never the entry just added
+            if len(self._rowgeom) <= self.ROWGEOM_MAX_TABLES and self._rowgeom_bytes <= self.ROWGEOM_MAX_BYTES:
+                break
+            t, _, _, pinned = self._rowgeom[key]
+            if pinned:
+                continue
+            for st in self._rowgeom_streams.values():  # a weight gradient on any of them may still be reading it
+                t.record_stream(st)
+            self._rowgeom_bytes -= t.numel()
+            del self._rowgeom[key]
 
     # ---- batch norm -------------------------------------------------------------------------------------------
     def bn_finalize(self, stats, count: int, conv_bias, gamma, beta, eps: float, momentum: float, running_mean,
@@ -730,6 +776,14 @@ class PackSet:
     def run(self):
         for kind, (table, n) in self.tables.items():
             _lib.check(self.be.lib.rsp_pack_run(_ptr(table), n, self.max_blocks[kind], _stream()), "rsp_pack_run")
+
+    def __del__(self):
+        # the library keeps a per-address note about packed stem buffers (three real input channels): withdrawn with the buffers
+        try:
+            for t in self.packed:
+                self.be.lib.rsp_conv3d_pack_forget(_ptr(t))
+        except Exception:      # noqa: BLE001 - interpreter shutdown: the library may be gone
+            pass
 
 
 _backend = None

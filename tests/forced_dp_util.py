@@ -69,7 +69,7 @@ def forced_worker(rank, backend, arch, seed, port, out_path, graph=False):
     dist.destroy_process_group()
 
 
-def segmented_worker(rank, arch, B, HW, port, out_path, steps=7):
+def segmented_worker(rank, arch, B, HW, port, out_path, mode="lanes", steps=7):
     """One RCCL rank with every collective forced on: `steps` consecutive steps of two identically initialised models — one
     driven by the eager data-parallel loop body (bucketed all-reduce from inside backward), one by GraphedPretextStep, which at
     collectives-on replays the step as HIP-graph SEGMENTS between the collective points — must leave bit-identical losses, logits,
@@ -90,6 +90,7 @@ def segmented_worker(rank, arch, B, HW, port, out_path, steps=7):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["RSP_FORCE_COLLECTIVES"] = "1"
+    os.environ["RSP_GRAPH_MODE"] = mode
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -105,7 +106,7 @@ def segmented_worker(rank, arch, B, HW, port, out_path, steps=7):
         setattr(dist, name, make(name, getattr(dist, name)))
     clips = [tuple(torch.from_numpy(c).to(dev) for c in P.clips(10 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
     results, info = [], {}
-    for mode in ("eager", "segments"):
+    for how in ("eager", "segments"):
         torch.manual_seed(7)
         torch.cuda.manual_seed(7)
         random.seed(7)
@@ -117,7 +118,7 @@ def segmented_worker(rank, arch, B, HW, port, out_path, steps=7):
         assert wrapped.module._dp()[2], "collectives must be on"
         crit = Loss(margin=2.0, A=1.0, M=1.0)
         opt = SGD(wrapped.parameters(), lr=0.05, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=False)
-        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2, issue="graph") if mode == "segments" else None
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2, issue="graph") if how == "segments" else None
         trace = []
         before = dict(calls)
         for im_q, im_k in clips:
@@ -131,13 +132,14 @@ def segmented_worker(rank, arch, B, HW, port, out_path, steps=7):
                 loss, la, lm, out, rl = stepper(im_q, im_k)
             trace.append((loss.detach().clone(), out[0].detach().clone(), rl[0].detach().clone()))
         torch.cuda.synchronize()
-        info[mode] = {k: calls[k] - before.get(k, 0) for k in calls}
+        info[how] = {k: calls[k] - before.get(k, 0) for k in calls}
         if stepper is not None:
-            assert stepper.mode == "segments" and not stepper.disabled, stepper.fallback_reason
+            assert stepper.mode == mode and not stepper.disabled, stepper.fallback_reason
             assert len(stepper.graphs) == 1
             seq = next(iter(stepper.graphs.values()))[3]
-            info["graph_segments"] = sum(1 for g, _ in seq if g is not None)
-            info["collective_points"] = sum(1 for g, _ in seq if g is None)
+            info["graphs"] = sum(1 for op in seq if op[0] == "g")
+            info["collective_points"] = sum(1 for op in seq if op[0] == "e")
+            info["lanes"] = sorted({op[1] for op in seq if op[0] == "g"})
         results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
     (te, se), (tg, sg) = results
     for i, ((l0, o0, r0), (l1, o1, r1)) in enumerate(zip(te, tg)):
@@ -147,5 +149,79 @@ def segmented_worker(rank, arch, B, HW, port, out_path, steps=7):
         assert torch.equal(se[k], sg[k]), (arch, k)
     with open(out_path, "w") as f:
         json.dump(info, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def bucket_order_worker(rank, arch, seed, port, out_path):
+    """Ordering of the bucketed gradient all-reduce against the weight-gradient side tasks: in a world of one rank an
+    all-reduce is the identity, so a bucket let go BEFORE a side-stream weight gradient has written into it would go unnoticed by
+    every value check.  Here `dist.all_reduce` is patched to snapshot the bucket ON THE ISSUING STREAM at the moment of issue; the
+    gradient buffer is poisoned with NaN before the backward, every weight gradient is sent to the side stream
+    (RSP_WGRAD_ASIDE_GFLOP huge), and each snapshot must hold no NaN and equal the bucket's final content bit for bit."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["RSP_WGRAD_ASIDE_GFLOP"] = "1e9"         # (read when rspnet_amd.engine is imported)
+    os.environ["RSP_FORCE_COLLECTIVES"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from golden_util import build_inputs, load_case
+    from model_util import ReplayRNG, make_cfg
+    from rspnet_amd import ops
+    from rspnet_amd.engine import BranchStreams
+    from rspnet_amd.moco import Loss, ModelFactory
+    from rspnet_amd.optim import SGD
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    assert ops.backend().name == "hip" and BranchStreams.SMALL_WGRAD_FLOPS > 1e17
+    z, meta = load_case(arch, 1, seed)
+    spec, (state, mom, clips, perms_B, sh) = build_inputs(arch, meta)
+    wrapped = ModelFactory(make_cfg(meta.get("arch", arch), meta["K"], fc_type=meta.get("fc_type", "linear"), m=meta["m"],
+                                    T=meta["T"])).build_moco_diffloss(device=dev)
+    model = wrapped.module
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    model.train()
+    opt = SGD([p for p in wrapped.parameters() if p.requires_grad], lr=meta["lr"], momentum=0.9, weight_decay=1e-4)
+    crit = Loss(margin=meta["margin"], A=meta["A"], M=meta["M"])
+    im_q, im_k = torch.from_numpy(clips[0][0]).to(dev), torch.from_numpy(clips[0][1]).to(dev)
+    snaps, side_issues = [], 0
+    real = dist.all_reduce
+    main = torch.cuda.current_stream(dev).cuda_stream
+
+    def spy(t, *a, **k):
+        nonlocal side_issues
+        if model._flat is not None and t.untyped_storage().data_ptr() == model._flat.g_flat.untyped_storage().data_ptr():
+            off = (t.data_ptr() - model._flat.g_flat.data_ptr()) // 4
+            snaps.append((off, t.numel(), t.clone()))          # a copy on the issuing stream: what RCCL would read
+            side_issues += int(torch.cuda.current_stream(dev).cuda_stream != main)
+        return real(t, *a, **k)
+
+    dist.all_reduce = spy
+    for it in range(3):                                        # several steps: the side stream is busy with the previous step's tail
+        snaps.clear()
+        with ReplayRNG([perms_B[0], sh[0], sh[1]], meta["speed"]):
+            out, tgt, rl, rt = wrapped(im_q, im_k)
+        loss, _, _ = crit(out, tgt, rl, rt)
+        opt.zero_grad()
+        model._flat.g_flat.fill_(float("nan"))
+        loss.backward()
+        torch.cuda.synchronize()
+        final = model._flat.g_flat.clone()
+        assert not torch.isnan(final).any(), "a trained parameter received no gradient"
+        assert len(snaps) >= 2, len(snaps)
+        covered = 0
+        for off, n, snap in snaps:
+            assert not torch.isnan(snap).any(), ("bucket issued before its gradients were written", it, off, n)
+            assert torch.equal(snap, final[off:off + n]), ("bucket changed after its all-reduce was issued", it, off, n)
+            covered += n
+        assert covered == final.numel()
+        opt.step()
+    with open(out_path, "w") as f:
+        json.dump({"buckets": len(snaps), "issued_from_side_stream": side_issues}, f)
+    dist.all_reduce = real
     dist.barrier()
     dist.destroy_process_group()

@@ -47,9 +47,10 @@ class ReplayRNG:
 
 def run_model_step(arch, meta, inputs, rank, device, optimizer="fused", issue="eager"):
     """One teacher-forced step of rspnet_amd on `device`.  Returns (out dict, post state dict, momentum_post dict).
-    issue="segments": the step cut at its collective points as rspnet_amd/graph_step.py replays it at more than one rank
-    (GraphedPretextStep._segments: device segments and collectives alternately, gradient all-reduce after the whole backward) —
-    here every segment is issued eagerly, so the cut itself is what is tested (any device, any op backend)."""
+    issue="segments" / "lanes": the step as the operation list rspnet_amd/graph_step.py captures and replays (GraphedPretextStep.
+    _schedule: graphs and collectives alternately; "lanes": the three forward passes as separate graphs, the backward in pieces
+    with the weight gradients set aside and the gradient buckets all-reduced between pieces) — here every operation is issued
+    eagerly, in order, so the cut itself is what is tested (any device, any op backend)."""
     from rspnet_amd.optim import SGD
     state, mom, clips, perms_B, sh = inputs
     wrapped = ModelFactory(make_cfg(meta.get("arch", arch), meta["K"], fc_type=meta.get("fc_type", "linear"), m=meta["m"],
@@ -70,24 +71,34 @@ def run_model_step(arch, meta, inputs, rank, device, optimizer="fused", issue="e
     crit = Loss(margin=meta["margin"], A=meta["A"], M=meta["M"])
     im_q = torch.from_numpy(clips[rank][0]).to(device)
     im_k = torch.from_numpy(clips[rank][1]).to(device)
-    if issue == "segments":
+    if issue in ("segments", "lanes"):
         from rspnet_amd.graph_step import GraphedPretextStep
         stepper = GraphedPretextStep(wrapped, crit, opt)
-        segs, box = stepper._segments(im_q, im_k)
-        assert [k for k, _ in segs] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"]
-        model._defer_reduce = True
+        ops, box = stepper._schedule(im_q, im_k, issue)
+        model._defer_reduce, model._defer_backward = True, issue == "lanes"
+        names_run = []
         try:
             with ReplayRNG([perms_B[rank], sh[0], sh[1]], meta["speed"]):
                 host = model._host_part(im_q.shape[0], device)
-                for _, fn in segs[:-1]:
-                    fn(host)
+                for op in ops:                         # (a generator in "lanes" mode: later operations depend on the earlier ones)
+                    if op[0] not in ("g", "e"):
+                        continue                       # fork / join: stream ordering only
+                    names_run.append(op[2])
+                    if op[2] == "update":
+                        # the last graph = DDP's average + SGD; the gradients are read between the two
+                        model._scale_gradients()
+                        grads = {names[id(p)]: (None if p.grad is None else p.grad.detach().cpu().numpy().copy()) for p in params}
+                        opt.step()
+                    else:
+                        op[3](host)
         finally:
-            model._defer_reduce = False
+            model._defer_reduce = model._defer_backward = False
+        assert names_run[0] == "top" and names_run[-1] == "update" and "tail" in names_run, names_run
+        if issue == "lanes":
+            assert {"query", "key_k", "key_kneg", "keys_join", "backward0"} <= set(names_run), names_run
+        run_model_step.last_ops = names_run
         loss, loss_A, loss_M, out, rl = box["outs"]
         tgt, rt = torch.zeros(im_q.shape[0], dtype=torch.long), torch.ones(im_q.shape[0], dtype=torch.long)
-        model._scale_gradients()                      # (first half of the last segment; the gradients are read between the two)
-        grads = {names[id(p)]: (None if p.grad is None else p.grad.detach().cpu().numpy().copy()) for p in params}
-        opt.step()
     else:
         with ReplayRNG([perms_B[rank], sh[0], sh[1]], meta["speed"]):
             out, tgt, rl, rt = wrapped(im_q, im_k)

@@ -34,6 +34,10 @@ def test_bench_prints_one_contract_line():
     # share with its source, traffic marked as a static lookup
     assert 0.5 < rf["executed_over_algorithmic"] <= 1.0 and abs(rf["executed_frac"] - rf["frac"] * rf["executed_over_algorithmic"]) < 2e-3
     assert rf["traffic_static"] is True and (rf["mfma_busy"] is None or 0.3 < rf["mfma_busy"] <= 1.0)
+    # ... and tied to the build the counters were collected on: a hash of rspnet_amd/csrc + include
+    assert "traffic_stale" in rf and rf["traffic_stale"] in (True, False, None)
+    if rf["traffic"] is not None:
+        assert isinstance(rf["traffic_stale"], bool) and "profiled_csrc_sha256" in rf["traffic_build"]
     assert rf["whole_step"]["executed_frac"] <= rf["whole_step"]["frac"]
     hk = d["hbm_kernels"]
     assert hk["peak_tb_s"] == 8.0 and {"bn_act_pool_fwd", "bn_bwd(reduce+apply)", "sgd_step", "momentum_update", "clip_gather"} <= set(hk["groups"])
@@ -43,6 +47,13 @@ def test_bench_prints_one_contract_line():
         assert d["issued_eagerly"]["clips_per_s"] > 0
     dp = d["dp_path_at_one_rank"]
     assert "error" not in dp and dp["clips_per_s"] > 0 and {"all_to_all_kneg", "all_to_all_k", "all_gather_keys", "allreduce_wait"} <= set(dp["comm_ms"])
+    # the data-parallel line diagnoses itself: who is in the job, how the step is issued, what issuing it costs
+    # the host — and the N = 1 number in that issue mode, to divide N > 1 values by
+    assert dp["rccl_ranks"] == {"world_size": 1, "distinct_devices": 1, "backend": "nccl", "host_cpus_per_rank": dp["rccl_ranks"]["host_cpus_per_rank"],
+                                "pinned": False}
+    assert dp["step_issue_mode"] in ("eager", "graph_segments", "graph_lanes") and dp["host_issue_idle_gpu_p50"] > 0
+    assert d["n1_same_mode"]["clips_per_s"] == dp["clips_per_s"] and d["n1_same_mode"]["step_issue_mode"] == dp["step_issue_mode"]
+    assert d["step_issue_mode"] in ("eager", "graph", "graph_lanes") and d["steps_ms"]["host_issue_idle_gpu_p50"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "clips/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert cb["cpu_model"] and cb["s_per_step"] > 0
@@ -60,6 +71,9 @@ def test_bench_prints_one_contract_line():
     assert set(ow) == {"resnet18", "r2plus1d-vcop", "s3dg"}
     for a, o in ow.items():
         assert o["clips_per_s"] > 0 and 0.1 < o["whole_step_frac"] < 1.0 and o["dominant_kernel"], a
+        # every backbone also runs the way N > 1 ranks run it: RCCL group of one rank, all collectives on
+        odp = o["dp_path_at_one_rank"]
+        assert "error" not in odp and odp["clips_per_s"] > 0 and odp["step_issue_mode"] in ("eager", "graph_segments", "graph_lanes"), (a, odp)
     assert "parity" not in d                       # --cpu-sample 2 != B: the CPU leg cannot replay the GPU's step
 
 

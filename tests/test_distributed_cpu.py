@@ -50,6 +50,18 @@ def test_two_rank_step_matches_golden(arch, seed):
         assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
 
 
+@pytest.mark.parametrize("arch", ["c3d", "resnet18"])
+def test_two_rank_step_in_lanes_matches_golden(arch):
+    """... and as the "lanes" schedule (the default of GraphedPretextStep): query / k / k_negative passes as separate graphs, the
+    backward cut into pieces with the small weight gradients set aside (engine.BranchStreams.deferred) and run as graphs of their
+    own, each 32 MiB gradient bucket all-reduced as soon as its last parameter has been issued, DDP's average and SGD last."""
+    from oracle.ref_harness import _free_port
+    a, _, seed = cases_for(arch, 2)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, a, seed, _free_port(), tmp, "lanes"), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
+
+
 def test_two_rank_step_in_segments_matches_golden():
     """The same 2-rank fixture with the step cut at its collective points, as rspnet_amd/graph_step.py replays it at more than
     one rank: top | all-to-all x2 | three forward passes | all-gather | logits + losses + whole backward | all-reduce | average +

@@ -27,9 +27,13 @@ def _build(arch, K, speeds=(2,)):
     return wrapped, Loss(margin=2.0, A=1.0, M=1.0), opt
 
 
-@pytest.mark.parametrize("arch,B,HW", [("c3d", 4, 32), ("s3dg", 4, 64), ("resnet18", 8, 64)])
-def test_graphed_step_equals_eager_step(arch, B, HW):
+@pytest.mark.parametrize("arch,B,HW,mode", [("c3d", 4, 32, "lanes"), ("s3dg", 4, 64, "lanes"), ("resnet18", 8, 64, "lanes"),
+                                            ("s3dg", 4, 64, "whole"), ("r2plus1d-vcop", 4, 32, "lanes")])
+def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
+    """mode "lanes" (default): seven linear graphs, the three forward passes replayed side by side on three streams; "whole": one graph
+    with the forks inside the capture (rounds 2-4)."""
     from rspnet_amd.graph_step import GraphedPretextStep
+    monkeypatch.setenv("RSP_GRAPH_MODE", mode)
     K, steps = 64, 6
     clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(10 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
     results = []
@@ -52,8 +56,10 @@ def test_graphed_step_equals_eager_step(arch, B, HW):
             trace.append((loss.detach().clone(), out[0].detach().clone(), rl[0].detach().clone()))
         torch.cuda.synchronize()
         if stepper is not None:
-            assert not stepper.disabled, stepper.fallback_reason
-            assert len(stepper.graphs) == 1                      # warm-up steps ran eagerly, the rest replayed one graph
+            assert not stepper.disabled and stepper.mode == mode, stepper.fallback_reason
+            assert len(stepper.graphs) == 1                      # warm-up steps ran eagerly, the rest replayed one captured schedule
+            seq = next(iter(stepper.graphs.values()))[3]
+            assert sum(1 for op in seq if op[0] == "g") == (7 if mode == "lanes" else 1)
         results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
     (te, se), (tg, sg) = results
     for i, ((l0, o0, r0), (l1, o1, r1)) in enumerate(zip(te, tg)):

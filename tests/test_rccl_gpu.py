@@ -74,21 +74,40 @@ def test_rccl_one_rank_forced_collectives_match_the_fixture(arch):
     assert rep["calls"]["all_to_all_single"] == 2 and rep["calls"]["all_gather_into_tensor"] == 1 and rep["calls"]["all_reduce"] >= 2
 
 
-@pytest.mark.parametrize("arch,B,HW", [("c3d", 4, 32), ("s3dg", 4, 64)])
-def test_rccl_one_rank_segmented_replay_equals_the_eager_dp_step(arch, B, HW):
+@pytest.mark.parametrize("arch,B,HW,mode", [("c3d", 4, 32, "lanes"), ("s3dg", 4, 64, "lanes"), ("s3dg", 4, 64, "segments")])
+def test_rccl_one_rank_segmented_replay_equals_the_eager_dp_step(arch, B, HW, mode):
     """The N > 1 issue mode that is not Python-bound: with the collectives on, GraphedPretextStep replays the
-    step as four HIP graphs between its collective points (RCCL calls issued eagerly in between) — bit-identical to the eager
+    step as HIP graphs between its collective points (RCCL calls issued eagerly in between) — "lanes": seven linear graphs, the
+    three forward passes side by side on three streams; "segments": four graphs with the forks inside — bit-identical to the eager
     data-parallel loop over seven steps, two of them eager warm-ups.  See forced_dp_util.segmented_worker."""
     import json
     from forced_dp_util import segmented_worker
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "ok.json")
-        mp.spawn(segmented_worker, args=(arch, B, HW, _free_port(), out), nprocs=1, join=True)
+        mp.spawn(segmented_worker, args=(arch, B, HW, _free_port(), out, mode), nprocs=1, join=True)
         with open(out) as f:
             rep = json.load(f)
     print("\n", arch, rep)
-    assert rep["graph_segments"] == 4 and rep["collective_points"] == 3
+    assert rep["collective_points"] == 3
+    assert (rep["graphs"], rep["lanes"]) == ((7, ["k", "main", "q"]) if mode == "lanes" else (4, ["main"]))
     # every step of either loop issues its 2 clip all-to-alls and its 1 key all-gather
-    for mode in ("eager", "segments"):
-        assert rep[mode]["all_to_all_single"] == 2 * 7 and rep[mode]["all_gather_into_tensor"] == 7 and rep[mode]["all_reduce"] >= 7
+    for m in ("eager", "segments"):
+        assert rep[m]["all_to_all_single"] == 2 * 7 and rep[m]["all_gather_into_tensor"] == 7 and rep[m]["all_reduce"] >= 7
+
+
+def test_bucket_all_reduce_is_ordered_behind_the_side_stream_weight_gradients():
+    """the data-parallel step runs weight gradients on a side stream and issues each bucket's all-reduce from a
+    stream context ordered behind trunk AND side stream.  With one rank the all-reduce moves nothing, so the ordering is checked
+    directly: see forced_dp_util.bucket_order_worker (NaN-poisoned gradient buffer, snapshot at issue == final content)."""
+    import json
+    from forced_dp_util import bucket_order_worker
+    from oracle.ref_harness import _free_port
+    a, _, seed = cases_for("c3d", 1)[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "ok.json")
+        mp.spawn(bucket_order_worker, args=(a, seed, _free_port(), out), nprocs=1, join=True)
+        with open(out) as f:
+            rep = json.load(f)
+    print("\n", rep)
+    assert rep["buckets"] >= 2 and rep["issued_from_side_stream"] >= 1

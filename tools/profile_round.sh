@@ -9,6 +9,8 @@ ARCHS=("$@"); [ ${#ARCHS[@]} -eq 0 ] && ARCHS=(c3d resnet18 r2plus1d-vcop s3dg)
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out"
 mkdir -p "$OUT"
+# the build these profiles are measured on (tools/summarize_profiles.py stores it next to the counters; bench.py compares)
+python3 -c "import sys; sys.path.insert(0, '$R'); from rspnet_amd import _lib; print(_lib.source_hash())" > "$OUT/csrc_hash_${TAG}.txt"
 cd /tmp && export TMPDIR=/tmp
 for a in "${ARCHS[@]}"; do
   # the bench line as the driver runs it for this backbone (step issue: bench.py --graph auto), then the profiled passes with the

@@ -49,6 +49,15 @@ traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 if "kernel" in traffic:      # round-1 single-kernel format
     traffic = {}
 
+sys.path.insert(0, ROOT)
+from rspnet_amd import _lib  # noqa: E402
+
+hpath = f"{g}/csrc_hash_{tag}.txt"
+# the hash written on the GPU box by tools/profile_round.sh = the sources the profiled build was compiled from
+build = {"csrc_sha256": open(hpath).read().strip() if os.path.exists(hpath) else _lib.source_hash(),
+         "hash_from": "the profiled run (tools/profile_round.sh)" if os.path.exists(hpath) else "the tree at summarise time",
+         "commit": os.popen(f"git -C {ROOT} rev-parse HEAD").read().strip() or None, "tag": tag}
+
 for arch, B in BATCH.items():
     ks = one(f"{g}/prof_{tag}_{arch}/*/*_kernel_stats.csv")
     if not ks:
@@ -84,6 +93,7 @@ for arch, B in BATCH.items():
                       "source": f"profiles/{rnd}/pmc_by_kernel_{arch}_b{B}_{tag}.txt"}
     with open(f"{out}/pmc_by_kernel_{arch}_b{B}_{tag}.txt", "w") as o:
         o.write("\n".join(lines) + "\n")
+    ent["_build"] = build
     traffic[f"{arch}_b{B}"] = ent
     rows = list(csv.DictReader(open(ks)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
