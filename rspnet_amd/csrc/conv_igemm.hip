@@ -1305,6 +1305,180 @@ __global__ __launch_bounds__(256, MINW) void igemm_multi_kernel(const IgemmMulti
   igemm_body<BM, BN, WAVES_M, WAVES_N, VEC>(m.p[c], (int)blockIdx.x - m.start[c], m.start[c + 1] - m.start[c]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Direct implicit GEMM for SMALL launches (round 5): 128 rows x 64 columns per workgroup, operands straight from L2 into MFMA
+// fragments — no LDS tiles, no tile pipeline to fill and drain.
+//
+// Why.  The LDS-DMA tile kernels above are built for launches of many rounds: a 128 x 128 tile lives 45-70 us even at K = 64-288
+// (15 us before its first MFMA, 8 us storing: tools/phase_probe.py), and a launch of a few dozen to a few hundred tiles — the
+// 14 x 14 / 7 x 7 stages of S3D-G and R3D-18 / R(2+1)D, every 1x1x1 stride-2 shortcut — is one ragged round of that life:
+// 15-56 TFLOP/s where the big layers run at 105-140 (profiles/r04).  Here a wave owns 32 rows x 64 columns (two 32x32 accumulators)
+// and per 32-deep K chunk each lane loads 64 contiguous bytes of ITS row of the im2col matrix (the half-wave h takes k 16h..16h+15 of
+// the chunk) and 64 bytes of each of its two weight rows — whole 128-byte lines per row and chunk, so nothing relies on L1 reuse —
+// one chunk ahead of the 32 MFMAs that consume them.  ~130 VGPRs: three waves per SIMD cover the L2 latency.  The K order is the
+// packed weights' (tap-major, or channel-slice-major: fill_fastdiv), the row geometry the general affine one of IgemmParams, so
+// forward convolutions and every stride-parity class of an input gradient run through it; a K split over blockIdx (unit = tile +
+// tiles * slice) feeds the existing fixed-order splitk_reduce_vec_kernel when the tiles alone cannot fill the machine.
+// Needs 16-byte rows with Cin % 16 == 0 (a 16-deep half-chunk never straddles a tap).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct DirectFrag {
+  floatx4 a[4];
+  floatx4 b[2][4];
+};
+
+__global__ __launch_bounds__(256, 3) void igemm_direct_kernel(const IgemmParams p) {
+  __shared__ long long rowaddr[128];
+  __shared__ float red[4][64][2];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l32 = lane & 31, h = lane >> 5;
+  const int tiles = p.m_tiles * p.n_tiles;
+  const int z = (int)blockIdx.x / tiles;                      // K slice (slice-major units: neighbours share the A rows in L2)
+  const int tile = (int)blockIdx.x - z * tiles;
+  const int m_tile = tile / p.n_tiles, n_tile = tile - m_tile * p.n_tiles;
+  const int m0 = m_tile * 128, n0 = n_tile * 64;
+  const bool is_partial = p.splitk > 1;
+  const int kc_begin = z * p.chunks_per_split;
+  const int kc_end = min(p.nchunks, kc_begin + p.chunks_per_split);
+  const int ntaps = p.nTd * p.nTh * p.nTw;
+
+  // this lane's row of the im2col matrix
+  const int r = m0 + wave * 32 + l32;
+  const bool rv = r < p.M;
+  int n = 0, gd = 0, gh = 0, gw = 0;
+  {
+    const int rr = rv ? r : 0;
+    const int q1 = fastdiv(rr, p.dGw);
+    gw = rr - q1 * p.Gw;
+    const int q2 = fastdiv(q1, p.dGh);
+    gh = q1 - q2 * p.Gh;
+    row_decode(p, false, q2, n, gd);
+  }
+  const int id0 = gd * p.sD + p.off0d, ih0 = gh * p.sH + p.off0h, iw0 = gw * p.sW + p.off0w;
+  const long long xn = (long long)n * p.Di;
+  const float* wrow[2];
+  bool cv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + j * 32 + l32;
+    cv[j] = col < p.Cout;
+    wrow[j] = p.w + (long long)(cv[j] ? col : 0) * p.Kld + 16 * h;
+  }
+
+  auto load = [&](int kc, DirectFrag& f) {
+    const int kpos = kc * BK + 16 * h;                         // this half-wave's 16 k of the chunk, in packed order
+    int tap, ci;
+    if (p.kmajor) {
+      const int sl = fastdiv(kc, p.dNt);
+      tap = kc - sl * ntaps;
+      ci = sl * BK + 16 * h;
+    } else {
+      tap = fastdiv(kpos, p.dCin);
+      ci = kpos - tap * p.Cin;
+    }
+    const bool kin = kpos < p.K;
+    const int q = fastdiv(tap, p.dTw), aw = tap - q * p.nTw;
+    const int ad = fastdiv(q, p.dTh), ah = q - ad * p.nTh;
+    const int id = id0 + ad * p.offstep, ih = ih0 + ah * p.offstep, iw = iw0 + aw * p.offstep;
+    const bool ok = rv && kin && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+    const floatx4* ap = reinterpret_cast<const floatx4*>(p.x + (((xn + id) * p.Hi + ih) * p.Wi + iw) * p.in_ld + ci);
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.a[i] = ok ? ap[i] : zero;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const floatx4* bp = reinterpret_cast<const floatx4*>(wrow[j] + (long long)kc * BK);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.b[j][i] = (cv[j] && kin) ? bp[i] : zero;
+    }
+  };
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  auto mma = [&](const DirectFrag& f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][i][e], acc[j], 0, 0, 0);
+  };
+
+  DirectFrag f0, f1;
+  if (kc_begin < kc_end) load(kc_begin, f0);
+  for (int kc = kc_begin; kc < kc_end; kc += 2) {
+    if (kc + 1 < kc_end) load(kc + 1, f1);
+    mma(f0);
+    if (kc + 1 < kc_end) {
+      if (kc + 2 < kc_end) load(kc + 2, f0);
+      mma(f1);
+    }
+  }
+
+  // ---- epilogue: rows of the accumulators -> addresses (general affine mapping through a per-tile table) ---------------------
+  if (!is_partial && !p.linear_out) {
+    if (t < 128) {
+      const int rr = m0 + t;
+      long long addr = -1;
+      if (rr < p.M) {
+        const int q1 = fastdiv(rr, p.dGw), w_ = rr - q1 * p.Gw;
+        const int q2 = fastdiv(q1, p.dGh), h_ = q1 - q2 * p.Gh;
+        int n_, d_;
+        row_decode(p, false, q2, n_, d_);
+        addr = ((((long long)n_ * p.oDm + d_ * p.oSd + p.oOd) * p.oHm + h_ * p.oSh + p.oOh) * p.oWm + w_ * p.oSw + p.oOw) * p.out_ld;
+      }
+      rowaddr[t] = addr;
+    }
+    __syncthreads();
+  }
+  float* dst = is_partial ? p.partial + (long long)z * p.M * p.Cout : p.y;
+  const long long ld = is_partial ? p.Cout : p.out_ld;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + j * 32 + l32;
+    if (col < p.Cout) {
+      const float bv = (p.bias && !is_partial) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wave * 32 + (e >> 2) * 8 + h * 4 + (e & 3);
+        if (m0 + rl < p.M) {
+          const long long addr = (is_partial || p.linear_out) ? (long long)(m0 + rl) * ld : rowaddr[rl];
+          dst[addr + col] = acc[j][e] + bv;
+        }
+      }
+    }
+  }
+  if (p.stat && !is_partial) {
+    // per-channel (sum, sumsq) of the bias-free output over this tile's 128 rows (rows >= M hold zeros): fixed order
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float sm = 0.f, ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[j][e];
+        sm += v;
+        ss = fmaf(v, v, ss);
+      }
+      sm += __shfl_xor(sm, 32);
+      ss += __shfl_xor(ss, 32);
+      if (h == 0) {
+        red[wave][j * 32 + l32][0] = sm;
+        red[wave][j * 32 + l32][1] = ss;
+      }
+    }
+    __syncthreads();
+    if (t < 64 && n0 + t < p.Cout) {
+      float* o = p.stat + ((long long)m_tile * p.stat_ld + n0 + t) * 2;
+      o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
+      o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
+    }
+  }
+}
+
 // split-K reduction: y[row] = sum_z partial[z][row] + bias, stats per 128-row tile.
 struct ReduceParams {
   const float* __restrict__ partial;
@@ -1373,9 +1547,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
 
 // Vector variant (Cout % 4 == 0, out_ld % 4 == 0, y 16-byte aligned): thread = (4 channels, 8 rows); the 8 rows' loads are
 // independent, so each thread keeps 8 x 16 B in flight per K-slice instead of one dependent 4-byte load at a time.
-__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const ReduceParams p) {
+__device__ __forceinline__ void splitk_reduce_vec_body(const ReduceParams& p, const int bx, const int by) {
   __shared__ floatx4 red[2][16][16];
-  const int m_tile = p.row0 / 128 + blockIdx.x, c0 = blockIdx.y * 64;
+  const int m_tile = p.row0 / 128 + bx, c0 = by * 64;
   const int q4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = c0 + 4 * q4;
   const bool cok = c < p.Cout;
@@ -1434,6 +1608,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const ReducePara
       if (c0 + cc < p.Cout) p.stat[((long long)m_tile * p.stat_ld + c0 + cc) * 2 + which] = a;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const ReduceParams p) {
+  splitk_reduce_vec_body(p, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ... of several problems in one launch (the K-split stride-parity classes of a few-tile input gradient, dgrad_run): blockIdx.z
+// picks the problem; problems without a K split wrote their output themselves
+struct ReduceMulti {
+  int n;
+  ReduceParams r[MAX_MULTI];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_vec_multi_kernel(const ReduceMulti m) {
+  const ReduceParams& p = m.r[blockIdx.z];
+  if (p.splitk <= 1 || (long long)blockIdx.x * 128 >= p.M - p.row0 || (int)blockIdx.y * 64 >= p.Cout) return;
+  splitk_reduce_vec_body(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Weight re-pack: out[o][tapidx*C + c] (row pitch Kld, zero padded) from the reference layout (Cout,Cin,kT,kH,kW).
@@ -1902,9 +2092,112 @@ Segments plan_segments(int Cout) {
   return g;
 }
 
+// ---- the direct kernel's share (igemm_direct_kernel): launches whose 128-row x 128-column tile count is at most DIRECT_MAX_TILES
+static bool direct_enabled() {
+  static const bool off = getenv("RSP_NO_DIRECT") != nullptr;      // (A/B switch for measurements, read once)
+  return !off;
+}
+static int direct_max_tiles() {
+  static const int v = getenv("RSP_DIRECT_MAX_TILES") ? atoi(getenv("RSP_DIRECT_MAX_TILES")) : 448;
+  return v;
+}
+// Measured per layer against the tile kernels (profiles/r05/direct_vs_tile_r5h.txt): the direct kernel tops out at 45-50 TFLOP/s
+// (L2 latency under three waves per SIMD), the tile kernels reach 100+ on anything of a few GFLOP — so it takes only what the tile
+// pipeline cannot amortise: at most 25 row tiles and 1.4 GFLOP (7 x 7 / 4 x 4 stages: 13-30 % faster), or K of at most two
+// chunks (the 1x1x1 stride-2 shortcuts: 15-25 %).
+bool direct_applies(long long M, int Cout, int Cin, int K, bool vec4) {
+  if (!vec4 || !direct_enabled() || Cin % 16 != 0 || M <= 0) return false;
+  if ((long long)rsp_cdiv(M, 128) * rsp_cdiv(Cout, 128) > direct_max_tiles()) return false;
+  if (getenv("RSP_DIRECT_MAX_TILES")) return true;      // (sweeps: the tile count alone decides)
+  const double flops = 2.0 * (double)M * Cout * K;
+  return (rsp_cdiv(M, 128) <= 25 && flops <= 1.4e9) || rsp_cdiv(K, BK) <= 2;
+}
+// K split of a direct launch: enough units for ~3 workgroups per CU, at least 4 chunks per slice
+struct DirectPlan {
+  int splitk, cps;
+};
+DirectPlan direct_plan(long long M, int Cout, int nchunks) {
+  const long long tiles = (long long)rsp_cdiv(M, 128) * rsp_cdiv(Cout, 64);
+  int S = (int)((768 + tiles - 1) / tiles);
+  if (S > nchunks / 4) S = nchunks / 4;
+  if (S > 32) S = 32;
+  if (S < 1) S = 1;
+  const int cps = rsp_cdiv(nchunks, S);
+  return {rsp_cdiv(nchunks, cps), cps};
+}
+size_t direct_partial_bytes(long long M, int Cout, int K) {
+  const DirectPlan dp = direct_plan(M, Cout, rsp_cdiv(K, BK));
+  return dp.splitk > 1 ? (size_t)dp.splitk * (size_t)M * Cout * sizeof(float) : 0;
+}
+
+// K split of the classes of a FEW-TILE strided input gradient that share one igemm_multi_kernel launch (dgrad_run): slices of about
+// equal length across the classes (a class has 1 ... kT*kH*kW/(sT*sH*sW) taps), enough units for ~3 workgroups per CU, at least
+// 4 chunks per slice; class c's partials follow class c-1's in the workspace.
+struct MultiSplit {
+  int S[MAX_MULTI], cps[MAX_MULTI];
+  size_t off[MAX_MULTI], bytes;
+};
+static MultiSplit plan_multi_split(int n, const long long* M, const int* tiles, const int* nchunks, int Cout) {
+  MultiSplit ms;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) total += (long long)tiles[i] * nchunks[i];
+  long long target = (total + 767) / 768;
+  if (target < 4) target = 4;
+  ms.bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    int S = (int)((nchunks[i] + target - 1) / target);
+    if (S > nchunks[i] / 4) S = nchunks[i] / 4;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    const int cps = rsp_cdiv(nchunks[i], S);
+    ms.cps[i] = cps;
+    ms.S[i] = rsp_cdiv(nchunks[i], cps);
+    ms.off[i] = ms.bytes;
+    if (ms.S[i] > 1) ms.bytes += rsp_align_up((size_t)ms.S[i] * (size_t)M[i] * Cout * sizeof(float), 256);
+  }
+  return ms;
+}
+static bool multi_split_enabled() {
+  static const bool off = getenv("RSP_NO_MULTI_SPLIT") != nullptr;      // (A/B switch for measurements, read once)
+  return !off;
+}
+int run_direct(IgemmParams& p, void* workspace, size_t ws_bytes, hipStream_t s) {
+  p.zero = nullptr;
+  p.nchunks = rsp_cdiv(p.K, BK);
+  fill_fastdiv(p);
+  p.dmajor = 0;                      // plain (sample, depth, h, w) rows
+  p.tm_skip = 0;
+  fill_fastdiv_linear(p);
+  p.m_tiles = rsp_cdiv(p.M, 128);
+  p.n_tiles = rsp_cdiv(p.Cout, 64);
+  DirectPlan dp = direct_plan(p.M, p.Cout, p.nchunks);
+  if (dp.splitk > 1 && (!workspace || ws_bytes < (size_t)dp.splitk * (size_t)p.M * p.Cout * sizeof(float))) dp = {1, p.nchunks};
+  p.splitk = dp.splitk;
+  p.chunks_per_split = dp.cps;
+  p.full_tiles = 0;
+  p.tail_row0 = 0;
+  p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+  rsp_note_kernel("igemm_direct_kernel");
+  hipLaunchKernelGGL(igemm_direct_kernel, dim3((unsigned)(p.m_tiles * p.n_tiles * p.splitk)), dim3(256), 0, s, p);
+  int rc = rsp_check_launch("igemm_direct_kernel");
+  if (rc != RSP_OK) return rc;
+  if (p.splitk > 1) {
+    ReduceParams r;
+    fill_reduce(r, p);
+    dim3 grid(rsp_cdiv(p.M, 128), rsp_cdiv(p.Cout, 64));
+    if (p.Cout % 4 == 0 && p.out_ld % 4 == 0 && rsp_aligned16(p.y) && (!p.bias || rsp_aligned16(p.bias)))
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel, grid, dim3(256), 0, s, r);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, r);
+    rc = rsp_check_launch("splitk_reduce_kernel");
+  }
+  return rc;
+}
+
 int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
-  const Segments g = plan_segments(p.Cout);
   p.stat_ld = p.Cout;
+  if (direct_applies(p.M, p.Cout, p.Cin, p.K, vec4)) return run_direct(p, workspace, ws_bytes, s);
+  const Segments g = plan_segments(p.Cout);
   if (g.n == 1) return run_igemm_segment(p, vec4, workspace, ws_bytes, s);
   for (int i = 0; i < g.n; ++i) {
     IgemmParams q = p;
@@ -1925,7 +2218,7 @@ size_t igemm_partial_bytes_segment(long long M, int Cout, int K);
 
 size_t igemm_partial_bytes(long long M, int Cout, int K) {
   const Segments g = plan_segments(Cout);
-  size_t best = 0;
+  size_t best = direct_partial_bytes(M, Cout, K);      // (whether the direct kernel runs depends on alignment, unknown here)
   for (int i = 0; i < g.n; ++i) {
     const size_t b = igemm_partial_bytes_segment(M, g.width[i], K);
     best = b > best ? b : best;
@@ -1968,7 +2261,10 @@ DgradClass dgrad_class(const rsp_conv3d_desc* d, int c) {
 // Host replica of the kernels' walk over K: the share of a problem's (tile, chunk) pairs that igemm_body executes once the chunks
 // whose taps are padding for a whole tile are skipped (1.0 when nothing is skipped).  Same row enumeration (row_decode), same
 // validity bits (span), same liveness tests as the device code; the column segments of one GEMM share the rows, hence the share.
-double igemm_live_fraction(IgemmParams p, bool vec4) {
+bool direct_applies(long long M, int Cout, int Cin, int K, bool vec4);
+
+double igemm_live_fraction(IgemmParams p, bool vec4, bool may_direct = true) {
+  if (may_direct && direct_applies(p.M, p.Cout, p.Cin, p.K, vec4)) return 1.0;      // igemm_direct_kernel walks every chunk
   p.nchunks = rsp_cdiv(p.K, BK);
   fill_fastdiv(p);
   if (!vec4) return 1.0;
@@ -2147,13 +2443,15 @@ double rsp_conv3d_executed_fraction(const rsp_conv3d_desc* d, int which) {
     return igemm_live_fraction(p, vec4);
   }
   double live = 0.0, tot = 0.0;
+  // (the tap-major classes that share one igemm_multi_kernel launch run the tile kernels' walk, whatever their size: dgrad_run)
+  const bool multi = strstr(rsp_conv3d_kernel_name(d, 1), "igemm_multi_kernel") != nullptr;
   for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
     const DgradClass g = dgrad_class(d, c);
     if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
     IgemmParams p;
     const bool vec4 = fill_dgrad_class_params(d, g, al, al, al, p);
     const double wgt = (double)p.M * p.K;
-    live += wgt * igemm_live_fraction(p, vec4);
+    live += wgt * igemm_live_fraction(p, vec4, !(multi && !k_slice_major(d->Cout, g.nt * g.nh * g.nw)));
     tot += wgt;
   }
   return tot > 0 ? live / tot : 1.0;
@@ -2175,16 +2473,17 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   const int cin = which == 0 ? d->Cin : d->Cout, ld = which == 0 ? d->in_ld : d->out_ld, cols = which == 0 ? d->Cout : d->Cin;
   const bool vec4 = cin % 4 == 0 && ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 && d->kW <= 8;
   if (which == 1 && vec4 && d->sT * d->sH * d->sW > 1 && plan_segments(cols).n == 1) {
-    // the stride-parity classes of a mid-sized strided dgrad share one launch (dgrad_run)
-    int ncls = 0;
+    // the tap-major stride-parity classes of a small or mid-sized strided dgrad share one launch, which runs first (dgrad_run)
+    int nm = 0;
     long long tiles = 0;
     for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
       const DgradClass g = dgrad_class(d, c);
-      if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
-      ++ncls;
+      if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0 || k_slice_major(d->Cout, g.nt * g.nh * g.nw)) continue;
+      ++nm;
       tiles += (long long)rsp_cdiv(d->N * g.Gd * g.Gh * g.Gw, 128) * rsp_cdiv(cols, tile_bn(cols));
     }
-    if (ncls >= 2 && ncls <= MAX_MULTI && tiles >= 512 && tiles <= 4096) {
+    if (nm >= 2 && nm <= MAX_MULTI && ((tiles >= 512 && tiles <= 4096) || (tiles < 512 && multi_split_enabled() && cols % 4 == 0 &&
+                                                                         (which == 0 ? d->out_ld : d->in_ld) % 4 == 0))) {
       switch (tile_bn(cols)) {
         case 160: return "igemm_multi_kernel<128, 160, 4, 1, 4, 2>";
         case 128: return "igemm_multi_kernel<128, 128, 2, 2, 4, 2>";
@@ -2193,6 +2492,21 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
         default: return "igemm_multi_kernel<128, 32, 4, 1, 4, 2>";
       }
     }
+  }
+  {
+    // small launches: the direct kernel (run_igemm).  dgrad: the first non-empty stride-parity class decides, as below
+    long long Mrows = (long long)d->N * d->Do * d->Ho * d->Wo;
+    int Kk = d->kT * d->kH * d->kW * d->Cin;
+    if (which == 1) {
+      for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
+        const DgradClass g = dgrad_class(d, c);
+        if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+        Mrows = (long long)d->N * g.Gd * g.Gh * g.Gw;
+        Kk = g.nt * g.nh * g.nw * d->Cout;
+        break;
+      }
+    }
+    if (direct_applies(Mrows, cols, cin, Kk, vec4)) return "igemm_direct_kernel";
   }
   // (a convolution that runs as two column segments is named after the first, wider one)
   int bn = tile_bn(plan_segments(cols).width[0]);
@@ -2255,6 +2569,27 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
 // ---- dgrad ----------------------------------------------------------------------------------------------------
 // dx[i] = sum_{k : (i + p - k) % s == 0} dy[(i + p - k)/s] * w[k]; positions are split into s^3 parity classes,
 // each a dense stride-1 "conv" over dy with its own tap subset; class c writes the strided sub-grid i = s*g + r.
+// partial bytes a descriptor's dgrad may need on the shared K-split launch (alignment-dependent conditions assumed true)
+static size_t dgrad_multi_split_bytes(const rsp_conv3d_desc* d) {
+  const int nclass = d->sT * d->sH * d->sW;
+  if (nclass < 2 || plan_segments(d->Cin).n != 1) return 0;
+  long long Ms[MAX_MULTI], tiles_all = 0;
+  int tl[MAX_MULTI], nc[MAX_MULTI], n = 0;
+  const int bn = tile_bn(d->Cin);
+  for (int c = 0; c < nclass; ++c) {
+    const DgradClass g = dgrad_class(d, c);
+    if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0 || k_slice_major(d->Cout, g.nt * g.nh * g.nw)) continue;
+    if (n >= MAX_MULTI) return 0;
+    Ms[n] = (long long)d->N * g.Gd * g.Gh * g.Gw;
+    tl[n] = rsp_cdiv(Ms[n], 128) * rsp_cdiv(d->Cin, bn);
+    nc[n] = rsp_cdiv((long long)g.nt * g.nh * g.nw * d->Cout, BK);
+    tiles_all += tl[n];
+    ++n;
+  }
+  if (n < 2 || tiles_all >= 512) return 0;
+  return plan_multi_split(n, Ms, tl, nc, d->Cin).bytes;
+}
+
 size_t rsp_conv3d_dgrad_workspace(const rsp_conv3d_desc* d) {
   if (!desc_ok(d)) return 0;
   size_t part = 0;
@@ -2265,8 +2600,11 @@ size_t rsp_conv3d_dgrad_workspace(const rsp_conv3d_desc* d) {
     const size_t b = igemm_partial_bytes((long long)d->N * g.Gd * g.Gh * g.Gw, d->Cin, g.nt * g.nh * g.nw * d->Cout);
     part = b > part ? b : part;
   }
+  const size_t mb = dgrad_multi_split_bytes(d);
+  part = mb > part ? mb : part;
   return dgrad_wpack_bytes(d) + part;
 }
+
 
 // Fill the re-pack description of one dgrad stride-parity class (source dims = the descriptor's: no padding).
 static void dgrad_pack_params(const rsp_conv3d_desc* d, const DgradClass& g, const float* w_ref, float* out, PackParams& pk) {
@@ -2312,18 +2650,39 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
     woff += (size_t)d->Cin * Kld;
     ++ncls;
   }
-  // Small classes of a strided convolution share ONE launch (igemm_multi_kernel): every class on the LDS-DMA path, a single
-  // column segment, and few enough tiles that separate launches would each leave most of the machine idle.
-  bool multi = ncls >= 2 && ncls <= MAX_MULTI && plan_segments(d->Cin).n == 1;
+  // Small classes of a strided convolution share ONE launch (igemm_multi_kernel): the classes on the LDS-DMA path with the
+  // tap-major K walk (one walk per launch; a class long enough for the slice-major walk — R3D-18 layer4.0's 8-tap class — runs on
+  // its own behind them), a single column segment, and few enough tiles that separate launches would each leave most of the
+  // machine idle.
+  int mi[MAX_MULTI + 1], nm = 0;      // the classes that share the launch
+  bool in_multi[64] = {false};
   long long tiles_all = 0;
   const int bn = tile_bn(d->Cin);
-  for (int i = 0; i < ncls && multi; ++i) {
-    multi = cvec[i] && !k_slice_major(cls[i].Cin, cls[i].nTd * cls[i].nTh * cls[i].nTw);   // (one K walk per launch: the tap-major one)
-    tiles_all += (long long)rsp_cdiv(cls[i].M, 128) * rsp_cdiv(d->Cin, bn);
+  if (ncls >= 2 && plan_segments(d->Cin).n == 1) {
+    for (int i = 0; i < ncls; ++i)
+      if (cvec[i] && !k_slice_major(cls[i].Cin, cls[i].nTd * cls[i].nTh * cls[i].nTw) && nm <= MAX_MULTI) mi[nm++] = i;
+    if (nm > MAX_MULTI) nm = 0;
+    for (int j = 0; j < nm; ++j) tiles_all += (long long)rsp_cdiv(cls[mi[j]].M, 128) * rsp_cdiv(d->Cin, bn);
   }
-  // (below ~one round of resident workgroups the classes need the K split of the single-problem path to fill the machine —
-  //  R3D-18 layer4.0: 64 tiles of 128 chunks; above a few thousand tiles each class fills it on its own)
-  if (multi && tiles_all >= 512 && tiles_all <= 4096) {
+  const bool multi = nm >= 2;
+  // (above a few thousand tiles each class fills the machine on its own)
+  // Few tiles (R3D-18 layer3.0 / layer4.0: 8 classes of 25 / 8 tiles): the classes still share ONE launch, each cut along K by one
+  // common plan, and ONE batched reduce sums all of them (round 5; until then each class ran its own K-split launch + reduce: 16
+  // dependent launches of 10-15 us for 3.6 GFLOP)
+  bool split_multi = multi && multi_split_enabled() && tiles_all < 512 && d->Cin % 4 == 0 && d->in_ld % 4 == 0 && rsp_aligned16(dx);
+  MultiSplit msp;
+  if (split_multi) {
+    long long Ms[MAX_MULTI];
+    int tl[MAX_MULTI], nc[MAX_MULTI];
+    for (int j = 0; j < nm; ++j) {
+      Ms[j] = cls[mi[j]].M;
+      tl[j] = rsp_cdiv(cls[mi[j]].M, 128) * rsp_cdiv(d->Cin, bn);
+      nc[j] = rsp_cdiv(cls[mi[j]].K, BK);
+    }
+    msp = plan_multi_split(nm, Ms, tl, nc, d->Cin);
+    if (msp.bytes > part_bytes || (msp.bytes && !part)) split_multi = false;
+  }
+  if (multi && ((tiles_all >= 512 && tiles_all <= 4096) || split_multi)) {
     const float* zero_page = igemm_zero_page();
     if (!zero_page) {
       rsp_set_error("hipGetSymbolAddress(g_zero) failed");
@@ -2331,9 +2690,13 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
     }
     IgemmMulti m;
     memset(&m, 0, sizeof m);
-    m.n = ncls;
-    for (int i = 0; i < ncls; ++i) {
-      IgemmParams& p = cls[i];
+    m.n = nm;
+    int multi_taps = 0;
+    for (int j = 0; j < nm; ++j) {
+      IgemmParams& p = cls[mi[j]];
+      in_multi[mi[j]] = true;
+      const int taps = p.nTd * p.nTh * p.nTw;
+      multi_taps = multi_taps > taps ? multi_taps : taps;
       p.zero = zero_page;
       p.stat_ld = p.Cout;
       p.nchunks = rsp_cdiv(p.K, BK);
@@ -2345,18 +2708,45 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
       p.nbuf = 2;
       p.chunks_per_split = p.nchunks;
       p.tail_row0 = p.m_tiles * 128;
-      m.p[i] = p;
-      m.start[i + 1] = m.start[i] + p.full_tiles;
+      int units = p.full_tiles;
+      if (split_multi && msp.S[j] > 1) {      // every tile of this class is a "tail" tile cut into S slices (igemm_body)
+        p.full_tiles = 0;
+        p.splitk = msp.S[j];
+        p.chunks_per_split = msp.cps[j];
+        p.tail_row0 = 0;
+        p.partial = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(part) + msp.off[j]);
+        units = p.m_tiles * p.n_tiles * p.splitk;
+      }
+      m.p[j] = p;
+      m.start[j + 1] = m.start[j] + units;
     }
+    int rc;
     switch (bn) {
-      case 160: return launch_multi_cfg<128, 160, 4, 1, 4>(m, max_taps, s);
-      case 128: return launch_multi_cfg<128, 128, 2, 2, 4>(m, max_taps, s);
-      case 96: return launch_multi_cfg<128, 96, 4, 1, 4>(m, max_taps, s);
-      case 64: return launch_multi_cfg<128, 64, 2, 2, 4>(m, max_taps, s);
-      default: return launch_multi_cfg<128, 32, 4, 1, 4>(m, max_taps, s);
+      case 160: rc = launch_multi_cfg<128, 160, 4, 1, 4>(m, multi_taps, s); break;
+      case 128: rc = launch_multi_cfg<128, 128, 2, 2, 4>(m, multi_taps, s); break;
+      case 96: rc = launch_multi_cfg<128, 96, 4, 1, 4>(m, multi_taps, s); break;
+      case 64: rc = launch_multi_cfg<128, 64, 2, 2, 4>(m, multi_taps, s); break;
+      default: rc = launch_multi_cfg<128, 32, 4, 1, 4>(m, multi_taps, s); break;
+    }
+    if (rc != RSP_OK) return rc;
+    if (split_multi && msp.bytes != 0) {
+      ReduceMulti rm;
+      memset(&rm, 0, sizeof rm);
+      rm.n = nm;
+      int max_mt = 1;
+      for (int j = 0; j < nm; ++j) {
+        fill_reduce(rm.r[j], m.p[j]);
+        if (m.p[j].splitk > 1 && m.p[j].m_tiles > max_mt) max_mt = m.p[j].m_tiles;
+      }
+      hipLaunchKernelGGL(splitk_reduce_vec_multi_kernel, dim3(max_mt, rsp_cdiv(d->Cin, 64), nm), dim3(256), 0, s, rm);
+      rc = rsp_check_launch("splitk_reduce_vec_multi_kernel");
+      if (rc != RSP_OK) return rc;
     }
   }
+  (void)max_taps;
+  // the rest one by one (same stream: the workspace is free again when each starts)
   for (int i = 0; i < ncls; ++i) {
+    if (in_multi[i]) continue;
     int rc = run_igemm(cls[i], cvec[i], part, part_bytes, s);
     if (rc != RSP_OK) return rc;
   }

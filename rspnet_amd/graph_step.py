@@ -194,6 +194,26 @@ class GraphedPretextStep:
             m._phase_exchange(box["st"], host, wait="first")
             m._last_draw = (m._last_draw[0], host["speed"]) + tuple(host["sh"])
 
+        coll = bool(m._dp()[2])
+        if not coll:
+            # One rank, no process group: no collective points, so the main lane needs only three graphs (every graph boundary
+            # costs ~50 us on the GPU side, profiles/r05/experiments_r5.txt): top | key_kneg | everything behind the joins
+            def rest(host):
+                m._passes_join(box["st"])
+                m._defer_backward = False
+                tail(host)
+                update(host)
+
+            yield ("g", "main", "top", top)
+            yield ("fork", "q")
+            yield ("g", "q", "query", lambda host: m._pass_query(box["st"]))
+            yield ("fork", "k")
+            yield ("g", "k", "key_k", lambda host: m._pass_key(box["st"], 1))
+            yield ("g", "main", "key_kneg", lambda host: m._pass_key(box["st"], 0))
+            yield ("join", "k")
+            yield ("join", "q")
+            yield ("g", "main", "tail+update", rest)
+            return
         yield ("g", "main", "top", top)
         yield ("fork", "q")
         yield ("g", "q", "query", lambda host: m._pass_query(box["st"]))
@@ -210,8 +230,8 @@ class GraphedPretextStep:
         # the encoder's backward: pieces of the node chain on the main lane; the weight gradients a piece set aside
         # (engine.BranchStreams.deferred) as one graph on the "w" lane, beside the next piece; a gradient bucket whose last
         # parameter has been issued is all-reduced from the "w" lane's stream — behind everything that writes into it
-        coll = bool(m._dp()[2])
-        buckets = m._flat.buckets(BUCKET_FLOATS) if coll else []
+        # (buckets of 64 MiB here: each one ends a graph, and an extra graph costs about what 10 MB of all-reduce do)
+        buckets = m._flat.buckets(2 * BUCKET_FLOATS)
         bw = {"it": None, "done": False, "tasks": [], "keep": [], "handed": set(), "launched": set(), "handles": []}
         box["backward"] = bw
 
@@ -224,7 +244,10 @@ class GraphedPretextStep:
                 for handed in bw["it"]:
                     bw["handed"] = handed
                     n += 1
-                    ready = any(bi not in bw["launched"] and all(pid in handed for pid in ids) for bi, (_, _, ids) in enumerate(buckets))
+                    done_now = [all(pid in handed for pid in ids) for _, _, ids in buckets]
+                    # (a cut where a bucket has just completed — unless every bucket has: what is left then is the end of the
+                    #  chain, and the flush behind the loop takes the rest)
+                    ready = not all(done_now) and any(d and bi not in bw["launched"] for bi, d in enumerate(done_now))
                     if ready or (self.BACKWARD_PIECE > 0 and n >= self.BACKWARD_PIECE and bw["tasks"]):
                         return
                 bw["done"] = True

@@ -37,12 +37,12 @@ def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
     K, steps = 64, 6
     clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(10 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
     results = []
-    for mode in ("eager", "graph"):
+    for how in ("eager", "graph"):
         torch.manual_seed(7)
         torch.cuda.manual_seed(7)
         random.seed(7)
         wrapped, crit, opt = _build(arch, K)
-        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2, issue="graph") if mode == "graph" else None
+        stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2, issue="graph") if how == "graph" else None
         trace = []
         for im_q, im_k in clips:
             if stepper is None:
@@ -59,7 +59,7 @@ def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
             assert not stepper.disabled and stepper.mode == mode, stepper.fallback_reason
             assert len(stepper.graphs) == 1                      # warm-up steps ran eagerly, the rest replayed one captured schedule
             seq = next(iter(stepper.graphs.values()))[3]
-            assert sum(1 for op in seq if op[0] == "g") == (7 if mode == "lanes" else 1)
+            assert sum(1 for op in seq if op[0] == "g") == (5 if mode == "lanes" else 1)      # (one rank: no collective points to cut at)
         results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
     (te, se), (tg, sg) = results
     for i, ((l0, o0, r0), (l1, o1, r1)) in enumerate(zip(te, tg)):

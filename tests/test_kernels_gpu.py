@@ -82,6 +82,12 @@ CONV_CASES = [
     # wgrad output-channel segments on the 32-wide tile
     (1, 3, 20, 20, 8, 20, (1, 3, 3), (1, 1, 1), (0, 1, 1)),        # 20 channels: one 32-wide tile
     (1, 3, 20, 20, 16, 272, (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # 272 = 256 + 16; K = 16 (64-wide k tile: the 16 ride on the 64-row tile)
+    # small launches with Cin % 16 == 0 run on igemm_direct_kernel (operands straight from L2, no LDS tiles): most of the small cases
+    # above — 1x1x1 stride 2, strided parity classes, slice-major K with a K split, 16 / 150 / 576 columns — plus half-chunks that
+    # straddle taps (Cin = 112, 208: not multiples of 32) and a K that ends inside a chunk (208 = 6.5 chunks)
+    (2, 4, 14, 14, 208, 160, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    (2, 4, 14, 14, 112, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (3, 4, 7, 7, 48, 72, (3, 3, 3), (2, 2, 2), (1, 1, 1)),         # Cin = 48, 72 columns (64 + 8), strided: dgrad classes with K = 72 * taps
     # 4-channel (zero-padded RGB) stems: direct LDS-halo kernel (conv_stem.hip)
     (2, 4, 12, 12, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # C3D conv1: all 3 time-slices resident, 14-tap chunks
     (2, 5, 18, 20, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),        # R3D stem: ring of 3 time-slices, stride 2 de-interleave
@@ -537,7 +543,10 @@ NAME_CASES = [
     (32, 16, 56, 56, 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     (16, 16, 224, 224, 4, 64, (1, 7, 7), (2, 2, 2), (0, 3, 3)),       # S3D-G stem (streaming stem kernel)
     (16, 8, 28, 28, 192, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # 96-wide tile
-    (16, 4, 14, 14, 160, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # dgrad N = 160
+    (16, 4, 14, 14, 160, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # dgrad N = 160 (98 x 3 tiles: the direct kernel)
+    (32, 8, 28, 28, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),        # R3D-18 layer2.0 shortcut: direct kernel
+    (16, 4, 14, 14, 480, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # S3D-G 14 x 14 pointwise trio: direct kernel
+    (16, 8, 28, 28, 192, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # ... at 28 x 28: 784 x 2 tiles, the tile kernels
 ]
 
 
@@ -769,3 +778,20 @@ def test_bn_act_gate_bwd_fused_matches_the_two_ops(hip, N, D, H, W, C, sliced):
                               dwc, dbc)
     for name, got, ref in (("dy", dy, dyc), ("dw", dw, dwc), ("dgamma", dg, dgc), ("dbeta", dbt, dbtc)):
         close(got, ref, 5e-5, name + " vs checker")
+
+
+def test_conv_cases_also_pass_on_the_tile_kernels():
+    """Small launches with Cin % 16 == 0 take igemm_direct_kernel by default, which covers most of the small geometries above; the
+    LDS-DMA tile kernels must keep passing them too (they run every large launch): the same cases in a child interpreter with
+    RSP_NO_DIRECT=1 (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RSP_NO_DIRECT"):
+        pytest.skip("already the tile-kernel run")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, RSP_NO_DIRECT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "conv_fwd_dgrad_wgrad or conv_fuzz or deterministic or reported_kernel_name"], capture_output=True, text=True,
+                       timeout=1800, env=env, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -89,8 +89,12 @@ def test_rccl_one_rank_segmented_replay_equals_the_eager_dp_step(arch, B, HW, mo
         with open(out) as f:
             rep = json.load(f)
     print("\n", arch, rep)
-    assert rep["collective_points"] == 3
-    assert (rep["graphs"], rep["lanes"]) == ((7, ["k", "main", "q"]) if mode == "lanes" else (4, ["main"]))
+    if mode == "lanes":
+        # top | query | key_k | key_kneg | keys_join | tail | backward pieces (one per 64 MiB gradient bucket) | update; the collective
+        # slots: all-to-all (+ its wait on the k lane), all-gather, one all-reduce per bucket, the wait for them
+        assert rep["lanes"] in (["k", "main", "q"], ["k", "main", "q", "w"]) and rep["graphs"] >= 8 and rep["collective_points"] >= 5, rep
+    else:
+        assert (rep["graphs"], rep["lanes"], rep["collective_points"]) == (4, ["main"], 3), rep
     # every step of either loop issues its 2 clip all-to-alls and its 1 key all-gather
     for m in ("eager", "segments"):
         assert rep[m]["all_to_all_single"] == 2 * 7 and rep[m]["all_gather_into_tensor"] == 7 and rep[m]["all_reduce"] >= 7
