@@ -319,6 +319,13 @@ int rsp_queue_enqueue_dev(float* queue, int32_t dim, int32_t K, int64_t* ptr_dev
  * C_out >= C, extra channels zero (C_out = 4 lets a 3-channel stem convolution use 16-byte gathers). */
 int rsp_clip_gather(const float* im, int32_t B_in, int32_t C, int32_t T_in, int32_t H, int32_t W, const int32_t* src,
                     const int32_t* step, int32_t B_out, int32_t T_out, int32_t C_out, float* out, void* stream);
+/* The step's gathers in ONE launch: n_jobs (<= 4) gathers of identical geometry — the k_negative clips, the k clips (both in the
+ * send order of their shuffle-BN exchange, :361-387) and the query clips (:421-447) — each with its own source batch, index and
+ * speed vectors and output.  A launch that moves 0.5 GB streams at HBM rate; three launches of 0.18 GB each spend a fifth of their
+ * 48 us on ramp-up and tail. */
+int rsp_clip_gather_multi(int32_t n_jobs, const float* const* ims, const int32_t* const* srcs, const int32_t* const* steps,
+                          float* const* outs, int32_t B_in, int32_t C, int32_t T_in, int32_t H, int32_t W, int32_t B_out, int32_t T_out,
+                          int32_t C_out, void* stream);
 
 /* _momentum_update_key_encoder (:337-343) on flat parameter buffers: k = k*m + q*(1-m). */
 int rsp_momentum_update(float* k, const float* q, int64_t n, float m, void* stream);

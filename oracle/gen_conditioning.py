@@ -1,6 +1,6 @@
 """How well-conditioned are the fixtures' gradients?  TEST INFRASTRUCTURE ONLY.
 
-``python -m oracle.gen_conditioning [arch ...]`` runs the oracle restatement of every single-rank fixture case three times
+``python -m oracle.gen_conditioning [arch | arch@ws2 ...]`` runs the oracle restatement of every fixture case (multi-rank ones under the key `arch@wsN`) three times
 on the same inputs with the same code — fp32 as the reference does (oneDNN convolutions, fused batch_norm), fp64, fp32 with
 oneDNN switched off (ATen's native convolution) and fp32 with BatchNorm evaluated in its folded scale/shift form (what a fused
 conv+BN kernel computes): the same function in other summation / evaluation orders, which is all that separates any two
@@ -35,16 +35,17 @@ from oracle import restatement as S     # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def measure(tag, seed, meta=None, spec=None, fast=False):
-    """fast=True: skip the fp64 variant (gen_golden's seed screen)."""
+def measure(tag, seed, meta=None, spec=None, fast=False, ws=1):
+    """fast=True: skip the fp64 variant (gen_golden's seed screen).  ws > 1: a multi-rank fixture — the same variants over `ws`
+    simulated ranks, distances of the DDP-averaged gradients (the checker variant is single-rank only)."""
     if spec is None:
         with open(os.path.join(GOLDEN, f"state_spec_{G.tag_file(tag)}.json")) as f:
             spec = {k: (tuple(s), d) for k, (s, d) in json.load(f).items()}
     z = None
     if meta is None:
-        z = np.load(os.path.join(GOLDEN, G.case_name(tag, 1, seed) + ".npz"))
+        z = np.load(os.path.join(GOLDEN, G.case_name(tag, ws, seed) + ".npz"))
         meta = json.loads(str(z["meta"]))
-    state, mom, clips, perms_B, sh = G.case_inputs(spec, tag, meta["B"], meta["HW"], meta["K"], 1, seed)
+    state, mom, clips, perms_B, sh = G.case_inputs(spec, tag, meta["B"], meta["HW"], meta["K"], ws, seed)
 
     import contextlib
 
@@ -58,10 +59,13 @@ def measure(tag, seed, meta=None, spec=None, fast=False):
 
     def _run_once(dt):
         if True:
-            st = {k: (torch.from_numpy(v.copy()).to(dt) if v.dtype == np.float32 else torch.from_numpy(v.copy())) for k, v in state.items()}
-            return S.moco_step(meta["arch"], [st], [torch.from_numpy(clips[0][0]).to(dt)], [torch.from_numpy(clips[0][1]).to(dt)],
-                               [torch.from_numpy(perms_B[0])], (torch.from_numpy(sh[0]), torch.from_numpy(sh[1])), meta["speed"],
-                               K=meta["K"], lr=meta["lr"], fc_type=meta.get("fc_type", "linear"), momentum_buffers=[{}])[0]
+            sts = [{k: (torch.from_numpy(v.copy()).to(dt) if v.dtype == np.float32 else torch.from_numpy(v.copy())) for k, v in state.items()}
+                   for _ in range(ws)]
+            return S.moco_step(meta["arch"], sts, [torch.from_numpy(clips[r][0]).to(dt) for r in range(ws)],
+                               [torch.from_numpy(clips[r][1]).to(dt) for r in range(ws)],
+                               [torch.from_numpy(perms_B[r]) for r in range(ws)], (torch.from_numpy(sh[0]), torch.from_numpy(sh[1])),
+                               meta["speed"], K=meta["K"], lr=meta["lr"], fc_type=meta.get("fc_type", "linear"),
+                               momentum_buffers=[{} for _ in range(ws)])[0]
 
     o32 = run(torch.float32)
     out = {}
@@ -78,7 +82,7 @@ def measure(tag, seed, meta=None, spec=None, fast=False):
         out[f"grad_rel_l2_max_{tag_v}"] = max(errs)
         out[f"grad_rel_l2_median_{tag_v}"] = float(np.median(errs))
         out[f"logits_rel_{tag_v}"] = float((other["logits1"].double() - o32["logits1"].double()).abs().max() / o32["logits1"].abs().max())
-    if z is not None and "r0.gradproj." + next(k for k, g in o32["grads"].items() if g is not None) in z.files:
+    if ws == 1 and z is not None and "r0.gradproj." + next(k for k, g in o32["grads"].items() if g is not None) in z.files:
         # fourth evaluation order: the product's host logic on the torch checker backend (channels-last convolutions, folded
         # BatchNorm, fused sibling GEMMs) against the reference's own gradients stored in the fixture (sketch estimate)
         out["grad_rel_l2_max_checker"] = G.checker_grad_error(tag, meta, spec, z)
@@ -92,15 +96,19 @@ def main():
     out = json.load(open(path)) if (only and os.path.exists(path)) else {}      # a full run starts from scratch
     for tag in only:
         out.pop(tag, None)
+        if "@" not in tag:
+            for k in [k for k in out if k.startswith(tag + "@ws")]:
+                out.pop(k)
     with open(os.path.join(GOLDEN, "index.json")) as f:
         index = json.load(f)
     for tag, ws, seed in index:
-        if ws != 1 or (only and tag not in only):
+        key = tag if ws == 1 else f"{tag}@ws{ws}"        # multi-rank fixtures have floors of their own (tests/golden_util.py:grad_tol)
+        if only and tag not in only and key not in only:
             continue
-        m = measure(tag, seed)
-        prev = out.get(tag)
-        out[tag] = m if prev is None else {k: max(m[k], prev.get(k, 0.0)) for k in m}       # worst over the arch's seeds
-        print(tag, seed, m, flush=True)
+        m = measure(tag, seed, ws=ws)
+        prev = out.get(key)
+        out[key] = m if prev is None else {k: max(m[k], prev.get(k, 0.0)) for k in m}       # worst over the arch's seeds
+        print(key, seed, m, flush=True)
         with open(path, "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
 

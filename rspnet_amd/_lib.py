@@ -127,6 +127,7 @@ SIGNATURES = {
     "rsp_queue_enqueue": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
     "rsp_queue_enqueue_dev": (C.c_int, [_p, _i32, _i32, _p, _p, _i32, _p]),
     "rsp_clip_gather": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _p]),
+    "rsp_clip_gather_multi": (C.c_int, [_i32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "rsp_momentum_update": (C.c_int, [_p, _p, _i64, _f, _p]),
     "rsp_sgd_step": (C.c_int, [_p, _p, _p, _i64, _f, _f, _f, _f, C.c_int, _p]),
     "rsp_rows_gather": (C.c_int, [_p, _p, _i32, _i32, _p, _p]),

@@ -61,6 +61,47 @@ __global__ __launch_bounds__(256) void clip_gather_rgb4_kernel(const float* __re
   }
 }
 
+// ... the same for up to four gathers of one geometry in one launch (blockIdx.y picks the job)
+struct GatherJobs {
+  const float* im[4];
+  const int* src[4];
+  const int* step[4];
+  float* out[4];
+};
+__global__ __launch_bounds__(256) void clip_gather_rgb4_multi_kernel(const GatherJobs jobs, int T_in, int hw4, int chunks, int T_out) {
+  const int jb = blockIdx.y;
+  const float* __restrict__ im = jobs.im[jb];
+  const int* __restrict__ src = jobs.src[jb];
+  const int* __restrict__ step = jobs.step[jb];
+  float* __restrict__ out = jobs.out[jb];
+  const long long plane4 = (long long)T_in * hw4;
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int j = row / T_out, t = row - j * T_out;
+  const floatx4* s = reinterpret_cast<const floatx4*>(im) + ((long long)src[j] * 3 * T_in + (long long)t * step[j]) * hw4;
+  floatx4* o = reinterpret_cast<floatx4*>(out) + (long long)row * hw4 * 4;
+  const int q0 = chunk * 512 + threadIdx.x, q1 = q0 + 256;
+  floatx4 v[2][3];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = u ? q1 : q0;
+    if (q < hw4) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[u][c] = __builtin_nontemporal_load(s + c * plane4 + q);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = u ? q1 : q0;
+    if (q < hw4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const floatx4 px = {v[u][0][e], v[u][1][e], v[u][2][e], 0.f};
+        o[(long long)q * 4 + e] = px;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ k, const float* __restrict__ q, long long n,
                                                        float m) {
   const float om = 1.f - m;
@@ -170,6 +211,34 @@ int rsp_clip_gather(const float* im, int32_t B_in, int32_t C, int32_t T_in, int3
   hipLaunchKernelGGL(clip_gather_kernel, dim3(grid_for(total) * 2), dim3(256), 0, (hipStream_t)stream, im, C, T_in, H, W, src,
                      step, B_out, T_out, C_out, out);
   return rsp_check_launch("clip_gather_kernel");
+}
+
+int rsp_clip_gather_multi(int32_t n_jobs, const float* const* ims, const int32_t* const* srcs, const int32_t* const* steps,
+                          float* const* outs, int32_t B_in, int32_t C, int32_t T_in, int32_t H, int32_t W, int32_t B_out, int32_t T_out,
+                          int32_t C_out, void* stream) {
+  RSP_REQUIRE(n_jobs >= 1 && n_jobs <= 4 && ims && srcs && steps && outs, "rsp_clip_gather_multi: bad argument");
+  bool fast = C == 3 && C_out == 4 && ((long long)H * W) % 4 == 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    RSP_REQUIRE(ims[i] && srcs[i] && steps[i] && outs[i], "rsp_clip_gather_multi: null pointer");
+    fast = fast && rsp_aligned16(ims[i]) && rsp_aligned16(outs[i]);
+  }
+  const int hw4 = (int)(((long long)H * W) / 4), chunks = (hw4 + 511) / 512;
+  const long long grid = (long long)B_out * T_out * chunks;
+  if (fast && grid < (1ll << 31) && B_in > 0 && T_in > 0 && B_out > 0 && T_out > 0) {
+    GatherJobs j;
+    memset(&j, 0, sizeof j);
+    for (int i = 0; i < n_jobs; ++i) {
+      j.im[i] = ims[i]; j.src[i] = srcs[i]; j.step[i] = steps[i]; j.out[i] = outs[i];
+    }
+    hipLaunchKernelGGL(clip_gather_rgb4_multi_kernel, dim3((unsigned)grid, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, j, T_in,
+                       hw4, chunks, T_out);
+    return rsp_check_launch("clip_gather_rgb4_multi_kernel");
+  }
+  for (int i = 0; i < n_jobs; ++i) {
+    const int rc = rsp_clip_gather(ims[i], B_in, C, T_in, H, W, srcs[i], steps[i], B_out, T_out, C_out, outs[i], stream);
+    if (rc != RSP_OK) return rc;
+  }
+  return RSP_OK;
 }
 
 int rsp_momentum_update(float* k, const float* q, int64_t n, float m, void* stream) {

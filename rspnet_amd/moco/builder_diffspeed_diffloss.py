@@ -631,10 +631,9 @@ class MoCoDiffLossTwoFc(nn.Module):
             src1, loc1, src2, loc2 = host["idx"]
             cpad = max(C, INPUT_CHANNEL_PAD)
             # the key passes keep the reference's order (k_negative first, :445, then k, :512)
-            xs_neg = be.clip_gather(im_k, src1, step_kn[src1.long()].contiguous(), T_real, cpad)
-            xs_k = be.clip_gather(im_k, src2, step_q[src2.long()].contiguous(), T_real, cpad)
             src = torch.arange(B, dtype=torch.int32, device=dev)
-            x_q = be.clip_gather(im_q, src, step_q, T_real, cpad)
+            xs_neg, xs_k, x_q = be.clip_gather_multi([(im_k, src1, step_kn[src1.long()].contiguous()),
+                                                      (im_k, src2, step_q[src2.long()].contiguous()), (im_q, src, step_q)], T_real, cpad)
             self._nbt_q += 1
             self._nbt_k += 2
             self.encoder_k._packed.refresh_now()      # (re-pack of the momentum-updated weights: before the passes fork)

@@ -666,6 +666,30 @@ class HipOps:
         self._log_hbm("clip_gather", 4 * (B_out * T_out * H * W * Cc + out.numel()), e0)
         return out
 
+    def clip_gather_multi(self, jobs, T_out: int, c_out: Optional[int] = None):
+        """jobs: [(im, src, step)] of ONE geometry (same clip shape, same number of output clips) -> their gathered clips, from one
+        launch (rsp_clip_gather_multi)."""
+        im0, src0, _ = jobs[0]
+        B_in, Cc, T_in, H, W = im0.shape
+        B_out = src0.shape[0]
+        c_out = c_out or Cc
+        outs = []
+        for im, src, step in jobs:
+            _chk(im, "im")
+            _chk(src, "src", torch.int32)
+            _chk(step, "step", torch.int32)
+            if tuple(im.shape) != tuple(im0.shape) or src.shape[0] != B_out or step.shape[0] != B_out:
+                raise _lib.RspError("clip_gather_multi: the jobs must share one geometry")
+            outs.append(torch.empty((B_out, T_out, H, W, c_out), dtype=torch.float32, device=im.device))
+        n = len(jobs)
+        arr = C.c_void_p * n
+        e0 = self._ev()
+        _lib.check(self.lib.rsp_clip_gather_multi(n, arr(*[j[0].data_ptr() for j in jobs]), arr(*[j[1].data_ptr() for j in jobs]),
+                                                  arr(*[j[2].data_ptr() for j in jobs]), arr(*[o.data_ptr() for o in outs]), B_in, Cc,
+                                                  T_in, H, W, B_out, T_out, c_out, _stream()), "rsp_clip_gather_multi")
+        self._log_hbm("clip_gather", 4 * n * (B_out * T_out * H * W * Cc + outs[0].numel()), e0)
+        return outs
+
     def momentum_update(self, k_flat, q_flat, m: float):
         e0 = self._ev()
         _lib.check(self.lib.rsp_momentum_update(_ptr(_chk(k_flat, "k")), _ptr(_chk(q_flat, "q")), k_flat.numel(), m,

@@ -282,6 +282,9 @@ class CpuOps:
             out[j][..., :im.shape[1]] = frames.permute(1, 2, 3, 0)
         return out
 
+    def clip_gather_multi(self, jobs, T_out, c_out=None):
+        return [self.clip_gather(im, src, step, T_out, c_out) for im, src, step in jobs]
+
     def momentum_update(self, k_flat, q_flat, m):
         k_flat.copy_(k_flat * m + q_flat * (1.0 - m))
 

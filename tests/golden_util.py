@@ -26,18 +26,25 @@ def cases_for(arch, ws=None):
 # correct fp32 implementations whose activations differ by a relative delta decide ~delta of the masks / arg-maxes
 # differently, each flip changing its gradient contribution by O(1) -> a whole-gradient distance ~sqrt(delta), independent
 # of the fixture size.  tests/golden/conditioning.json (oracle/gen_conditioning.py) holds that floor per fixture family,
-# measured as the oracle restatement in fp32 vs fp64 on the fixture's own inputs: ~3e-6 for the knife-edge-guarded C3D /
-# R3D / R(2+1)D fixtures (no flip at all), 1e-2 for S3D-G, 3e-2 for the Bottleneck ResNet-50 (deep stacks, forward
-# delta ~3e-5).  The gate is 2e-2 or 3x the measured floor, whichever is larger.  The exact check of the backward
-# composition, unit by unit at 2e-5, is the teacher-forced replay (tests/test_teacher_forced_gpu.py).
-GRAD_TOL = 2e-2
+# measured as the distance of the oracle restatement in fp32 from fp64 (and from two other fp32 evaluation orders) on the
+# fixture's own inputs: 2e-5 for the guarded head variants, 1.8-3.9e-3 for C3D / R3D-18 / R(2+1)D (a fixture with ONE flip sits
+# there), 1.7e-2 for S3D-G, 3.5e-2 for ResNet-34 / -50 (deep stacks, forward delta ~3e-5).
+# The gate is THREE floors per family, never below 1e-3 (round 5; a flat 2e-2 until then: a backward bug of 1-2 % on one small
+# tensor passed every whole-step gate of the first three families) -> C3D 6.3e-3, R3D-18 8.1e-3, R(2+1)D 5.4e-3, the guarded
+# C3D head variants 1e-3.  Measured on the HIP path (tools/grad_report.py, profiles/r05): 1e-5 ... 2.3e-3 on those families.
+# The exact check of the backward composition, unit by unit at 2e-5, is the teacher-forced replay
+# (tests/test_teacher_forced_gpu.py).
+GRAD_TOL_MIN = 1e-3
 with open(os.path.join(GOLDEN, "conditioning.json")) as _f:
     CONDITIONING = json.load(_f)
 FWD_TOL_BY_ARCH = {"s3dg": 1e-3}
 
 
-def grad_tol(arch):
-    return max(GRAD_TOL, 3.0 * CONDITIONING.get(arch, {}).get("grad_rel_l2_max", 0.0))
+def grad_tol(arch, ws=1):
+    """ws > 1: the multi-rank fixtures of the family have floors of their own (`arch@wsN` in conditioning.json: other clips, other
+    permutations — another state)."""
+    floor = CONDITIONING.get(arch if ws == 1 else f"{arch}@ws{ws}", CONDITIONING.get(arch, {})).get("grad_rel_l2_max", 0.0)
+    return max(GRAD_TOL_MIN, 3.0 * floor)
 
 
 def fwd_tol(arch, default):

