@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void clip_gather_kernel(const float* __restric
 // — and a thread turns two groups of FOUR consecutive pixels: six 16-byte plane loads issued up front, then eight 16-byte pixels
 // (2 x 64 contiguous bytes) out; a wave writes 4 KB contiguous per group.  (The general kernel stores 4 bytes per lane at a 16-byte
 // stride, four times: 3.4 TB/s of algorithmic bytes; r4 VERDICT item 7.)
-__global__ __launch_bounds__(256) void clip_gather_rgb4_kernel(const float* __restrict__ im, int T_in, int hw4, int chunks,
+__global__ __launch_bounds__(256) void clip_gather_rgb4_kernel(const float* __restrict__ im, int T_in, int hw4, int chunks, int cw,
                                                                const int* __restrict__ src, const int* __restrict__ step,
                                                                int T_out, float* __restrict__ out) {
   const long long plane4 = (long long)T_in * hw4;      // one channel of one clip, in float4 units
@@ -38,12 +38,13 @@ __global__ __launch_bounds__(256) void clip_gather_rgb4_kernel(const float* __re
   const int j = row / T_out, t = row - j * T_out;
   const floatx4* s = reinterpret_cast<const floatx4*>(im) + ((long long)src[j] * 3 * T_in + (long long)t * step[j]) * hw4;
   floatx4* o = reinterpret_cast<floatx4*>(out) + (long long)row * hw4 * 4;
-  const int q0 = chunk * 512 + threadIdx.x, q1 = q0 + 256;
+  // (cw <= 512 columns per workgroup, equal shares of the row: 112 x 112 = 7 x 448, no nearly empty last workgroup)
+  const int q0 = chunk * cw + threadIdx.x, q1 = q0 + 256, qe = min(hw4, (chunk + 1) * cw);
   floatx4 v[2][3];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int q = u ? q1 : q0;
-    if (q < hw4) {
+    if (q < qe) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[u][c] = __builtin_nontemporal_load(s + c * plane4 + q);
     }
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void clip_gather_rgb4_kernel(const float* __re
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int q = u ? q1 : q0;
-    if (q < hw4) {
+    if (q < qe) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const floatx4 px = {v[u][0][e], v[u][1][e], v[u][2][e], 0.f};
@@ -68,7 +69,7 @@ struct GatherJobs {
   const int* step[4];
   float* out[4];
 };
-__global__ __launch_bounds__(256) void clip_gather_rgb4_multi_kernel(const GatherJobs jobs, int T_in, int hw4, int chunks, int T_out) {
+__global__ __launch_bounds__(256) void clip_gather_rgb4_multi_kernel(const GatherJobs jobs, int T_in, int hw4, int chunks, int cw, int T_out) {
   const int jb = blockIdx.y;
   const float* __restrict__ im = jobs.im[jb];
   const int* __restrict__ src = jobs.src[jb];
@@ -79,12 +80,13 @@ __global__ __launch_bounds__(256) void clip_gather_rgb4_multi_kernel(const Gathe
   const int j = row / T_out, t = row - j * T_out;
   const floatx4* s = reinterpret_cast<const floatx4*>(im) + ((long long)src[j] * 3 * T_in + (long long)t * step[j]) * hw4;
   floatx4* o = reinterpret_cast<floatx4*>(out) + (long long)row * hw4 * 4;
-  const int q0 = chunk * 512 + threadIdx.x, q1 = q0 + 256;
+  // (cw <= 512 columns per workgroup, equal shares of the row: 112 x 112 = 7 x 448, no nearly empty last workgroup)
+  const int q0 = chunk * cw + threadIdx.x, q1 = q0 + 256, qe = min(hw4, (chunk + 1) * cw);
   floatx4 v[2][3];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int q = u ? q1 : q0;
-    if (q < hw4) {
+    if (q < qe) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[u][c] = __builtin_nontemporal_load(s + c * plane4 + q);
     }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void clip_gather_rgb4_multi_kernel(const Gathe
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int q = u ? q1 : q0;
-    if (q < hw4) {
+    if (q < qe) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const floatx4 px = {v[u][0][e], v[u][1][e], v[u][2][e], 0.f};
@@ -200,10 +202,10 @@ int rsp_clip_gather(const float* im, int32_t B_in, int32_t C, int32_t T_in, int3
               "rsp_clip_gather: bad size");
   const long long total = (long long)B_out * T_out * H * W;
   if (C == 3 && C_out == 4 && ((long long)H * W) % 4 == 0 && rsp_aligned16(im) && rsp_aligned16(out)) {
-    const int hw4 = (int)(((long long)H * W) / 4), chunks = (hw4 + 511) / 512;
+    const int hw4 = (int)(((long long)H * W) / 4), chunks = (hw4 + 511) / 512, cw = ((hw4 + chunks - 1) / chunks + 63) / 64 * 64;
     const long long grid = (long long)B_out * T_out * chunks;
     if (grid < (1ll << 31)) {
-      hipLaunchKernelGGL(clip_gather_rgb4_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, im, T_in, hw4, chunks, src,
+      hipLaunchKernelGGL(clip_gather_rgb4_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, im, T_in, hw4, chunks, cw, src,
                          step, T_out, out);
       return rsp_check_launch("clip_gather_rgb4_kernel");
     }
@@ -222,7 +224,7 @@ int rsp_clip_gather_multi(int32_t n_jobs, const float* const* ims, const int32_t
     RSP_REQUIRE(ims[i] && srcs[i] && steps[i] && outs[i], "rsp_clip_gather_multi: null pointer");
     fast = fast && rsp_aligned16(ims[i]) && rsp_aligned16(outs[i]);
   }
-  const int hw4 = (int)(((long long)H * W) / 4), chunks = (hw4 + 511) / 512;
+  const int hw4 = (int)(((long long)H * W) / 4), chunks = (hw4 + 511) / 512, cw = ((hw4 + chunks - 1) / chunks + 63) / 64 * 64;
   const long long grid = (long long)B_out * T_out * chunks;
   if (fast && grid < (1ll << 31) && B_in > 0 && T_in > 0 && B_out > 0 && T_out > 0) {
     GatherJobs j;
@@ -231,7 +233,7 @@ int rsp_clip_gather_multi(int32_t n_jobs, const float* const* ims, const int32_t
       j.im[i] = ims[i]; j.src[i] = srcs[i]; j.step[i] = steps[i]; j.out[i] = outs[i];
     }
     hipLaunchKernelGGL(clip_gather_rgb4_multi_kernel, dim3((unsigned)grid, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, j, T_in,
-                       hw4, chunks, T_out);
+                       hw4, chunks, cw, T_out);
     return rsp_check_launch("clip_gather_rgb4_multi_kernel");
   }
   for (int i = 0; i < n_jobs; ++i) {

@@ -158,9 +158,10 @@ class Engine:
         sums = torch.zeros(4, device=self.device)
         n = 0
         t0 = time.perf_counter()
-        if self._stepper is None and not self.model.module._dp()[2] and not getattr(self.args, "no_graph", False):
-            # one rank: the five statements below run through the stepper — ONE replayed HIP graph per (speed, learning rate) where the
-            # host cannot issue the step fast enough, the eager loop with its side streams otherwise (rspnet_amd/graph_step.py)
+        if self._stepper is None and self.device.type == "cuda" and not getattr(self.args, "no_graph", False):
+            # the five statements below run through the stepper — replayed as linear HIP graphs on three streams, with the
+            # data-parallel collectives between them at more than one rank, where the host cannot issue the step fast enough; the
+            # eager loop with its side streams otherwise (rspnet_amd/graph_step.py)
             from .graph_step import GraphedPretextStep
             self._stepper = GraphedPretextStep(self.model, self.criterion, self.optimizer)
         for it, (clip_q, clip_k) in enumerate(self.train_loader):
@@ -335,7 +336,7 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-scale-lr", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=100, help="synthetic loader length")
-    ap.add_argument("--no-graph", action="store_true", help="one rank: never replay the step as a captured HIP graph (default: only when the host is the limiter)")
+    ap.add_argument("--no-graph", action="store_true", help="never replay the step as captured HIP graphs (default: only when the host is the limiter)")
     ap.add_argument("--loader", choices=("tensor", "uint8"), default="tensor",
                     help="tensor: fixed N(0,1) device clips; uint8: synthetic uint8 videos -> CPU random crop -> fused GPU augmentation")
     ap.add_argument("--run-dir", default=None, help="default: EXP/run_{id}_{timestamp}")

@@ -114,6 +114,11 @@ class Recorder:
         dy, _ = self.bn_act_pool_bwd(pg, y, None, dx, gamma, mean_invstd, scale_shift, relu, False, dgamma_out, dbeta_out)
         return dy
 
+    def clip_gather_multi(self, jobs, T_out, c_out=None):
+        """The step's three gathers in one launch are recorded as the single gathers they stand for; the fused device path is pinned
+        to them bit for bit by tests/test_kernels_gpu.py::test_clip_gather."""
+        return [self.clip_gather(im, src, step, T_out, c_out) for im, src, step in jobs]
+
     def __getattr__(self, name):
         fn = getattr(self.inner, name)
         if not callable(fn) or name in ("pack_signature", "bn_ema_set"):      # (host queries / set builders: nothing to replay)
