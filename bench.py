@@ -663,9 +663,13 @@ def run_rank(args):
     # GPU / process-group call, which is where those threads are created
     cpus = None
     if ws > 1 and hasattr(os, "sched_setaffinity") and not os.environ.get("RSP_NO_PIN"):
-        cpus = rank_cpu_set(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", ws)))
-        if cpus:
-            os.sched_setaffinity(0, cpus)
+        try:
+            cpus = rank_cpu_set(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", ws)))
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+        except (OSError, ValueError) as e:      # a restricted cgroup / unusual topology: run unpinned rather than not at all
+            print(f"bench.py: rank {rank}: CPU pinning skipped ({e})", file=sys.stderr)
+            cpus = None
     if cpu_selftest:
         dev = torch.device("cpu")
         torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(ws, 1) // 2))

@@ -440,6 +440,8 @@ class GraphedPretextStep:
             share = shares[len(shares) // 2]
             h_med, g_med = sorted(h for h, _ in got)[len(got) // 2], sorted(g for _, g in got)[len(got) // 2]
             bound = self.HOST_BOUND_DP if self.model._dp()[2] else self.HOST_BOUND
+            share = self._agree(share, max)      # every rank must reach the same decision: the two issue modes bucket the
+            #   gradient all-reduce differently, and ranks that disagree would wait for each other's collectives forever
             if share <= bound:
                 self.eager_keys[cfg] = (f"issued eagerly by policy: the host issues this step in {h_med:.1f} ms of the {g_med:.1f} ms it runs "
                                         f"(median of {len(got)} measured warm-up steps; a replayed graph pays off above {bound:.0%})")
@@ -448,7 +450,25 @@ class GraphedPretextStep:
                 log.info("rspnet_amd: pretext step (speed %s) %s", cfg[0], self.eager_keys[cfg])
         return out
 
+    def _agree(self, value: float, op):
+        """The same value on every rank of the data-parallel job (op = max or min over the ranks); the value itself otherwise."""
+        if not self.model._dp()[2]:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.model.queue.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op is max else dist.ReduceOp.MIN)
+        return float(t.item())
+
     def _capture(self, key, host):
+        entry = self._capture_local(key, host)
+        # a capture that failed on ONE rank (that rank would issue the eager step, with other collectives) is a failure everywhere
+        if self.model._dp()[2] and self._agree(0.0 if entry is None else 1.0, min) < 0.5 and entry is not None:
+            self.graphs.pop(key, None)
+            self.disabled, self.fallback_reason = True, "HIP-graph capture failed on another rank; all ranks issue eagerly"
+            log.warning("rspnet_amd: %s", self.fallback_reason)
+            return None
+        return entry
+
+    def _capture_local(self, key, host):
         from . import ops as _ops
         st = self.static
         be = _ops.backend()

@@ -21,8 +21,8 @@ out = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
 BATCH = {"c3d": 32, "resnet18": 32, "r2plus1d-vcop": 32, "s3dg": 16}
-PROFILED_STEPS = 6          # --steps 2 --warmup 1 in the PMC passes, + bench.py's roofline pass behind them (1 + 2 steps)
-TRACED_STEPS = 24           # --steps 10 --warmup 3 in the kernel-trace pass, + the roofline pass (1 + 10 steps)
+PROFILED_STEPS = 11         # --steps 2 --warmup 1 in the PMC passes, + bench.py's 5 idle-queue issue samples + its roofline pass (1 + 2 steps)
+TRACED_STEPS = 29           # --steps 10 --warmup 3 in the kernel-trace pass, + the 5 issue samples + the roofline pass (1 + 10 steps)
 
 
 def short(name):
