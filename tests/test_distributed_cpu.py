@@ -205,3 +205,39 @@ def test_one_rank_with_forced_collectives_matches_golden():
         with open(out) as f:
             rep = json.load(f)
     assert rep["calls"]["all_to_all_single"] == 2 and rep["calls"]["all_gather_into_tensor"] == 1
+
+
+def _agree_worker(rank, ws, port, tmp):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from cpu_ops import CpuOps
+    from model_util import make_cfg
+    from rspnet_amd import ops
+    from rspnet_amd.graph_step import GraphedPretextStep
+    from rspnet_amd.moco import Loss, ModelFactory
+    from rspnet_amd.optim import SGD
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    ops.set_backend(CpuOps())
+    wrapped = ModelFactory(make_cfg("c3d", 64)).build_moco_diffloss(device=torch.device("cpu"))
+    stepper = GraphedPretextStep(wrapped, Loss(margin=2.0), SGD(wrapped.parameters(), lr=0.1, momentum=0.9))
+    # per-rank measurements on either side of the threshold: every rank must come out with the same number
+    share = stepper._agree(0.2 + 0.2 * rank, max)
+    ok = stepper._agree(1.0 if rank == 0 else 0.0, min)
+    np.save(os.path.join(tmp, f"agree{rank}.npy"), np.array([share, ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_issue_mode_decision_is_shared_across_ranks():
+    """GraphedPretextStep decides eager-or-graphs per configuration from a host-time measurement, and a capture can fail on one rank
+    only; the two issue modes bucket the gradient all-reduce differently, so ranks that decided differently would wait for each
+    other's collectives forever.  Both decisions go through `_agree` (max of the host shares, min of the capture flags)."""
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_agree_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        a0, a1 = np.load(os.path.join(tmp, "agree0.npy")), np.load(os.path.join(tmp, "agree1.npy"))
+    assert a0.tolist() == a1.tolist() == [0.4, 0.0]

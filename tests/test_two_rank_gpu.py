@@ -18,7 +18,11 @@ from golden_util import build_inputs, cases_for, compare_to_golden, grad_tol, lo
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-GRAD_GATE = {}
+# Per-fixture exceptions to tests/golden_util.py:grad_tol (three family floors), each with its measurement.
+# resnet18, 2 ranks: ONE tensor — layer4.1.conv1.weight, a 512-row layer where a single flipped ReLU mask moves the gradient by half a
+# percent — sits at 8.8e-3 = 3.3 floors on the HIP path (r5k; every other tensor of the fixture is under 8.1e-3, every op of the
+# fixture's step agrees with the checker at 2e-5 teacher-forced: tests/test_teacher_forced_gpu.py).  Four floors for this fixture.
+GRAD_GATE = {"resnet18": 1.08e-2}
 
 
 def _run_rank(rank, ws, arch, seed, lock, tls, out, dev):
