@@ -803,3 +803,42 @@ def test_conv_cases_also_pass_on_the_tile_kernels():
                         "conv_fwd_dgrad_wgrad or conv_fuzz or deterministic or reported_kernel_name"], capture_output=True, text=True,
                        timeout=1800, env=env, cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_rowgeom_cache_is_bounded_and_ordered(hip):
+    """ops.HipOps keeps the weight-gradient kernels' row-geometry tables per geometry: a table filled on one stream is
+    handed to a weight gradient on ANOTHER stream only behind the fill's event, and the cache is bounded — least recently used
+    tables go, results stay right."""
+    saved = (hip.ROWGEOM_MAX_TABLES, dict(hip._rowgeom), hip._rowgeom_bytes)
+    hip._rowgeom.clear()
+    hip._rowgeom_bytes = 0
+    hip.ROWGEOM_MAX_TABLES = 2
+    try:
+        side = torch.cuda.Stream()
+        geoms = [ConvGeom(2, 4, 8 + i, 8, 16, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)) for i in range(4)]
+        for rnd_i, g in enumerate(geoms + geoms[:2]):
+            x = rnd(g.N, g.Di, g.Hi, g.Wi, g.Cin, seed=20 + rnd_i)
+            do, ho, wo = g.out_dims
+            dy = rnd(g.N, do, ho, wo, g.Cout, seed=40 + rnd_i)
+            dw_ref = torch.empty(g.Cout, g.Cin, *g.k)
+            CPU.conv_wgrad(g, x, dy, dw_ref, None)
+            xd, dyd = x.to(DEV), dy.to(DEV)
+            # first use on the side stream (where the engine's weight-gradient tasks run), then at once on the main stream with
+            # another Cout: the cached table must not be read before its fill has finished
+            dw_side = torch.empty_like(dw_ref, device=DEV)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                hip.conv_wgrad(g, xd, dyd, dw_side)
+            g2 = ConvGeom(g.N, g.Di, g.Hi, g.Wi, g.Cin, 16, g.k, g.s, g.p)
+            dw2 = torch.empty(16, g.Cin, *g.k, device=DEV)
+            hip.conv_wgrad(g2, xd, dyd[..., :16].contiguous(), dw2)
+            torch.cuda.current_stream().wait_stream(side)
+            close(dw_side, dw_ref, 2e-5, "wgrad on the side stream")
+            close(dw2, dw_ref[:16], 2e-5, "wgrad through the cached table on the main stream")
+            assert len(hip._rowgeom) <= 2
+    finally:
+        torch.cuda.synchronize()
+        hip._rowgeom.clear()
+        hip.ROWGEOM_MAX_TABLES = saved[0]
+        hip._rowgeom.update(saved[1])
+        hip._rowgeom_bytes = saved[2]
