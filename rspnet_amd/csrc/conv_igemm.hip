@@ -48,9 +48,12 @@ const float* igemm_zero_page() {
 // puts a row's w-neighbour taps in adjacent chunks.  Measured on C3D (PMC FETCH_SIZE x2 per launch): conv3b 4.5 -> 0.95 GB,
 // conv4b 1.8 -> 0.67 GB, conv2 dgrad 9.7 -> 1.5 GB (conv2 fwd + dgrad average), at unchanged time.  Used when the GEMM's
 // channel count is a multiple of 32 (every chunk is then one tap of one slice), there is more than one tap, and K is long
-// (>= 96 chunks).  (With the wave-uniform walk of igemm_ks_kernel a threshold of 32 or 0 chunks measured the same step times on all
+// (>= 48 chunks; 96 until round 5).  (Round 3, per-tile kernels: a threshold of 32 or 0 chunks measured the same step times on all
 // four backbones, +-0.5 %; the short-K layers' 64..192-channel rows never thrashed, so they keep the tap-major kernel.)
-__host__ __device__ inline bool k_slice_major(int C, int ntaps) { return ntaps > 1 && (C & 31) == 0 && C * ntaps >= 96 * 32; }
+// (threshold: 48 chunks since round 5 — C3D conv2's 54-chunk forward moved from the per-tile tap-major kernel to the persistent
+//  slice-major one: 131 -> 137 TF, C3D +0.7 % per step on two boxes; R3D-18 / R(2+1)D / S3D-G within +-0.3 %; at 32 chunks R3D-18
+//  loses 0.8 %: profiles/r05/experiments_r5.txt)
+__host__ __device__ inline bool k_slice_major(int C, int ntaps) { return ntaps > 1 && (C & 31) == 0 && C * ntaps >= 48 * 32; }
 __host__ __device__ inline int k_index(bool slice_major, int tap, int c, int C, int ntaps) {
   return slice_major ? (c >> 5) * (ntaps * 32) + tap * 32 + (c & 31) : tap * C + c;
 }

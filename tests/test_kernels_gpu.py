@@ -64,7 +64,7 @@ CONV_CASES = [
     (1, 6, 130, 128, 16, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # 780 tiles of 128x128, K = 432
     (1, 6, 130, 128, 16, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 780 tiles of 128x96
     (1, 6, 130, 128, 128, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # dgrad: 780 tiles of 128x128 over K = 32 (one chunk)
-    # channel-slice-major K order (igemm_ks_kernel: C % 32 == 0, >= 96 chunks) on the 96-, 64- and 32-wide tiles; strided: per-class choice
+    # channel-slice-major K order (igemm_ks_kernel: C % 32 == 0, >= 48 chunks) on the 96-, 64- and 32-wide tiles; strided: per-class choice
     (1, 2, 6, 6, 128, 96, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 2, 6, 6, 128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 2, 6, 6, 128, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
@@ -542,7 +542,7 @@ def test_mlp_head_pieces(hip):
 # column segments, single- and multi-launch strided dgrad, the 343-tap stem on the implicit-GEMM path
 NAME_CASES = [
     (32, 16, 112, 112, 4, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # C3D conv1: stem_resident
-    (32, 16, 56, 56, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # conv2: tap-major 128x128
+    (32, 16, 56, 56, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # conv2: 54 chunks, slice-major since round 5
     (32, 4, 14, 14, 512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # conv4b: slice-major
     (32, 16, 112, 112, 4, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),       # R3D stem
     (32, 8, 28, 28, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),        # strided: dgrad parity classes in one launch
