@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Forward time of a list of convolution geometries on the library RSPNET_HIP_LIB points at (default: the product build): 60
+back-to-back launches each (sustained clocks), HIP events.  For A/B runs of variant builds (tools/build_variant.sh) on the layers a
+change is aimed at:  python tools/geom_bench.py [s3dg14|r3d|all]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from rspnet_amd import ops
+from rspnet_amd.ops import ConvGeom
+
+SETS = {
+    "s3dg14": [(16, 4, 14, 14, 528, 448, (1, 1, 1)), (16, 4, 14, 14, 512, 288, (1, 1, 1)), (16, 4, 14, 14, 480, 304, (1, 1, 1)),
+               (16, 4, 14, 14, 160, 320, (1, 3, 3)), (16, 4, 14, 14, 144, 288, (1, 3, 3)), (16, 4, 14, 14, 320, 320, (3, 1, 1)),
+               (16, 4, 14, 14, 288, 288, (3, 1, 1)), (16, 4, 14, 14, 128, 256, (1, 3, 3)), (16, 4, 14, 14, 256, 256, (3, 1, 1)),
+               (16, 4, 14, 14, 112, 224, (1, 3, 3)), (16, 4, 14, 14, 224, 224, (3, 1, 1)), (16, 4, 14, 14, 96, 208, (1, 3, 3)),
+               (16, 4, 14, 14, 208, 208, (3, 1, 1)), (16, 4, 14, 14, 512, 64, (1, 1, 1))],
+    "s3dg28": [(16, 8, 28, 28, 256, 288, (1, 1, 1)), (16, 8, 28, 28, 192, 176, (1, 1, 1)), (16, 8, 28, 28, 128, 192, (1, 3, 3)),
+               (16, 8, 28, 28, 192, 192, (3, 1, 1)), (16, 8, 28, 28, 96, 128, (1, 3, 3)), (16, 8, 28, 28, 128, 128, (3, 1, 1))],
+    "r3d": [(32, 4, 14, 14, 128, 128, (3, 3, 3)), (32, 2, 7, 7, 256, 256, (3, 3, 3)), (32, 1, 4, 4, 512, 512, (3, 3, 3))],
+    "r21d": [(32, 4, 14, 14, 256, 576, (1, 3, 3)), (32, 4, 14, 14, 576, 256, (3, 1, 1)), (32, 2, 7, 7, 512, 1152, (1, 3, 3)),
+             (32, 2, 7, 7, 1152, 512, (3, 1, 1))],
+}
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+cases = sum(SETS.values(), []) if which == "all" else SETS[which]
+be = ops.backend()
+dev = torch.device("cuda", 0)
+print("lib:", os.environ.get("RSPNET_HIP_LIB", "product"))
+tot = 0.0
+for N, D, H, W, cin, cout, k in cases:
+    p = tuple(x // 2 for x in k)
+    g = ConvGeom(N, D, H, W, cin, cout, k, (1, 1, 1), p)
+    x = torch.randn(N, D, H, W, cin, device=dev)
+    w = torch.randn(cout, cin, *k, device=dev) * 0.05
+    wp = be.conv_pack_fwd(g, w)
+    for _ in range(10):
+        be.conv_fwd(g, x, wp, None, True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(60):
+        be.conv_fwd(g, x, wp, None, True)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 60 * 1e3
+    tot += us
+    print(f"{N}x{D}x{H}x{W}x{cin}->{cout} k{k}: {us:8.1f} us  {g.flops / us / 1e6:6.1f} TF")
+print(f"sum {tot:.1f} us")
