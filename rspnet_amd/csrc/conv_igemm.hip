@@ -90,6 +90,7 @@ struct IgemmParams {
   FastDiv dGw, dGh, dGd, dCin, dTw, dTh;   // filled by fill_fastdiv() from Gw, Gh, Gd, Cin, nTw, nTh
   int adv_tap, adv_ci;                     // BK / Cin, BK % Cin
   int nbuf;                                // LDS tile buffers: 2, or 1 (see igemm_body)
+  int bn_narrow;                           // 64: this launch runs on the 64-wide tile whatever its column count (narrow_tiles()); 0: tile_bn(Cout)
   int kmajor;                              // 1: channel-slice-major K order (k_slice_major)
   int skip_pad;                            // slice-major walk: skip the chunks of taps that are padding for the whole tile
   int tm_skip, cpt;                        // the same in the tap-major DMA walk when a chunk is one tap for all lanes; cpt = Cin / BK
@@ -1777,6 +1778,24 @@ inline int tile_bn(int Cout) {
   return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
 }
 
+// Launches of less than one round of 128-wide tiles run on the 64-WIDE tile instead (round 5): twice the units, so 392 tiles on 256 CUs
+// are 2.7-3 short units per CU instead of "1.53 rounds" = two long ones on half of the CUs.  Measured per layer (tools/geom_bench.py,
+// profiles/r05/experiments_r5.txt): S3D-G's 14 x 14 layers +2-5 % (528 -> 448: +16 %), R(2+1)D's 576 -> 256 temporal convolution +13 %,
+// 7 x 7 / 4 x 4 layers +1-3 %; per step S3D-G 405.3 -> 412.5 (+1.8 %) and +0.25 % more with the 97..128-column launches included,
+// R3D-18 +0.8 %, R(2+1)D +0.1 %, C3D -0.1 % (conv5: noise).  Launches of a full round or more lose up to 1 % (the 64-wide tile re-reads the
+// A operand for half as many MFMAs: C3D -0.8 % with the limit at 1024 tiles) and keep the wide tile.
+static int narrow_max_tiles() {
+  static const int v = getenv("RSP_NARROW_MAX_TILES") ? atoi(getenv("RSP_NARROW_MAX_TILES")) : 512;      // (0: off; A/B switch, read once)
+  return v;
+}
+inline bool narrow_tiles(long long M, int Cout) {
+  // (97..128 and > 160 columns: whole 64-wide tiles or nearly; 65..96 / 129..160 keep their 96- / 160-wide tile, whose last 64-wide
+  //  tile would be half empty)
+  const bool cols = Cout > 160 || (Cout > 96 && Cout <= 128);
+  return cols && (long long)rsp_cdiv(M, 128) * rsp_cdiv(Cout, 128) < narrow_max_tiles();
+}
+inline int tile_bn_of(const IgemmParams& p) { return p.bn_narrow ? p.bn_narrow : tile_bn(p.Cout); }
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
 int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + (size_t)(max_taps + 1) * sizeof(int4) + BM * sizeof(long long);
@@ -1829,7 +1848,7 @@ int launch_persist_cfg(const IgemmParams& p, hipStream_t s) {
 }
 
 int launch_persist(IgemmParams& p, hipStream_t s) {
-  const int bn = tile_bn(p.Cout);
+  const int bn = tile_bn_of(p);
   p.m_tiles = rsp_cdiv(p.M, 128);
   p.n_tiles = rsp_cdiv(p.Cout, bn);
   const int R = p.m_tiles * p.n_tiles - p.full_tiles;
@@ -1904,7 +1923,7 @@ inline void fill_fastdiv(IgemmParams& p) {
 
 int launch_igemm(IgemmParams& p, bool vec4, hipStream_t s) {
   // BM is fixed at 128 (stat partials are defined on 128-row tiles); BN follows Cout.
-  int bn = tile_bn(p.Cout);
+  int bn = tile_bn_of(p);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;      // the scalar-gather fallback only has the power-of-two tiles
   p.m_tiles = rsp_cdiv(p.M, 128);
   p.n_tiles = rsp_cdiv(p.Cout, bn);
@@ -2037,7 +2056,7 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
     p.tm_skip = 0;
     fill_fastdiv_linear(p);
   }
-  int bn = tile_bn(p.Cout);
+  int bn = tile_bn_of(p);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
   const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
   SplitPlan sp = plan_split(m_tiles, n_tiles, bn, vec4, p.nchunks, p.Cout);
@@ -2200,6 +2219,10 @@ int run_direct(IgemmParams& p, void* workspace, size_t ws_bytes, hipStream_t s) 
 int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
   p.stat_ld = p.Cout;
   if (direct_applies(p.M, p.Cout, p.Cin, p.K, vec4)) return run_direct(p, workspace, ws_bytes, s);
+  if (vec4 && narrow_tiles(p.M, p.Cout)) {      // one launch of 64-wide tiles over all columns (no column segments)
+    p.bn_narrow = 64;
+    return run_igemm_segment(p, vec4, workspace, ws_bytes, s);
+  }
   const Segments g = plan_segments(p.Cout);
   if (g.n == 1) return run_igemm_segment(p, vec4, workspace, ws_bytes, s);
   for (int i = 0; i < g.n; ++i) {
@@ -2222,6 +2245,11 @@ size_t igemm_partial_bytes_segment(long long M, int Cout, int K);
 size_t igemm_partial_bytes(long long M, int Cout, int K) {
   const Segments g = plan_segments(Cout);
   size_t best = direct_partial_bytes(M, Cout, K);      // (whether the direct kernel runs depends on alignment, unknown here)
+  if (narrow_tiles(M, Cout)) {
+    const int n_tiles = rsp_cdiv(Cout, 64);
+    const size_t b = split_partial_bytes(plan_split(rsp_cdiv(M, 128), n_tiles, 64, true, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
+    best = b > best ? b : best;
+  }
   for (int i = 0; i < g.n; ++i) {
     const size_t b = igemm_partial_bytes_segment(M, g.width[i], K);
     best = b > best ? b : best;
@@ -2514,6 +2542,17 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   // (a convolution that runs as two column segments is named after the first, wider one)
   int bn = tile_bn(plan_segments(cols).width[0]);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
+  {
+    long long Mrows = (long long)d->N * d->Do * d->Ho * d->Wo;
+    if (which == 1)
+      for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
+        const DgradClass g = dgrad_class(d, c);
+        if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+        Mrows = (long long)d->N * g.Gd * g.Gh * g.Gw;
+        break;
+      }
+    if (vec4 && narrow_tiles(Mrows, cols)) bn = 64;
+  }
   // spelled as rocprofv3 prints the demangled instance (minus namespace and argument list)
   const bool ks = vec4 && ((which == 0 && k_slice_major(d->Cin, d->kT * d->kH * d->kW)) ||
                            (which == 1 && d->sT * d->sH * d->sW == 1 && k_slice_major(d->Cout, d->kT * d->kH * d->kW)));
