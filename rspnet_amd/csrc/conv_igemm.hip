@@ -1311,8 +1311,8 @@ __global__ __launch_bounds__(256, MINW) void igemm_multi_kernel(const IgemmMulti
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Direct implicit GEMM for SMALL launches (round 5): 128 rows x 64 columns per workgroup, operands straight from L2 into MFMA
-// fragments — no LDS tiles, no tile pipeline to fill and drain.
+// Direct implicit GEMM for SMALL launches (round 5; measured, then superseded by narrow_tiles(): see direct_applies): 128 rows x 64
+// columns per workgroup, operands straight from L2 into MFMA fragments — no LDS tiles, no tile pipeline to fill and drain.
 //
 // Why.  The LDS-DMA tile kernels above are built for launches of many rounds: a 128 x 128 tile lives 45-70 us even at K = 64-288
 // (15 us before its first MFMA, 8 us storing: tools/phase_probe.py), and a launch of a few dozen to a few hundred tiles — the
@@ -2114,25 +2114,20 @@ Segments plan_segments(int Cout) {
   return g;
 }
 
-// ---- the direct kernel's share (igemm_direct_kernel): launches whose 128-row x 128-column tile count is at most DIRECT_MAX_TILES
-static bool direct_enabled() {
-  static const bool off = getenv("RSP_NO_DIRECT") != nullptr;      // (A/B switch for measurements, read once)
-  return !off;
-}
+// ---- the direct kernel (igemm_direct_kernel): OFF by default since the 64-wide tiles of narrow_tiles().  History (profiles/r05/
+// direct_vs_tile_r5h.txt, experiments_r5.txt): against 128-wide tiles it won the 7 x 7 / 4 x 4 stages (13-30 % per launch) and the
+// 1x1x1 stride-2 shortcuts (15-25 %) and lost everything above ~1.4 GFLOP (it tops out at 45-50 TFLOP/s: L2 latency under three waves
+// per SIMD); against 64-wide tiles it loses those too (eleven small geometries back to back: 361 vs 326 us, tools/geom_bench.py small).
+// RSP_DIRECT_MAX_TILES=N selects it for launches of at most N 128 x 128 tiles with Cin % 16 == 0 (re-measurements, and the GPU tests run
+// the small convolution cases through it in a child interpreter).
 static int direct_max_tiles() {
-  static const int v = getenv("RSP_DIRECT_MAX_TILES") ? atoi(getenv("RSP_DIRECT_MAX_TILES")) : 448;
+  static const int v = getenv("RSP_DIRECT_MAX_TILES") ? atoi(getenv("RSP_DIRECT_MAX_TILES")) : 0;
   return v;
 }
-// Measured per layer against the tile kernels (profiles/r05/direct_vs_tile_r5h.txt): the direct kernel tops out at 45-50 TFLOP/s
-// (L2 latency under three waves per SIMD), the tile kernels reach 100+ on anything of a few GFLOP — so it takes only what the tile
-// pipeline cannot amortise: at most 25 row tiles and 1.4 GFLOP (7 x 7 / 4 x 4 stages: 13-30 % faster), or K of at most two
-// chunks (the 1x1x1 stride-2 shortcuts: 15-25 %).
 bool direct_applies(long long M, int Cout, int Cin, int K, bool vec4) {
-  if (!vec4 || !direct_enabled() || Cin % 16 != 0 || M <= 0) return false;
-  if ((long long)rsp_cdiv(M, 128) * rsp_cdiv(Cout, 128) > direct_max_tiles()) return false;
-  if (getenv("RSP_DIRECT_MAX_TILES")) return true;      // (sweeps: the tile count alone decides)
-  const double flops = 2.0 * (double)M * Cout * K;
-  return (rsp_cdiv(M, 128) <= 25 && flops <= 1.4e9) || rsp_cdiv(K, BK) <= 2;
+  (void)K;
+  if (!vec4 || direct_max_tiles() <= 0 || Cin % 16 != 0 || M <= 0) return false;
+  return (long long)rsp_cdiv(M, 128) * rsp_cdiv(Cout, 128) <= direct_max_tiles();
 }
 // K split of a direct launch: enough units for ~3 workgroups per CU, at least 4 chunks per slice
 struct DirectPlan {

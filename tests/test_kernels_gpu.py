@@ -82,9 +82,10 @@ CONV_CASES = [
     # wgrad output-channel segments on the 32-wide tile
     (1, 3, 20, 20, 8, 20, (1, 3, 3), (1, 1, 1), (0, 1, 1)),        # 20 channels: one 32-wide tile
     (1, 3, 20, 20, 16, 272, (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # 272 = 256 + 16; K = 16 (64-wide k tile: the 16 ride on the 64-row tile)
-    # small launches with Cin % 16 == 0 run on igemm_direct_kernel (operands straight from L2, no LDS tiles): most of the small cases
-    # above — 1x1x1 stride 2, strided parity classes, slice-major K with a K split, 16 / 150 / 576 columns — plus half-chunks that
-    # straddle taps (Cin = 112, 208: not multiples of 32) and a K that ends inside a chunk (208 = 6.5 chunks)
+    # small launches of > 96 columns run on the 64-wide tile (narrow_tiles); with RSP_DIRECT_MAX_TILES set (the child run at the end of
+    # this file) every small launch with Cin % 16 == 0 runs on igemm_direct_kernel: 1x1x1 stride 2, strided parity classes, slice-major
+    # K with a K split, 16 / 150 / 576 columns — plus half-chunks that straddle taps (Cin = 112, 208: not multiples of 32) and a K
+    # that ends inside a chunk (208 = 6.5 chunks)
     (2, 4, 14, 14, 208, 160, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (2, 4, 14, 14, 112, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (3, 4, 7, 7, 48, 72, (3, 3, 3), (2, 2, 2), (1, 1, 1)),         # Cin = 48, 72 columns (64 + 8), strided: dgrad classes with K = 72 * taps
@@ -551,9 +552,9 @@ NAME_CASES = [
     (32, 16, 56, 56, 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     (16, 16, 224, 224, 4, 64, (1, 7, 7), (2, 2, 2), (0, 3, 3)),       # S3D-G stem (streaming stem kernel)
     (16, 8, 28, 28, 192, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # 96-wide tile
-    (16, 4, 14, 14, 160, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # dgrad N = 160 (98 x 3 tiles: the direct kernel)
-    (32, 8, 28, 28, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),        # R3D-18 layer2.0 shortcut: direct kernel
-    (16, 4, 14, 14, 480, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # S3D-G 14 x 14 pointwise trio: direct kernel
+    (16, 4, 14, 14, 160, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # dgrad N = 160; forward 98 x 3 tiles: the 64-wide tile
+    (32, 8, 28, 28, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),        # R3D-18 layer2.0 shortcut: 196 tiles, 64-wide
+    (16, 4, 14, 14, 480, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # S3D-G 14 x 14 pointwise trio: 64-wide tiles
     (16, 8, 28, 28, 192, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # ... at 28 x 28: 784 x 2 tiles, the tile kernels
 ]
 
@@ -788,17 +789,18 @@ def test_bn_act_gate_bwd_fused_matches_the_two_ops(hip, N, D, H, W, C, sliced):
         close(got, ref, 5e-5, name + " vs checker")
 
 
-def test_conv_cases_also_pass_on_the_tile_kernels():
-    """Small launches with Cin % 16 == 0 take igemm_direct_kernel by default, which covers most of the small geometries above; the
-    LDS-DMA tile kernels must keep passing them too (they run every large launch): the same cases in a child interpreter with
-    RSP_NO_DIRECT=1 (the switch is read once per process)."""
+def test_conv_cases_also_pass_on_the_direct_kernel():
+    """igemm_direct_kernel (operands straight from L2, no LDS tiles) is off by default since the 64-wide tiles took over the small
+    launches (conv_igemm.hip: direct_applies); it stays selectable for re-measurements, so it stays correct: the convolution cases
+    in a child interpreter with RSP_DIRECT_MAX_TILES=448 — every launch of at most 448 tiles with Cin % 16 == 0 then runs on it (the
+    switch is read once per process)."""
     import os
     import subprocess
     import sys
-    if os.environ.get("RSP_NO_DIRECT"):
-        pytest.skip("already the tile-kernel run")
+    if os.environ.get("RSP_DIRECT_MAX_TILES"):
+        pytest.skip("already the direct-kernel run")
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, RSP_NO_DIRECT="1")
+    env = dict(os.environ, RSP_DIRECT_MAX_TILES="448")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
                         "conv_fwd_dgrad_wgrad or conv_fuzz or deterministic or reported_kernel_name"], capture_output=True, text=True,
                        timeout=1800, env=env, cwd=os.path.dirname(here))

@@ -20,6 +20,11 @@ SETS = {
                (16, 4, 14, 14, 208, 208, (3, 1, 1)), (16, 4, 14, 14, 512, 64, (1, 1, 1))],
     "s3dg28": [(16, 8, 28, 28, 256, 288, (1, 1, 1)), (16, 8, 28, 28, 192, 176, (1, 1, 1)), (16, 8, 28, 28, 128, 192, (1, 3, 3)),
                (16, 8, 28, 28, 192, 192, (3, 1, 1)), (16, 8, 28, 28, 96, 128, (1, 3, 3)), (16, 8, 28, 28, 128, 128, (3, 1, 1))],
+    "small": [(16, 2, 7, 7, 832, 448, (1, 1, 1)), (16, 2, 7, 7, 832, 128, (1, 1, 1)), (16, 2, 7, 7, 320, 320, (3, 1, 1)),
+              (16, 2, 7, 7, 160, 320, (1, 3, 3)), (16, 2, 7, 7, 128, 128, (3, 1, 1)), (16, 2, 7, 7, 384, 384, (3, 1, 1)),
+              (16, 2, 7, 7, 192, 384, (1, 3, 3)), (16, 2, 7, 7, 832, 624, (1, 1, 1)),
+              (32, 8, 28, 28, 64, 128, (1, 1, 1), (2, 2, 2)), (32, 4, 14, 14, 128, 256, (1, 1, 1), (2, 2, 2)),
+              (32, 2, 7, 7, 256, 512, (1, 1, 1), (2, 2, 2))],
     "r3d": [(32, 4, 14, 14, 128, 128, (3, 3, 3)), (32, 2, 7, 7, 256, 256, (3, 3, 3)), (32, 1, 4, 4, 512, 512, (3, 3, 3))],
     "r21d": [(32, 4, 14, 14, 256, 576, (1, 3, 3)), (32, 4, 14, 14, 576, 256, (3, 1, 1)), (32, 2, 7, 7, 512, 1152, (1, 3, 3)),
              (32, 2, 7, 7, 1152, 512, (3, 1, 1))],
@@ -30,9 +35,11 @@ be = ops.backend()
 dev = torch.device("cuda", 0)
 print("lib:", os.environ.get("RSPNET_HIP_LIB", "product"))
 tot = 0.0
-for N, D, H, W, cin, cout, k in cases:
+for case in cases:
+    N, D, H, W, cin, cout, k = case[:7]
+    st = case[7] if len(case) > 7 else (1, 1, 1)
     p = tuple(x // 2 for x in k)
-    g = ConvGeom(N, D, H, W, cin, cout, k, (1, 1, 1), p)
+    g = ConvGeom(N, D, H, W, cin, cout, k, st, p)
     x = torch.randn(N, D, H, W, cin, device=dev)
     w = torch.randn(cout, cin, *k, device=dev) * 0.05
     wp = be.conv_pack_fwd(g, w)
@@ -46,5 +53,5 @@ for N, D, H, W, cin, cout, k in cases:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 60 * 1e3
     tot += us
-    print(f"{N}x{D}x{H}x{W}x{cin}->{cout} k{k}: {us:8.1f} us  {g.flops / us / 1e6:6.1f} TF")
+    print(f"{N}x{D}x{H}x{W}x{cin}->{cout} k{k} s{st}: {us:8.1f} us  {g.flops / us / 1e6:6.1f} TF")
 print(f"sum {tot:.1f} us")

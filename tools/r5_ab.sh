@@ -1,12 +1,10 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-O=gpurun_out/r5u; mkdir -p $O
-for arch in s3dg resnet18 r2plus1d-vcop; do
-  for v in A B A B; do
-    if [ "$v" = A ]; then unset RSP_NARROW_128; else export RSP_NARROW_128=1; fi
-    python3 bench.py --arch $arch --no-cpu-baseline --no-other-workloads --steps 30 --warmup 8 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']
-print('$arch $v', d['value'], d['ms_per_step'], 'conv ms', r['all_conv_launches']['ms_per_step'])"
-  done
-done > $O/ab_narrow128.txt 2>&1; cat $O/ab_narrow128.txt
+O=gpurun_out/r5v; mkdir -p $O
+for v in A B A B; do
+  if [ "$v" = A ]; then unset RSP_NO_DIRECT; else export RSP_NO_DIRECT=1; fi
+  python3 tools/geom_bench.py small > $O/small_$v$RANDOM.txt 2>&1
+done
+unset RSP_NO_DIRECT
+tail -n 13 $O/small_A*.txt | cut -c1-90; tail -n 13 $O/small_B*.txt | cut -c1-90
+timeout 2400 python -m pytest tests/test_kernels_gpu.py tests/test_full_size_gpu.py tests/test_full_size_parity_gpu.py tests/test_teacher_forced_gpu.py tests/test_step_gpu.py -x -q -m gpu > $O/tests.log 2>&1; echo "tests rc $?" >> $O/tests.log; tail -3 $O/tests.log
