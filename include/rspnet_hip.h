@@ -136,6 +136,15 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which);
  * bench.py prices roofline.executed_frac with it next to the algorithmic rate. */
 double rsp_conv3d_executed_fraction(const rsp_conv3d_desc* d, int which);
 
+/* Planning options of the convolution launchers, settable at run time (process-wide; host arithmetic only: which kernel instance and
+ * which K split a descriptor gets — every choice computes the same convolution, in another summation order).  Returns the previous
+ * value, or RSP_EINVAL for an unknown name.
+ *   "narrow_max_tiles"  launches of fewer than this many 128-wide tiles (and 97..128 or > 160 columns) run on the 64-wide tile
+ *                       (default 512, environment RSP_NARROW_MAX_TILES; 0: never; < 0: back to the default).
+ * The whole-step parity tests use it to evaluate a fixture under TWO valid tile plans: a state whose gradient moves by percents
+ * between them holds ReLU / max-pool decisions within rounding of a knife edge (tests/golden_util.py). */
+int rsp_conv3d_set_option(const char* name, int32_t value);
+
 /* Host evaluation of the constant division the conv kernels use to decode GEMM rows and k positions (multiply-high by a
  * host-computed magic number + shift, exact for 0 <= n < 2^31): returns n / d computed that way.  No GPU needed; exists so
  * the CPU test suite can check the derivation over the full range. */

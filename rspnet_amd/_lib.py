@@ -87,6 +87,7 @@ SIGNATURES = {
     "rsp_conv3d_wgrad_t": (C.c_int, [_PD, _p, _p, _p, _p, _i32, _i32, _p, _p, _sz, _p]),
     "rsp_conv3d_kernel_name": (C.c_char_p, [_PD, C.c_int]),
     "rsp_conv3d_executed_fraction": (C.c_double, [_PD, C.c_int]),
+    "rsp_conv3d_set_option": (C.c_int, [C.c_char_p, _i32]),
     "rsp_fastdiv_check": (C.c_int, [C.c_int, C.c_int]),
     "rsp_bn_finalize_workspace": (_sz, [_i32, _i32]),
     "rsp_bn_finalize": (C.c_int, [_p, _i32, _i32, _i32, _i64, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),

@@ -16,6 +16,7 @@
 // input are served by L2 (27 x re-read of conv2's 411 MB input = 1.6 TB/s of L2 traffic, L2 peak 34 TB/s).
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include "conv_stem.h"
 
@@ -1784,7 +1785,10 @@ inline int tile_bn(int Cout) {
 // 7 x 7 / 4 x 4 layers +1-3 %; per step S3D-G 405.3 -> 412.5 (+1.8 %) and +0.25 % more with the 97..128-column launches included,
 // R3D-18 +0.8 %, R(2+1)D +0.1 %, C3D -0.1 % (conv5: noise).  Launches of a full round or more lose up to 1 % (the 64-wide tile re-reads the
 // A operand for half as many MFMAs: C3D -0.8 % with the limit at 1024 tiles) and keep the wide tile.
+std::atomic<int> g_narrow_max_tiles{-1};      // >= 0: set through rsp_conv3d_set_option; -1: the environment / the default
 static int narrow_max_tiles() {
+  const int set = g_narrow_max_tiles.load(std::memory_order_relaxed);
+  if (set >= 0) return set;
   static const int v = getenv("RSP_NARROW_MAX_TILES") ? atoi(getenv("RSP_NARROW_MAX_TILES")) : 512;      // (0: off; A/B switch, read once)
   return v;
 }
@@ -2893,6 +2897,16 @@ int32_t rsp_conv3d_pack_jobs(const rsp_conv3d_desc* d, int32_t which, int32_t Co
 }
 
 void rsp_conv3d_pack_forget(const void* w_packed) { rsp_stem_forget_packed(w_packed); }
+
+int rsp_conv3d_set_option(const char* name, int32_t value) {
+  if (name && !strcmp(name, "narrow_max_tiles")) {
+    const int prev = narrow_max_tiles();
+    g_narrow_max_tiles.store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    return prev;
+  }
+  rsp_set_error("rsp_conv3d_set_option: unknown option");
+  return RSP_EINVAL;
+}
 
 int rsp_pack_run(const rsp_pack_job* jobs_device, int32_t n_jobs, int32_t max_blocks, void* stream) {
   RSP_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_blocks > 0, "rsp_pack_run: bad argument");

@@ -228,6 +228,16 @@ class HipOps:
             self._ws[key] = buf
         return buf
 
+    def set_option(self, name: str, value: int) -> int:
+        """rsp_conv3d_set_option: a planning option of the convolution launchers (process-wide; e.g. "narrow_max_tiles").  Returns
+        the previous value.  The per-geometry plan cache (kernel names, workspace sizes) is dropped with it."""
+        prev = self.lib.rsp_conv3d_set_option(name.encode(), int(value))
+        if prev < 0:
+            _lib.check(prev, "rsp_conv3d_set_option")
+        _conv_plan.cache_clear()
+        executed_fraction.cache_clear()
+        return prev
+
     # ---- conv -------------------------------------------------------------------------------------------------
     def conv_pack_fwd(self, g: ConvGeom, w_ref: torch.Tensor) -> torch.Tensor:
         _chk(w_ref, "w_ref")

@@ -51,10 +51,17 @@ def forced_worker(rank, backend, arch, seed, port, out_path, graph=False):
         setattr(dist, name, make(name, getattr(dist, name)))
     z, meta = load_case(arch, 1, seed)
     spec, inputs = build_inputs(arch, meta)
-    res, post, mom_post, grads = run_model_step(arch, meta, inputs, 0, dev, "fused")
-    errs = compare_to_golden(z, 0, res, post, mom_post, tol=tol, tol_grad=grad_tol(arch))
-    wkey, worst = worst_grad_err(z, 0, grads)
-    assert worst <= grad_tol(arch), (wkey, worst)
+    from golden_util import check_step_gradients
+    runs = []
+
+    def step():
+        before = dict(calls)
+        out = run_model_step(arch, meta, inputs, 0, dev, "fused")
+        runs.append({k: calls[k] - before.get(k, 0) for k in calls})
+        return out
+
+    errs, worst, plan, _ = check_step_gradients(arch, 1, 0, z, step, tol)
+    calls = collections.Counter(runs[0])       # (the collectives of ONE step: a second run under the wide-tile plan repeats them)
     # what ran: 2 clip all-to-alls, 1 fused key all-gather, >= 1 bucket all-reduce (+1: the side-group agreement under nccl),
     # the constructor's broadcasts + 1 host-side broadcast of (speed, permutations) per step
     assert calls["all_to_all_single"] == 2 and calls["all_gather_into_tensor"] == 1, dict(calls)
