@@ -1,6 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-O=gpurun_out/r5z; mkdir -p $O
-echo "== narrow off"; RSP_NARROW_MAX_TILES=0 timeout 900 python tools/grad_report.py 2>&1 | grep -E "^(c3d  |resnet18|s3dg|r2plus)" 
-echo "== narrow off, multi split off"; RSP_NARROW_MAX_TILES=0 RSP_NO_MULTI_SPLIT=1 timeout 900 python tools/grad_report.py 2>&1 | grep -E "^(c3d  |resnet18|s3dg|r2plus)"
-echo "== direct on"; RSP_DIRECT_MAX_TILES=448 timeout 900 python tools/grad_report.py 2>&1 | grep -E "^(c3d  |resnet18|s3dg|r2plus)"
+O=gpurun_out/r6a; mkdir -p $O
+timeout 3000 python -m pytest tests/test_step_gpu.py tests/test_rccl_gpu.py tests/test_two_rank_gpu.py tests/test_bench_contract_gpu.py tests/test_abi.py -q -m gpu -s > $O/tests.log 2>&1; echo "tests rc $?" >> $O/tests.log; grep -E "tile plan|passed|failed|FAILED" $O/tests.log | cut -c1-260
