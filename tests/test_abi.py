@@ -77,3 +77,22 @@ def test_constant_division_matches_integer_division():
             n = int(n)
             if 0 <= n <= top:
                 assert lib.rsp_fastdiv_check(d, n) == n // d, (d, n)
+
+
+def test_tile_plan_option_changes_the_dispatch_not_the_interface():
+    """rsp_conv3d_set_option("narrow_max_tiles", v): launches of less than one round of 128-wide tiles run on the 64-wide tile by
+    default; 0 switches that off (the parity tests' second evaluation order), a negative value restores the default.  Host
+    arithmetic only: checked through the dispatch predictor."""
+    lib = _lib.load()
+    d = _lib.ConvDesc(16, 4, 14, 14, 528, 4, 14, 14, 448, 1, 1, 1, 1, 1, 1, 0, 0, 0, 528, 448)      # S3D-G 14 x 14 pointwise: 98 x 4 tiles
+    big = _lib.ConvDesc(32, 8, 28, 28, 256, 8, 28, 28, 256, 3, 3, 3, 1, 1, 1, 1, 1, 1, 256, 256)    # C3D conv3b: 1568 x 2 tiles
+    name = lambda dd: lib.rsp_conv3d_kernel_name(ctypes.byref(dd), 0).decode()
+    assert name(d).startswith("igemm_persist_kernel<128, 64,") and name(big).startswith("igemm_persist_kernel<128, 128,")
+    prev = lib.rsp_conv3d_set_option(b"narrow_max_tiles", 0)
+    try:
+        assert prev == 512
+        assert name(d).startswith("igemm_persist_kernel<128, 128,") and name(big).startswith("igemm_persist_kernel<128, 128,")
+    finally:
+        assert lib.rsp_conv3d_set_option(b"narrow_max_tiles", -1) == 0
+    assert name(d).startswith("igemm_persist_kernel<128, 64,")
+    assert lib.rsp_conv3d_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.rsp_last_error()
