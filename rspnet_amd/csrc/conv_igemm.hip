@@ -744,20 +744,27 @@ struct UnitPos {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS>
 __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg, const int nwg, const int n_units) {
-  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int AR = BM / 32, BR = BN / 32;
+  // HALF (BN = 32 * TN + 16, four waves stacked along M): the last 16 columns of the tile are two 16x16 blocks per wave on
+  // v_mfma_f32_16x16x4_f32 — the same 64 flops per cycle and SIMD as the 32x32x2 form, so a 144-column segment (R(2+1)D's mid
+  // channels) costs 4.5 column blocks of matrix-pipe time instead of the 160-wide tile's 5.  The B tile in LDS keeps whole 32-row
+  // groups (BNL rows; the loader's rows beyond the segment read as zeros), the tile's N extent (unit_pos, statistics) is BN.
+  constexpr bool HALF = BN % 32 == 16;
+  constexpr int BNL = HALF ? BN + 16 : BN;
+  constexpr int WM = BM / WAVES_M, WN = BNL / WAVES_N;
+  constexpr int TM = WM / 32, TN = (BN / WAVES_N) / 32;
+  constexpr int AR = BM / 32, BR = BNL / 32;
   static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
+  static_assert(!HALF || (WAVES_N == 1 && TM == 1), "half column block: waves stacked along M, one row block each");
   constexpr int LDR = BK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nbuf = p.nbuf;
   const int ntaps = p.nTd * p.nTh * p.nTw;
   float* As = reinterpret_cast<float*>(smem_raw);                 // [nbuf][BM][LDR]
-  float* Bs = As + nbuf * BM * LDR;                               // [nbuf][BN][LDR]
-  int2* taptab = reinterpret_cast<int2*>(Bs + nbuf * BN * LDR);    // [ntaps + 1] {validity bits the tap needs, input offset}
+  float* Bs = As + nbuf * BM * LDR;                               // [nbuf][BNL][LDR]
+  int2* taptab = reinterpret_cast<int2*>(Bs + nbuf * BNL * LDR);   // [ntaps + 1] {validity bits the tap needs, input offset}
   unsigned* rowaddr = reinterpret_cast<unsigned*>(taptab + ntaps + 1);   // [BM] byte offsets of the strided-output rows
-  float* red = reinterpret_cast<float*>(rowaddr + BM);            // [WAVES_M][BN][2] statistics scratch
-  unsigned* xch = reinterpret_cast<unsigned*>(red + WAVES_M * BN * 2);   // [4] the waves' tap masks
+  float* red = reinterpret_cast<float*>(rowaddr + BM);            // [WAVES_M][BNL][2] statistics scratch
+  unsigned* xch = reinterpret_cast<unsigned*>(red + WAVES_M * BNL * 2);  // [4] the waves' tap masks
   unsigned char* pblk = reinterpret_cast<unsigned char*>(xch + 4);       // copy of the argument block (see below)
 
   const int t = threadIdx.x;
@@ -1001,7 +1008,7 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const unsigned off = wrowoff[i] + k4;
-        float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;
+        float* dst = Bs + buf * BNL * LDR + i * 32 * LDR + wave * 64 * 4;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, off, 0, 0, 0);
       }
       const unsigned need = (1u << ukd) | (1u << (8 + ukh)) | (1u << (16 + ukw));
@@ -1024,7 +1031,7 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const unsigned off = (wrowoff[i] + k4) | kout;
-      float* dst = Bs + buf * BN * LDR + i * 32 * LDR + wave * 64 * 4;
+      float* dst = Bs + buf * BNL * LDR + i * 32 * LDR + wave * 64 * 4;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)dst, 16, off, 0, 0, 0);
     }
     const unsigned need = ctap < ntaps ? (unsigned)ctt.x : 0xffffffffu;      // (a lane past the last tap: never satisfied)
@@ -1044,6 +1051,7 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
   };
 
   floatx16 acc[TM][TN];
+  floatx4 acch[2];      // HALF: rows 16*blk + 4*(lane / 16) + r of the wave's 32, column 32*TN + lane % 16
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1051,6 +1059,10 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acch[bl][e] = 0.f;
   };
 
   // ---- epilogue of one unit ---------------------------------------------------------------------------------------------------
@@ -1113,6 +1125,14 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bvs[j]));
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int colh = q.n0 + TN * 32 + r16;      // HALF: this lane's column of the half block
+    const bool cokh = HALF && colh < vp.Cout;
+    float bvh = 0.f;
+    if (HALF) {
+      bvh = (vp.bias && !q.is_partial && cokh) ? vp.bias[colh] : 0.f;
+      asm volatile("" : "+v"(bvh));
+    }
     auto store_tile = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;      // 0 linear, 1 piecewise (two linear runs), 2 per-row table
 #pragma unroll
@@ -1149,6 +1169,25 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
             }
           }
       }
+      if (HALF) {
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int lrow = wm * WM + bl * 16 + g16 * 4 + k;      // local row of the tile
+            const float v = acch[bl][k] + bvh;
+            unsigned off;
+            if (MODE == 2) {
+              const unsigned a = rowaddr[lrow];
+              off = (cokh && a != 0xffffffffu) ? a + (unsigned)colh * 4u : 0x80000000u;
+            } else {
+              off = base4 + (unsigned)lrow * pitch4 + (unsigned)colh * 4u;
+              if (MODE == 1) off += lrow < pw_split ? 0u : pwD4;
+              if (!cokh || q.m0 + lrow >= vp.M) off = 0x80000000u;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off, 0, 0);
+          }
+      }
     };
     // statistics first: their barrier then waits for the (already landed) prefetch only, not for the tile's 64 stores per wave
     if (vp.stat && !q.is_partial) {
@@ -1170,8 +1209,27 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
         ss += __shfl_xor(ss, 32);
         if (h == 0) {
           const int c = wn * WN + j * 32 + l32;
-          red[(wm * BN + c) * 2 + 0] = s;
-          red[(wm * BN + c) * 2 + 1] = ss;
+          red[(wm * BNL + c) * 2 + 0] = s;
+          red[(wm * BNL + c) * 2 + 1] = ss;
+        }
+      }
+      if (HALF) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acch[bl][e];
+            s += v;
+            ss = fmaf(v, v, ss);
+          }
+        s += __shfl_xor(s, 16);
+        ss += __shfl_xor(ss, 16);
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (g16 == 0) {
+          red[(wm * BNL + TN * 32 + r16) * 2 + 0] = s;
+          red[(wm * BNL + TN * 32 + r16) * 2 + 1] = ss;
         }
       }
       __syncthreads();
@@ -1181,8 +1239,8 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
           float s = 0.f, ss = 0.f;
 #pragma unroll
           for (int w = 0; w < WPB; ++w) {
-            s += red[((sb * WPB + w) * BN + c) * 2 + 0];
-            ss += red[((sb * WPB + w) * BN + c) * 2 + 1];
+            s += red[((sb * WPB + w) * BNL + c) * 2 + 0];
+            ss += red[((sb * WPB + w) * BNL + c) * 2 + 1];
           }
           float* o = vp.stat + ((long long)(q.m_tile * SB + sb) * vp.stat_ld + q.n0 + c) * 2;
           o[0] = s;
@@ -1202,9 +1260,15 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
   // geometry is decoded before the fragment reads (the finished unit's loader registers are free by then), its first live chunk is
   // copied under this step's MFMAs — and the finished unit's epilogue behind the closing barrier.  A unit without a live chunk
   // (the very start; a K slice whose chunks are all padding) runs the boundary step without fragments or MFMAs.
-  auto read_frags = [&](int buf, floatx4 (&af)[4][TM], floatx4 (&bf)[4][TN]) {
+  // HALF: operands of the 16x16x4 blocks.  Lane (r = lane % 16, g = lane / 16) holds the 16-byte slots 2g, 2g + 1 of rows r and
+  // 16 + r of the wave's A rows and of row 32*TN + r of B: k-step (hh, e) multiplies the four k = 4 * (2g + hh) + e, g = 0..3.
+  // (The chunk's 32 k are summed in another order than by the 32x32x2 blocks; A and B agree, which is all a block needs.)
+  struct HalfFrag {
+    floatx4 a[2][2], b[2];
+  };
+  auto read_frags = [&](int buf, floatx4 (&af)[4][TM], floatx4 (&bf)[4][TN], HalfFrag& hf) {
     const float* a = As + buf * BM * LDR + (wm * WM + l32) * LDR;
-    const float* b = Bs + buf * BN * LDR + (wn * WN + l32) * LDR;
+    const float* b = Bs + buf * BNL * LDR + (wn * WN + l32) * LDR;
     const int swz = (l32 >> 1) & 7;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -1214,17 +1278,37 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[kk][j] = *reinterpret_cast<const floatx4*>(b + j * 32 * LDR + slot);
     }
+    if (HALF) {
+      const int r16 = lane & 15, g16 = lane >> 4;
+      const int swh = (r16 >> 1) & 7;      // (rows 16 + r and 32*TN + r swizzle like row r)
+      const float* ah = As + buf * BM * LDR + (wm * WM + r16) * LDR;
+      const float* bh = Bs + buf * BNL * LDR + (TN * 32 + r16) * LDR;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int slot = ((2 * g16 + hh) ^ swh) * 4;
+        hf.a[0][hh] = *reinterpret_cast<const floatx4*>(ah + slot);
+        hf.a[1][hh] = *reinterpret_cast<const floatx4*>(ah + 16 * LDR + slot);
+        hf.b[hh] = *reinterpret_cast<const floatx4*>(bh + slot);
+      }
+    }
   };
-  auto mfmas = [&](const floatx4 (&af)[4][TM], const floatx4 (&bf)[4][TN]) {
+  auto mfmas = [&](const floatx4 (&af)[4][TM], const floatx4 (&bf)[4][TN], const HalfFrag& hf) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i][e], bf[kk][j][e], acc[i][j], 0, 0, 0);
+        if (HALF && (kk & 1) == 0) {      // the half block's 8 k-steps, spread over the chunk's 16
+          const int hh = kk >> 1;
+#pragma unroll
+          for (int bl = 0; bl < 2; ++bl)
+            acch[bl] = __builtin_amdgcn_mfma_f32_16x16x4f32(hf.a[bl][hh][e], hf.b[hh][e], acch[bl], 0, 0, 0);
+        }
+      }
   };
   zero_acc();
   int u = wg - nwg;                      // the unit being computed (none yet)
@@ -1236,11 +1320,12 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
     // ---- all chunks of the current unit but the last
     while (have && ckc < ld_end) {
       floatx4 af[4][TM], bf[4][TN];
-      read_frags(buf, af, bf);
+      HalfFrag hf;
+      read_frags(buf, af, bf, hf);
       const int nb = nbuf == 1 ? 0 : buf ^ 1;
       if (nbuf == 1) __syncthreads();    // every wave holds its fragments: the buffer may be overwritten
       load_chunk(nb);
-      mfmas(af, bf);
+      mfmas(af, bf, hf);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       buf = nb;
@@ -1257,14 +1342,15 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
     const int nb = nbuf == 1 ? 0 : buf ^ 1;
     if (have) {
       floatx4 af[4][TM], bf[4][TN];
-      read_frags(buf, af, bf);
+      HalfFrag hf;
+      read_frags(buf, af, bf, hf);
       __syncthreads();                   // fragments held by every wave (single buffer); the waves' masks
       if (has_next) {
         walk_mask();
         next_have = ckc < ld_end;
         if (next_have) load_chunk(nb);
       }
-      mfmas(af, bf);
+      mfmas(af, bf, hf);
     } else {
       __syncthreads();
       if (has_next) {
@@ -1828,9 +1914,10 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS>
 int launch_persist_cfg(const IgemmParams& p, hipStream_t s) {
   constexpr int MINW = persist_minw(BN);
   const int ntaps = p.nTd * p.nTh * p.nTw;
+  constexpr int BNL = (BN + 31) / 32 * 32;      // (B tile rows in LDS: whole 32-row groups, igemm_persist)
   auto lds_of = [&](int nbuf, int taps) {
-    return (size_t)nbuf * (BM + BN) * BK * sizeof(float) + (size_t)(taps + 2) / 2 * sizeof(int4) + BM * sizeof(unsigned) +
-           (size_t)WAVES_M * BN * 2 * sizeof(float) + 4 * sizeof(unsigned) + sizeof(IgemmParams);
+    return (size_t)nbuf * (BM + BNL) * BK * sizeof(float) + (size_t)(taps + 2) / 2 * sizeof(int4) + BM * sizeof(unsigned) +
+           (size_t)WAVES_M * BNL * 2 * sizeof(float) + 4 * sizeof(unsigned) + sizeof(IgemmParams);
   };
   const size_t lds = lds_of(p.nbuf, ntaps);
   static bool attr_set = false;
@@ -1851,6 +1938,14 @@ int launch_persist_cfg(const IgemmParams& p, hipStream_t s) {
   return rsp_check_launch("igemm_persist_kernel");
 }
 
+// Segments of 129..144 columns: the 160-wide tile's plan (one N tile, same splits) on the instance whose fifth column block is 16
+// wide (igemm_persist, HALF).  RSP_NO_HALF_BLOCK=1: the 160-wide instance (A/B switch, read once).
+static bool half_block_cols(int cols) {
+  static const bool off = getenv("RSP_NO_HALF_BLOCK") != nullptr;
+  return !off && cols > 128 && cols <= 144;
+}
+static bool half_block(const IgemmParams& p) { return half_block_cols(p.Cout); }
+
 int launch_persist(IgemmParams& p, hipStream_t s) {
   const int bn = tile_bn_of(p);
   p.m_tiles = rsp_cdiv(p.M, 128);
@@ -1860,7 +1955,7 @@ int launch_persist(IgemmParams& p, hipStream_t s) {
   p.dNtl = fastdiv_make(p.n_tiles);
   if (p.kmajor) {
     switch (bn) {
-      case 160: return launch_persist_cfg<128, 160, 4, 1, true>(p, s);
+      case 160: return half_block(p) ? launch_persist_cfg<128, 144, 4, 1, true>(p, s) : launch_persist_cfg<128, 160, 4, 1, true>(p, s);
       case 128: return launch_persist_cfg<128, 128, 2, 2, true>(p, s);
       case 96: return launch_persist_cfg<128, 96, 4, 1, true>(p, s);
       case 64: return launch_persist_cfg<128, 64, 2, 2, true>(p, s);
@@ -1868,7 +1963,7 @@ int launch_persist(IgemmParams& p, hipStream_t s) {
     }
   }
   switch (bn) {
-    case 160: return launch_persist_cfg<128, 160, 4, 1, false>(p, s);
+    case 160: return half_block(p) ? launch_persist_cfg<128, 144, 4, 1, false>(p, s) : launch_persist_cfg<128, 160, 4, 1, false>(p, s);
     case 128: return launch_persist_cfg<128, 128, 2, 2, false>(p, s);
     case 96: return launch_persist_cfg<128, 96, 4, 1, false>(p, s);
     case 64: return launch_persist_cfg<128, 64, 2, 2, false>(p, s);
@@ -2571,7 +2666,7 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   if (vec4 && persist_enabled() && !long_tm128 && out_b < 0x7ffffff0ull) {
     if (ks) {
       switch (bn) {
-        case 160: return "igemm_persist_kernel<128, 160, 4, 1, true, 2>";
+        case 160: return half_block_cols(cols) ? "igemm_persist_kernel<128, 144, 4, 1, true, 2>" : "igemm_persist_kernel<128, 160, 4, 1, true, 2>";
         case 128: return "igemm_persist_kernel<128, 128, 2, 2, true, 3>";
         case 96: return "igemm_persist_kernel<128, 96, 4, 1, true, 3>";
         case 64: return "igemm_persist_kernel<128, 64, 2, 2, true, 4>";
@@ -2579,7 +2674,7 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
       }
     }
     switch (bn) {
-      case 160: return "igemm_persist_kernel<128, 160, 4, 1, false, 2>";
+      case 160: return half_block_cols(cols) ? "igemm_persist_kernel<128, 144, 4, 1, false, 2>" : "igemm_persist_kernel<128, 160, 4, 1, false, 2>";
       case 128: return "igemm_persist_kernel<128, 128, 2, 2, false, 3>";
       case 96: return "igemm_persist_kernel<128, 96, 4, 1, false, 3>";
       case 64: return "igemm_persist_kernel<128, 64, 2, 2, false, 4>";

@@ -349,8 +349,12 @@ __global__ void rowgeom_kernel(const RowGeomParams p) {
   p.out[r] = make_uint2((unsigned)(((((long long)n * p.Di + id0) * p.Hi + ih0) * p.Wi + iw0) * p.in_ld * 4), m);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// H16 (the 32-row tile only): at most 16 output channels are live — the 16-channel remainder of R(2+1)D's 144 mid channels, whose
+// launch walks all 1.6 M rows for them — and each wave's 32 x 32 block becomes two 16 x 16 blocks on v_mfma_f32_16x16x4_f32: half the
+// matrix-pipe time for the same operand tiles.  Lane (r = lane % 16, g = lane / 16): channel r, GEMM-k rows 4*s + g of the chunk.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool H16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) {
+  static_assert(!H16 || (BM == 32 && WAVES_M == 1 && BN / WAVES_N == 32), "H16: the 32-row tile, one 32-column block per wave");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int ACOLS = BM / 4, BCOLS = BN / 4;
@@ -446,6 +450,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  floatx4 acc16[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};      // H16: columns 16 j + r of the wave's 32
+  const int r16 = lane & 15, g16 = lane >> 4;
 
   const int nchunk = (row_end - row_begin + RK - 1) / RK;
   // Row chunks that cannot contribute to THIS k tile are skipped: the tile's taps span the kernel depths [kt_lo, kt_hi]; a chunk of
@@ -481,23 +487,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
     // adjacent floats: one ds_read_b64 instead of two ds_read_b32 (the epilogue undoes the interleave)
     typename FragVec<TM>::type af[RK / 2];
     typename FragVec<TN>::type bf[RK / 2];
+    float a16[RK / 4], b16[2][RK / 4];
+    if (H16) {
+      const float* ah = At + buf * RK * BM + r16;
+      const float* bh = Bt + buf * RK * BN + wn * WN + r16;
 #pragma unroll
-    for (int s2 = 0; s2 < RK / 2; ++s2) {
-      af[s2] = *reinterpret_cast<const typename FragVec<TM>::type*>(a + (2 * s2 + h) * BM);
-      bf[s2] = *reinterpret_cast<const typename FragVec<TN>::type*>(b + (2 * s2 + h) * BN);
+      for (int s4 = 0; s4 < RK / 4; ++s4) {
+        a16[s4] = ah[(4 * s4 + g16) * BM];
+        b16[0][s4] = bh[(4 * s4 + g16) * BN];
+        b16[1][s4] = bh[(4 * s4 + g16) * BN + 16];
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < RK / 2; ++s2) {
+        af[s2] = *reinterpret_cast<const typename FragVec<TM>::type*>(a + (2 * s2 + h) * BM);
+        bf[s2] = *reinterpret_cast<const typename FragVec<TN>::type*>(b + (2 * s2 + h) * BN);
+      }
     }
     fetch_rows(c_fetch, slot_fetch);
     // 2. next chunk's copies in flight under this chunk's MFMAs
     if (more) issue(c_issue, buf ^ 1);
     beside();
     // 3. MFMAs
+    if (H16) {
 #pragma unroll
-    for (int s2 = 0; s2 < RK / 2; ++s2)
+      for (int s4 = 0; s4 < RK / 4; ++s4)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < 2; ++j) acc16[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16[s4], b16[j][s4], acc16[j], 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FragVec<TM>::get(af[s2], i), FragVec<TN>::get(bf[s2], j), acc[i][j], 0, 0, 0);
+      for (int s2 = 0; s2 < RK / 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FragVec<TM>::get(af[s2], i), FragVec<TN>::get(bf[s2], j), acc[i][j], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     buf ^= 1;
@@ -531,6 +556,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p) 
   }
 
   float* dst = p.partial + (long long)z * p.Cout * p.Kld;
+  if (H16) {      // block j: element r of lane (r16, g16) is channel 4 * g16 + r, column 16 j + r16
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = k0 + wn * WN + 16 * j + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + 4 * g16 + r;
+        if (kc < p.Kld && co < p.Cout) dst[(long long)co * p.Kld + kc] = acc16[j][r];
+      }
+    }
+    return;
+  }
   const int k = k0 + wn * WN + TN * l32;   // TN adjacent columns per lane; Kld % 4 == 0 and k % TN == 0
   if (k < p.Kld) {
 #pragma unroll
@@ -620,19 +657,25 @@ int launch_w(const WgradParams& p, hipStream_t s) {
   return rsp_check_launch("wgrad_kernel");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool H16 = false>
 int launch_w_dma(const WgradParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * RK * (BM + BN) * sizeof(float) + 3 * RK * sizeof(uint2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N, H16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid((unsigned)(p.co_tiles * p.k_tiles) * (unsigned)p.splitm);
-  rsp_note_kernel("wgrad_dma_kernel<%d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N);
-  hipLaunchKernelGGL((wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds, s, p);
+  rsp_note_kernel(H16 ? "wgrad_dma_kernel<%d, %d, %d, %d, true>" : "wgrad_dma_kernel<%d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N);
+  hipLaunchKernelGGL((wgrad_dma_kernel<BM, BN, WAVES_M, WAVES_N, H16>), grid, dim3(256), lds, s, p);
   return rsp_check_launch("wgrad_dma_kernel");
+}
+
+// the 32-row tile with at most 16 live channels: two 16 x 16 blocks per wave (RSP_NO_HALF_BLOCK=1: the 32 x 32 block; read once)
+static bool wgrad_h16(int cout) {
+  static const bool off = getenv("RSP_NO_HALF_BLOCK") != nullptr;
+  return !off && cout <= 16;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -715,7 +758,7 @@ const char* rsp_wgrad_kernel_name(const rsp_conv3d_desc* d0) {
   const WPlan w = wplan(d);
   const bool dma = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && d->Cin % 4 == 0 && d->in_ld % 4 == 0 && d->kT <= 8 && d->kH <= 8 &&
                    d->kW <= 8;
-  if (w.bm == 32) return dma ? "wgrad_dma_kernel<32, 128, 1, 4>" : "wgrad_kernel<32, 128, 1, 4, *>";
+  if (w.bm == 32) return dma ? (wgrad_h16(d->Cout) ? "wgrad_dma_kernel<32, 128, 1, 4, true>" : "wgrad_dma_kernel<32, 128, 1, 4>") : "wgrad_kernel<32, 128, 1, 4, *>";
   if (dma) return w.bm == 128 ? (w.bn == 128 ? "wgrad_dma_kernel<128, 128, 2, 2>" : "wgrad_dma_kernel<128, 64, 2, 2>")
                               : (w.bn == 128 ? "wgrad_dma_kernel<64, 128, 2, 2>" : "wgrad_dma_kernel<64, 64, 2, 2>");
   return w.bm == 128 ? (w.bn == 128 ? "wgrad_kernel<128, 128, 2, 2, *>" : "wgrad_kernel<128, 64, 2, 2, *>")
@@ -958,7 +1001,7 @@ int wgrad_one(const rsp_conv3d_desc* d, const float* x, const float* dy, float* 
     }
     p.rowgeom = g.out;
   }
-  if (dma && w.bm == 32) rc = launch_w_dma<32, 128, 1, 4>(p, s);
+  if (dma && w.bm == 32) rc = wgrad_h16(p.Cout) ? launch_w_dma<32, 128, 1, 4, true>(p, s) : launch_w_dma<32, 128, 1, 4>(p, s);
   else if (w.bm == 32) rc = launch_w_vec<32, 128, 1, 4>(p, va, vb, s);
   else if (dma && w.bm == 128 && w.bn == 128) rc = launch_w_dma<128, 128, 2, 2>(p, s);
   else if (dma && w.bm == 128) rc = launch_w_dma<128, 64, 2, 2>(p, s);

@@ -60,6 +60,12 @@ CONV_CASES = [
     (2, 4, 9, 9, 64, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # 96-wide tile (4 waves along M); dgrad N = 64
     (2, 4, 9, 9, 96, 160, (3, 1, 1), (1, 1, 1), (1, 0, 0)),        # 160-wide tile forward, 96-wide tile in dgrad
     (1, 2, 7, 7, 160, 150, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # 150 columns in one 160-wide tile, K-split tail; dgrad N = 160
+    # 129..144 columns: the 144-wide tile (four 32-wide column blocks + one 16-wide block on the 16x16x4 MFMA) — 132 / 140 columns
+    # (ragged half block), whole rounds + K-split tail, strided (per-row output table in dgrad), depth-major rows with 144 columns
+    (2, 4, 12, 12, 64, 132, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (1, 4, 70, 80, 32, 144, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # 175 tiles, bias + statistics on every one
+    (2, 4, 9, 9, 144, 140, (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # dgrad classes with N = 144; forward 140 columns
+    (3, 4, 7, 7, 128, 144, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # slice-major K, depth-major rows (two linear runs per tile)
     # >= 768 tiles: the single-LDS-buffer mode of the 128- / 96-wide tiles (three workgroups per CU), with a K-split tail
     (1, 6, 130, 128, 16, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # 780 tiles of 128x128, K = 432
     (1, 6, 130, 128, 16, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 780 tiles of 128x96

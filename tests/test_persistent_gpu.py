@@ -23,6 +23,8 @@ CASES = {
     "piecewise_short_frames": (16, 4, 19, 11, 128, 32, (3, 1, 3), (1, 1, 1), (1, 0, 0)),
     "one_chunk": (8, 3, 7, 21, 4, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     "bn160": (4, 4, 14, 14, 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "bn160_dgrad": (4, 4, 14, 14, 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    "bn160_ks_depth_major": (3, 4, 7, 7, 128, 140, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "ksplit_tail": (32, 2, 7, 7, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "many_units_per_workgroup": (32, 8, 56, 56, 32, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     "ksplit_r3d_layer2": (32, 4, 14, 14, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
@@ -55,12 +57,17 @@ def _child(path):
 
 
 def test_persistent_kernels_equal_the_per_tile_kernels_bit_for_bit(tmp_path):
+    """... and the 144-wide instance (segments of 129..144 columns: a 16-wide fifth column block on the 16x16x4 MFMA, round 5) equals the
+    160-wide one bit for bit in its four 32-wide blocks and to rounding in the half block, whose k are summed in another order."""
     res = {}
-    for mode in ("persistent", "per_tile"):
+    for mode in ("persistent", "per_tile", "half"):
         env = dict(os.environ)
         env.pop("RSP_NO_PERSIST", None)
+        env.pop("RSP_NO_HALF_BLOCK", None)
         if mode == "per_tile":
             env["RSP_NO_PERSIST"] = "1"
+        if mode == "persistent":
+            env["RSP_NO_HALF_BLOCK"] = "1"      # the per-tile kernels' tiles: 160-wide
         f = str(tmp_path / f"{mode}.pt")
         subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
                                               f"import test_persistent_gpu as t; t._child({f!r})"], env=env, check=True, cwd=ROOT)
@@ -75,6 +82,19 @@ def test_persistent_kernels_equal_the_per_tile_kernels_bit_for_bit(tmp_path):
         assert torch.equal(sp, sc), (name, "BatchNorm partials", kfp)
         assert torch.equal(dp, dc), (name, "input gradient", kdp, float((dp - dc).abs().max()))
     assert ran_persistent >= 16, ran_persistent      # (the long tap-major 128-wide launches and multi-class dgrads stay per-tile)
+    ran_half = 0
+    for name in CASES:
+        yp, sp, dp, kfp, kdp = res["persistent"][name]
+        yh, sh, dh, kfh, kdh = res["half"][name]
+        for what, a, b, kern in (("forward", yp, yh, kfh), ("BatchNorm partials", sp.transpose(1, 2), sh.transpose(1, 2), kfh), ("input gradient", dp, dh, kdh)):
+            if "<128, 144," not in kern:
+                assert torch.equal(a, b), (name, what, kern)
+                continue
+            ran_half += 1
+            assert a.shape[-1] > 128 and torch.equal(a[..., :128], b[..., :128]), (name, what, "32-wide blocks")
+            tol = 2e-6 * float(a.abs().max())
+            assert float((a[..., 128:] - b[..., 128:]).abs().max()) <= tol, (name, what, "half block")
+    assert ran_half >= 7, ran_half
 
 
 def test_k_split_layers_are_run_to_run_identical():

@@ -26,14 +26,19 @@ SETS = {
               (32, 8, 28, 28, 64, 128, (1, 1, 1), (2, 2, 2)), (32, 4, 14, 14, 128, 256, (1, 1, 1), (2, 2, 2)),
               (32, 2, 7, 7, 256, 512, (1, 1, 1), (2, 2, 2))],
     "r3d": [(32, 4, 14, 14, 128, 128, (3, 3, 3)), (32, 2, 7, 7, 256, 256, (3, 3, 3)), (32, 1, 4, 4, 512, 512, (3, 3, 3))],
+    "wg": [(32, 16, 56, 56, 64, 144, (1, 3, 3)), (32, 16, 56, 56, 64, 128, (3, 3, 3)), (32, 8, 28, 28, 128, 288, (1, 3, 3)),
+           (32, 16, 56, 56, 144, 64, (3, 1, 1)), (32, 8, 28, 28, 128, 256, (3, 3, 3)), (32, 4, 14, 14, 256, 576, (1, 3, 3)),
+           (16, 8, 56, 56, 64, 192, (1, 3, 3)), (16, 8, 56, 56, 192, 192, (3, 1, 1)), (16, 8, 28, 28, 128, 192, (1, 3, 3)),
+           (32, 16, 56, 56, 64, 232, (1, 3, 3), (1, 2, 2)), (32, 8, 28, 28, 64, 64, (3, 3, 3))],
     "r21d": [(32, 4, 14, 14, 256, 576, (1, 3, 3)), (32, 4, 14, 14, 576, 256, (3, 1, 1)), (32, 2, 7, 7, 512, 1152, (1, 3, 3)),
              (32, 2, 7, 7, 1152, 512, (3, 1, 1))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+mode = sys.argv[2] if len(sys.argv) > 2 else "fwd"      # fwd | wgrad | dgrad
 cases = sum(SETS.values(), []) if which == "all" else SETS[which]
 be = ops.backend()
 dev = torch.device("cuda", 0)
-print("lib:", os.environ.get("RSPNET_HIP_LIB", "product"))
+print("lib:", os.environ.get("RSPNET_HIP_LIB", "product"), "mode:", mode)
 tot = 0.0
 for case in cases:
     N, D, H, W, cin, cout, k = case[:7]
@@ -43,12 +48,19 @@ for case in cases:
     x = torch.randn(N, D, H, W, cin, device=dev)
     w = torch.randn(cout, cin, *k, device=dev) * 0.05
     wp = be.conv_pack_fwd(g, w)
+    if mode == "fwd":
+        run = lambda: be.conv_fwd(g, x, wp, None, True)
+    else:
+        do, ho, wo = g.out_dims
+        dy = torch.randn(N, do, ho, wo, cout, device=dev)
+        dw = torch.empty_like(w)
+        run = (lambda: be.conv_wgrad(g, x, dy, dw, None)) if mode == "wgrad" else (lambda: be.conv_dgrad(g, dy, w))
     for _ in range(10):
-        be.conv_fwd(g, x, wp, None, True)
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(60):
-        be.conv_fwd(g, x, wp, None, True)
+        run()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 60 * 1e3
