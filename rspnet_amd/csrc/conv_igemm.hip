@@ -1804,15 +1804,40 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const rsp_pack_job* __r
   for (int c0 = 0; c0 < j.C; c0 += CH) {
     const int nc = min(CH, j.C - c0);
     __syncthreads();
-    for (int e = threadIdx.x; e < nc * T; e += 256) {
-      const int cl = e / T, t = e - cl * T;
-      const int c = c0 + cl;
-      tile[e] = (o_in && c < c_in) ? w[fbase + c * fstride + t] : 0.f;
+    // (indices advance by 256 elements per trip: one division per thread and chunk instead of two per element — the kernel was
+    //  bound by its index arithmetic at 2.3 TB/s)
+    const int nel = nc * T;
+    if (!j.transpose) {      // the filters of consecutive c follow each other in the source: one contiguous run
+      const float* __restrict__ src = w + fbase + (long long)c0 * T;
+      const int lim = o_in ? min(nel, max(0, c_in - c0) * T) : 0;      // elements of real (un-padded) channels
+      for (int e = threadIdx.x; e < nel; e += 256) tile[e] = e < lim ? src[e] : 0.f;
+    } else {
+      int cl = (int)threadIdx.x / T, t = (int)threadIdx.x - cl * T;
+      const int dcl = 256 / T, dt = 256 - dcl * T;
+      for (int e = threadIdx.x; e < nel; e += 256) {
+        const int c = c0 + cl;
+        tile[e] = (o_in && c < c_in) ? w[fbase + c * fstride + t] : 0.f;
+        cl += dcl;
+        t += dt;
+        if (t >= T) {
+          t -= T;
+          ++cl;
+        }
+      }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < j.ntaps * nc; e += 256) {
-      const int tap = e / nc, cl = e - tap * nc;
-      row[k_index(kmaj, tap, c0 + cl, j.C, j.ntaps)] = tile[cl * T + tsrc_of[tap]];
+    {
+      int tap = (int)threadIdx.x / nc, cl = (int)threadIdx.x - tap * nc;
+      const int dtap = 256 / nc, dcl = 256 - dtap * nc;
+      for (int e = threadIdx.x; e < j.ntaps * nc; e += 256) {
+        row[k_index(kmaj, tap, c0 + cl, j.C, j.ntaps)] = tile[cl * T + tsrc_of[tap]];
+        tap += dtap;
+        cl += dcl;
+        if (cl >= nc) {
+          cl -= nc;
+          ++tap;
+        }
+      }
     }
   }
   for (int k = j.ntaps * j.C + threadIdx.x; k < j.Kld; k += 256) row[k] = 0.f;
