@@ -210,6 +210,17 @@ int rsp_bn_act_pool_fwd(const rsp_pool3d_desc* d, const float* y, const float* s
 int rsp_bn_act_pool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, const float* residual,
                              int relu, const float* gate, float* out, void* stream);
 
+/* The ResNet stems' bn1 -> relu -> MaxPool3d(3, 2, 1) (models/resnet.py:139,203-207) — BatchNorm apply and an OVERLAPPING 3x3x3 or
+ * 1x3x3 max-pool (any stride / padding) in one pass over the convolution output: out = maxpool(act(scale*y + shift)); argmax
+ * (nullable) as rsp_maxpool3d_fwd writes it (first maximum in scan order, linear input position per sample), so that
+ * rsp_maxpool3d_bwd and then rsp_bn_act_pool_bwd (unit window) form its backward.  Bit-identical to rsp_bn_act_pool_fwd with a unit
+ * window followed by rsp_maxpool3d_fwd; the activated tensor is neither written nor read.  rsp_bn_act_pool_fwd takes this path
+ * itself for such windows (no residual).  Needs C, in_ld, out_ld multiples of 4 and 16-byte aligned pointers
+ * (rsp_bn_act_maxpool_applicable). */
+int rsp_bn_act_maxpool_applicable(const rsp_pool3d_desc* d);
+int rsp_bn_act_maxpool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, int relu, float* out, int32_t* argmax,
+                           void* stream);
+
 /* Backward of the fused block, two launches:
  *  reduce: per-channel partial sums of dz and dz*xhat (dz = grad at the BN output after pool routing + ReLU mask)
  *  apply : dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also d(residual) = dz (if dres != NULL),

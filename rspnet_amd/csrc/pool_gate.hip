@@ -81,8 +81,10 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 // KT/KH/KW > 0: window dims known at compile time — the tap loops unroll into straight-line code whose loads are all issued
 // before the first compare (an out-of-range tap reads a clamped, valid address and is masked to -inf), instead of one
 // load-compare round trip per tap behind three run-time loops with `continue`s.  KEEP = false (key-encoder passes): value only.
-template <bool KEEP, int KT, int KH, int KW>
-__global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) {
+// BN: the input is a convolution output and every loaded value first goes through the BatchNorm apply a = act(x * scale + shift)
+// (bn_maxpool_fwd_vec_kernel: the ResNet stems' bn1 -> relu -> MaxPool3d(3, 2, 1) in one pass, engine._pool_fusion).
+template <bool KEEP, int KT, int KH, int KW, bool BN>
+__device__ __forceinline__ void maxpool_fwd_vec_body(const MPParams& p, const float* __restrict__ ss, const int relu) {
   const rsp_pool3d_desc& d = p.d;
   const int C4 = d.C >> 2;
   const int kT = KT > 0 ? KT : d.kT, kH = KH > 0 ? KH : d.kH, kW = KW > 0 ? KW : d.kW;
@@ -113,6 +115,16 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) 
             lin[t] = ok ? l : -1;
             v[t] = *reinterpret_cast<const floatx4*>(xn + (long long)l * d.in_ld);
           }
+      if (BN) {
+        const floatx4 sc = *reinterpret_cast<const floatx4*>(ss + c), sh = *reinterpret_cast<const floatx4*>(ss + d.C + c);
+#pragma unroll
+        for (int t = 0; t < KT * KH * KW; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(v[t][e], sc[e], sh[e]);
+            v[t][e] = relu ? fmaxf(z, 0.f) : z;
+          }
+      }
 #pragma unroll
       for (int t = 0; t < KT * KH * KW; ++t) {
         if (KEEP) {
@@ -152,6 +164,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) 
     *reinterpret_cast<floatx4*>(p.out + o * d.out_ld + c) = best;
     if (KEEP) *reinterpret_cast<intx4*>(p.idx + o * d.C + c) = bi;
   }
+}
+template <bool KEEP, int KT, int KH, int KW>
+__global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) {
+  maxpool_fwd_vec_body<KEEP, KT, KH, KW, false>(p, nullptr, 0);
+}
+template <bool KEEP, int KT, int KH, int KW>
+__global__ __launch_bounds__(256) void bn_maxpool_fwd_vec_kernel(const MPParams p, const float* __restrict__ ss, const int relu) {
+  static_assert(KT > 0, "compile-time windows only");
+  maxpool_fwd_vec_body<KEEP, KT, KH, KW, true>(p, ss, relu);
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const MPParams p) {
@@ -727,6 +748,34 @@ int rsp_maxpool3d_fwd(const rsp_pool3d_desc* d, const float* x, float* out, int3
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * d->C)), dim3(256), 0,
                        (hipStream_t)stream, p);
   return rsp_check_launch("maxpool_fwd_kernel");
+}
+
+int rsp_bn_act_maxpool_applicable(const rsp_pool3d_desc* d) {
+  if (!mp_ok(d)) return 0;
+  const int kkk = d->kT * 100 + d->kH * 10 + d->kW;
+  return (kkk == 333 || kkk == 133) && d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 &&
+         (long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4) < (1ll << 31);
+}
+
+int rsp_bn_act_maxpool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, int relu, float* out, int32_t* argmax,
+                           void* stream) {
+  RSP_REQUIRE(rsp_bn_act_maxpool_applicable(d), "rsp_bn_act_maxpool_fwd: 3x3x3 / 1x3x3 windows, channels and pitches multiples of 4");
+  RSP_REQUIRE(y && scale_shift && out, "rsp_bn_act_maxpool_fwd: null pointer");
+  RSP_REQUIRE(rsp_aligned16(y) && rsp_aligned16(out) && rsp_aligned16(scale_shift) && (!argmax || rsp_aligned16(argmax)),
+              "rsp_bn_act_maxpool_fwd: pointers must be 16-byte aligned");
+  MPParams p;
+  memset(&p, 0, sizeof p);
+  p.d = *d; p.x = y; p.out = out; p.idx = argmax;
+  const dim3 grid(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4)));
+  hipStream_t st = (hipStream_t)stream;
+  if (d->kT == 3) {
+    if (argmax) hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<true, 3, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
+    else hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<false, 3, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
+  } else {
+    if (argmax) hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<true, 1, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
+    else hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<false, 1, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
+  }
+  return rsp_check_launch("bn_maxpool_fwd_vec_kernel");
 }
 
 int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t* argmax, float* dx, void* stream) {

@@ -447,6 +447,34 @@ def _gate_fusion(plan: "Plan"):
     return table
 
 
+def _pool_fusion(plan: "Plan"):
+    """{index of a ConvBN: index of the Pool that is the only reader of its output} — the ResNet stems (conv1 -> bn1 -> relu ->
+    MaxPool3d(3, 2, 1), models/resnet.py:124-139,203-207).  A forward that keeps nothing for a backward (the two key passes) applies
+    the BatchNorm and takes the window maximum in ONE pass over the convolution output (rsp_bn_act_pool_fwd takes any window): the
+    activated tensor — 411 MB per pass on R3D-18 — is neither written nor read back.  Same arithmetic per element, same bits."""
+    cached = getattr(plan, "_pool_fusion", None)
+    if cached is not None:
+        return cached
+    readers: Dict[int, List[int]] = {}
+    for i, n in enumerate(plan.nodes):
+        for m in (n.members if isinstance(n, ConvBNGroup) else [n]):
+            for slot in (getattr(m, "src", None), getattr(m, "residual", None)):
+                if slot is not None:
+                    readers.setdefault(slot, []).append(i)
+    table = {}
+    if not os.environ.get("RSP_NO_POOL_FUSION"):
+        gated = _gate_fusion(plan)
+        for i, n in enumerate(plan.nodes[:-1]):
+            q = plan.nodes[i + 1]
+            if not (isinstance(n, ConvBN) and isinstance(q, Pool) and q.src == n.dst and q.branch == n.branch) or i in gated:
+                continue
+            if n.pool or n.into is not None or n.cout_pad or n.dst == plan.output_slot or readers.get(n.dst) != [i + 1]:
+                continue
+            table[i] = i + 1
+    plan._pool_fusion = table
+    return table
+
+
 def _slice_of(slots, into, lead_shape, device):
     """Channel-slice view of a concat tensor, allocating the tensor on first use."""
     slot, off, total = into
@@ -489,10 +517,29 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
 
     slots: Dict[int, torch.Tensor] = {plan.input_slot: x}
     ctx = ForwardCtx(packed=packed) if keep else None
-    def bn_apply(node, y, ss, cg_cout, N, do, ho, wo, xin):
+    pool_fusion = _pool_fusion(plan)
+    skipped = set()
+
+    def bn_apply(node, y, ss, cg_cout, N, do, ho, wo, xin, key=None):
         pk, ps = node.pool if node.pool else ((1, 1, 1), (1, 1, 1))
         pg = PoolGeom(N, do, ho, wo, cg_cout, pk, ps, (0, 0, 0))
         res = slots[node.residual] if node.residual is not None else None
+        pi = pool_fusion.get(key) if key is not None else None
+        if pi is not None:      # the max-pool behind this unit taken by the kernel that applies the BatchNorm (_pool_fusion)
+            pnode = plan.nodes[pi]
+            pgf = PoolGeom(N, do, ho, wo, cg_cout, pnode.k, pnode.s, pnode.p)
+            if not keep:
+                slots[pnode.dst] = be.bn_act_pool_fwd(pgf, y, ss, res, node.relu)
+                skipped.add(pi)
+                return pgf, res
+            # kept for a backward: the same pass also writes the arg-max (the Pool node's saved state); the BatchNorm backward
+            # recomputes the activation from y as everywhere, so the activated tensor is never materialised
+            fused = be.bn_act_maxpool_fwd(pgf, y, ss, node.relu, True) if (res is None and hasattr(be, "bn_act_maxpool_fwd")) else None
+            if fused is not None:
+                slots[pnode.dst], idx = fused
+                ctx.saved[pi] = (pgf, idx)
+                skipped.add(pi)
+                return pg, res
         if node.into is not None:
             pdo, pho, pwo = pg.out_dims
             out = _view(_slice_of(slots, node.into, (N, pdo, pho, pwo), xin.device), node.into, cg_cout)
@@ -523,7 +570,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             parts.append(st)
         rows = N * do * ho * 2 * g
         mi, ss = finalize(node.bn, torch.cat(parts), rows, None)
-        pg, res, = bn_apply(node, y, ss, Cp, N, do, ho, 2 * g, xin)
+        pg, res, = bn_apply(node, y, ss, Cp, N, do, ho, 2 * g, xin, key)
         if keep:
             ctx.saved[key] = ("vstem", x_e, x_o, y, mi, ss, cg, pg, vs)
 
@@ -578,7 +625,7 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
                 ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, None)
                 ctx.saved[gi] = (a, mean, gate) if keep_act else ("fused", key, mean, gate)
             return
-        pg, res = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin)
+        pg, res = bn_apply(node, y, ss, cg.Cout, N, do, ho, wo, xin, key)
         if keep:
             ctx.saved[key] = _Saved(xin, y, mi, ss, cg, pg, res)
 
@@ -610,7 +657,6 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             ctx.saved[ni] = ("group", xin, y, cg, per)
 
     fusion = _gate_fusion(plan) if training else {}
-    skipped = set()
 
     def run_node(ni, node):
         if ni in skipped:

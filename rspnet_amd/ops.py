@@ -412,6 +412,23 @@ class HipOps:
         self._log_hbm("bn_act_pool_fwd", 4 * (n_in * (1 if residual is None else 2) + out.numel()), e0)
         return out
 
+    def bn_act_maxpool_fwd(self, pg: PoolGeom, y, scale_shift, relu: bool, keep: bool):
+        """BatchNorm apply (+ ReLU) and an OVERLAPPING max-pool (the ResNet stems' 3x3x3 / 2 / 1) in one pass over the convolution
+        output, with the arg-max a backward needs (keep) — (out, idx | None), or None when the shape is not covered
+        (rsp_bn_act_maxpool_applicable; the caller runs bn_act_pool_fwd + maxpool_fwd then).  Same bits as those two."""
+        in_ld = _rows_ld(y, "y")
+        do, ho, wo = pg.out_dims
+        d = pg.desc(in_ld=in_ld)
+        if not self.lib.rsp_bn_act_maxpool_applicable(C.byref(d)) or y.data_ptr() % 16 or scale_shift.data_ptr() % 16:
+            return None
+        out = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.float32, device=y.device)
+        idx = torch.empty((pg.N, do, ho, wo, pg.C), dtype=torch.int32, device=y.device) if keep else None
+        e0 = self._ev()
+        _lib.check(self.lib.rsp_bn_act_maxpool_fwd(C.byref(d), _ptr(y), _ptr(scale_shift), int(relu), _ptr(out), _ptr(idx), _stream()),
+                   "rsp_bn_act_maxpool_fwd")
+        self._log_hbm("bn_act_pool_fwd", 4 * (pg.N * pg.Di * pg.Hi * pg.Wi * pg.C + out.numel() * (2 if keep else 1)), e0)
+        return out, idx
+
     def bn_act_pool_bwd(self, pg: PoolGeom, y, residual, dout, gamma, mean_invstd, scale_shift, relu: bool,
                         want_dres: bool, dgamma_out, dbeta_out, dy_out=None):
         """dy_out: where to write dy (same channel pitch as y — a slice of a wider gradient tensor when y is a slice)."""

@@ -114,6 +114,13 @@ class Recorder:
         dy, _ = self.bn_act_pool_bwd(pg, y, None, dx, gamma, mean_invstd, scale_shift, relu, False, dgamma_out, dbeta_out)
         return dy
 
+    def bn_act_maxpool_fwd(self, pg, y, scale_shift, relu, keep):
+        """BatchNorm apply + overlapping max-pool in one pass (the ResNet stems) is recorded as the two primitives it stands for; the
+        fused device path is pinned to them bit for bit by tests/test_kernels_gpu.py (overlapping-window test)."""
+        from rspnet_amd.ops import PoolGeom
+        a = self.bn_act_pool_fwd(PoolGeom(pg.N, pg.Di, pg.Hi, pg.Wi, pg.C), y, scale_shift, None, relu)
+        return self.maxpool_fwd(pg, a, keep)
+
     def clip_gather_multi(self, jobs, T_out, c_out=None):
         """The step's three gathers in one launch are recorded as the single gathers they stand for; the fused device path is pinned
         to them bit for bit by tests/test_kernels_gpu.py::test_clip_gather."""

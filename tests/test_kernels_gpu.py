@@ -762,6 +762,30 @@ def test_bn_act_gate_fused_is_bit_identical_to_the_three_ops(hip, N, D, H, W, C,
     close(gate, gc, 2e-5, "gate")
 
 
+@pytest.mark.parametrize("N,D,H,W,C,k,s,p", [(2, 4, 12, 12, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (1, 5, 9, 11, 20, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                             (2, 3, 8, 8, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1))])
+def test_bn_act_pool_fwd_overlapping_window_equals_apply_then_maxpool(hip, N, D, H, W, C, k, s, p):
+    """The ResNet stems' bn1 -> relu -> MaxPool3d(3, 2, 1) (models/resnet.py:203-207) as ONE pass over the convolution output
+    (engine._pool_fusion, forwards that keep nothing): bn_act_pool_fwd with the overlapping, padded window against the unit-window
+    apply followed by maxpool_fwd — same bits; and against the checker."""
+    y = rnd(N, D, H, W, C, seed=61).to(DEV)
+    ss = torch.stack([rnd(C, seed=62).abs() + 0.5, rnd(C, seed=63) * 0.3]).contiguous().to(DEV)
+    a = hip.bn_act_pool_fwd(PoolGeom(N, D, H, W, C), y, ss, None, True)
+    pg = PoolGeom(N, D, H, W, C, k, s, p)
+    want, _ = hip.maxpool_fwd(pg, a, False)
+    got = hip.bn_act_pool_fwd(pg, y, ss, None, True)
+    assert got.shape == want.shape and torch.equal(got, want)
+    # ... and with the arg-max a backward needs (the kept forward): same values, same first-maximum indices
+    want_k, idx_k = hip.maxpool_fwd(pg, a, True)
+    fused = hip.bn_act_maxpool_fwd(pg, y, ss, True, True)
+    if C % 4 == 0:
+        assert fused is not None and torch.equal(fused[0], want_k) and torch.equal(fused[1], idx_k)
+        assert hip.bn_act_maxpool_fwd(pg, y, ss, True, False)[1] is None
+    else:
+        assert fused is None                      # (not covered: the caller runs the two ops)
+    close(got, CPU.bn_act_pool_fwd(pg, y.cpu(), ss.cpu(), None, True), 2e-6, "fused apply + overlapping max-pool")
+
+
 @pytest.mark.parametrize("N,D,H,W,C,sliced", [(2, 4, 12, 12, 64, False), (3, 2, 7, 7, 48, True), (2, 3, 9, 10, 6, False)])
 def test_bn_act_gate_bwd_fused_matches_the_two_ops(hip, N, D, H, W, C, sliced):
     """ops.bn_act_gate_bwd (activation recomputed from y, the gate's data gradient formed inside the BatchNorm backward kernels)

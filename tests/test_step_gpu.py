@@ -49,3 +49,43 @@ def test_wrapper_forward_ncdhw_matches_oracle():
     # train-mode BN side effect: running stats moved like the restatement's
     got = model.state_dict()["encoder_q.encoder.bn5b.running_mean"].cpu()
     assert float((got - sd["encoder_q.encoder.bn5b.running_mean"]).abs().max()) < 1e-5
+
+
+def test_resnet_stem_pool_fusion_changes_no_bit(monkeypatch):
+    """engine._pool_fusion: bn1 + relu + the 3x3x3/2 max-pool of the ResNet stem run as one kernel — without the arg-max in a forward
+    that keeps nothing (key passes), with it in the one a backward follows.  Against the three ops run apart (RSP_NO_POOL_FUSION=1):
+    same embeddings and, after a backward, the same stem gradients, bit for bit."""
+    from model_util import make_cfg
+    from oracle import portable as P
+    from golden_util import load_spec
+    from rspnet_amd import engine
+    from rspnet_amd.moco import ModelFactory
+    dev = torch.device("cuda", 0)
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("RSP_NO_POOL_FUSION", raising=False)
+        else:
+            monkeypatch.setenv("RSP_NO_POOL_FUSION", "1")
+        model = ModelFactory(make_cfg("resnet18", 64)).build_moco_diffloss(device=dev).module
+        state = P.fill_state(load_spec("resnet18"), 5)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+        enc = model.encoder_q
+        enc.train()
+        assert engine._pool_fusion(enc.plan()) == ({0: 1} if fused else {})
+        xn = enc._to_ndhwc(torch.from_numpy(P.clips(7, 0, (4, 3, 16, 64, 64))[0]).to(dev))
+        sd0 = {k: v.clone() for k, v in enc.state_dict().items()}
+        with torch.no_grad():
+            a0, m0, ctx0 = enc.forward_ndhwc(xn, keep=False)
+            enc.load_state_dict(sd0)                               # (running statistics back)
+            a1, m1, ctx1 = enc.forward_ndhwc(xn, keep=True)
+            assert ctx0 is None and ctx1 is not None and torch.equal(a0, a1) and torch.equal(m0, m1)
+            grads = {}
+
+            def grad_of(prm):
+                return grads.setdefault(id(prm), torch.zeros_like(prm))
+            enc.backward_ndhwc(ctx1, torch.ones_like(a1) * 0.01, torch.ones_like(m1) * -0.02, grad_of)
+        torch.cuda.synchronize()
+        out[fused] = (a0.clone(), m0.clone(), grads[id(enc.encoder.conv1.weight)].clone(), grads[id(enc.encoder.bn1.weight)].clone())
+    for x, y in zip(out[True], out[False]):
+        assert torch.equal(x, y)
