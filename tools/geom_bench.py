@@ -30,6 +30,7 @@ SETS = {
            (32, 16, 56, 56, 144, 64, (3, 1, 1)), (32, 8, 28, 28, 128, 256, (3, 3, 3)), (32, 4, 14, 14, 256, 576, (1, 3, 3)),
            (16, 8, 56, 56, 64, 192, (1, 3, 3)), (16, 8, 56, 56, 192, 192, (3, 1, 1)), (16, 8, 28, 28, 128, 192, (1, 3, 3)),
            (32, 16, 56, 56, 64, 232, (1, 3, 3), (1, 2, 2)), (32, 8, 28, 28, 64, 64, (3, 3, 3))],
+    "stem": [(32, 16, 112, 112, 4, 64, (3, 3, 3))],
     "r21d": [(32, 4, 14, 14, 256, 576, (1, 3, 3)), (32, 4, 14, 14, 576, 256, (3, 1, 1)), (32, 2, 7, 7, 512, 1152, (1, 3, 3)),
              (32, 2, 7, 7, 1152, 512, (3, 1, 1))],
 }
