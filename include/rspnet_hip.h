@@ -220,6 +220,11 @@ int rsp_bn_act_pool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const flo
 int rsp_bn_act_maxpool_applicable(const rsp_pool3d_desc* d);
 int rsp_bn_act_maxpool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, int relu, float* out, int32_t* argmax,
                            void* stream);
+/* ... with S3D-G's per-sample channel gates ([N][C], nullable) multiplied in between the activation and the pool (models/s3dg.py:105-108:
+ * the two front-end sep_conv units are followed by (1,3,3) / (1,2,2) max-pools): rsp_bn_gate_sums -> this, instead of
+ * rsp_bn_act_pool_gate_fwd (unit window) -> rsp_maxpool3d_fwd; same bits, and rsp_bn_act_pool_gate_fwd takes this path itself. */
+int rsp_bn_act_maxpool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, int relu, const float* gate, float* out,
+                                int32_t* argmax, void* stream);
 
 /* Backward of the fused block, two launches:
  *  reduce: per-channel partial sums of dz and dz*xhat (dz = grad at the BN output after pool routing + ReLU mask)

@@ -100,6 +100,7 @@ SIGNATURES = {
     "rsp_bn_act_pool_gate_fwd": (C.c_int, [_PP, _p, _p, _p, C.c_int, _p, _p, _p]),
     "rsp_bn_act_maxpool_applicable": (C.c_int, [_PP]),
     "rsp_bn_act_maxpool_fwd": (C.c_int, [_PP, _p, _p, C.c_int, _p, _p, _p]),
+    "rsp_bn_act_maxpool_gate_fwd": (C.c_int, [_PP, _p, _p, C.c_int, _p, _p, _p, _p]),
     "rsp_bn_bwd_workspace": (_sz, [_PP]),
     "rsp_bn_act_pool_bwd": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _p, _sz, _p]),
     "rsp_bn_act_pool_bwd_v": (C.c_int, [_PP, _p, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p, _p, _i32, _p, _sz, _p]),

@@ -1032,11 +1032,12 @@ int rsp_bn_act_pool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const flo
                              int relu, const float* gate, float* out, void* stream) {
   RSP_REQUIRE(pool_ok(d, false), "rsp_bn_act_pool_fwd: bad descriptor");
   RSP_REQUIRE(y && scale_shift && out, "rsp_bn_act_pool_fwd: null pointer");
-  // overlapping 3x3x3 / 1x3x3 windows without residual or gate (the ResNet stems): the sliding-window pooling body with the apply folded
+  // overlapping 3x3x3 / 1x3x3 windows without residual (the ResNet stems; S3D-G's gated front-end units): the pooling body with the apply folded
   // into its loads — all 27 loads of an output issued before the first compare — instead of the generic window loop below
-  if (!residual && !gate && (d->kT != d->sT || d->kH != d->sH || d->kW != d->sW || d->pT || d->pH || d->pW) &&
-      rsp_bn_act_maxpool_applicable(d) && rsp_aligned16(y) && rsp_aligned16(out) && rsp_aligned16(scale_shift))
-    return rsp_bn_act_maxpool_fwd(d, y, scale_shift, relu, out, nullptr, stream);
+  if (!residual && (d->kT != d->sT || d->kH != d->sH || d->kW != d->sW || d->pT || d->pH || d->pW) &&
+      rsp_bn_act_maxpool_applicable(d) && rsp_aligned16(y) && rsp_aligned16(out) && rsp_aligned16(scale_shift) &&
+      (!gate || rsp_aligned16(gate)))
+    return rsp_bn_act_maxpool_gate_fwd(d, y, scale_shift, relu, gate, out, nullptr, stream);
   PoolParams p;
   p.d = *d; p.y = y; p.ss = scale_shift; p.res = residual; p.gate = gate; p.out = out; p.relu = relu;
   const bool vec = d->C % 4 == 0 && d->in_ld % 4 == 0 && d->out_ld % 4 == 0 && rsp_aligned16(y) && rsp_aligned16(out) &&

@@ -84,7 +84,8 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 // BN: the input is a convolution output and every loaded value first goes through the BatchNorm apply a = act(x * scale + shift)
 // (bn_maxpool_fwd_vec_kernel: the ResNet stems' bn1 -> relu -> MaxPool3d(3, 2, 1) in one pass, engine._pool_fusion).
 template <bool KEEP, int KT, int KH, int KW, bool BN>
-__device__ __forceinline__ void maxpool_fwd_vec_body(const MPParams& p, const float* __restrict__ ss, const int relu) {
+__device__ __forceinline__ void maxpool_fwd_vec_body(const MPParams& p, const float* __restrict__ ss, const int relu,
+                                                     const float* __restrict__ gate = nullptr) {
   const rsp_pool3d_desc& d = p.d;
   const int C4 = d.C >> 2;
   const int kT = KT > 0 ? KT : d.kT, kH = KH > 0 ? KH : d.kH, kW = KW > 0 ? KW : d.kW;
@@ -124,6 +125,13 @@ __device__ __forceinline__ void maxpool_fwd_vec_body(const MPParams& p, const fl
             const float z = fmaf(v[t][e], sc[e], sh[e]);
             v[t][e] = relu ? fmaxf(z, 0.f) : z;
           }
+        if (gate) {      // S3D-G's self-gating between the activation and the pool (models/s3dg.py:105-108): per (sample, channel)
+          const floatx4 gt = *reinterpret_cast<const floatx4*>(gate + (long long)n * d.C + c);
+#pragma unroll
+          for (int t = 0; t < KT * KH * KW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[t][e] *= gt[e];
+        }
       }
 #pragma unroll
       for (int t = 0; t < KT * KH * KW; ++t) {
@@ -170,9 +178,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const MPParams p) 
   maxpool_fwd_vec_body<KEEP, KT, KH, KW, false>(p, nullptr, 0);
 }
 template <bool KEEP, int KT, int KH, int KW>
-__global__ __launch_bounds__(256) void bn_maxpool_fwd_vec_kernel(const MPParams p, const float* __restrict__ ss, const int relu) {
+__global__ __launch_bounds__(256) void bn_maxpool_fwd_vec_kernel(const MPParams p, const float* __restrict__ ss, const int relu,
+                                                                 const float* __restrict__ gate) {
   static_assert(KT > 0, "compile-time windows only");
-  maxpool_fwd_vec_body<KEEP, KT, KH, KW, true>(p, ss, relu);
+  maxpool_fwd_vec_body<KEEP, KT, KH, KW, true>(p, ss, relu, gate);
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const MPParams p) {
@@ -757,11 +766,12 @@ int rsp_bn_act_maxpool_applicable(const rsp_pool3d_desc* d) {
          (long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4) < (1ll << 31);
 }
 
-int rsp_bn_act_maxpool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, int relu, float* out, int32_t* argmax,
-                           void* stream) {
+int rsp_bn_act_maxpool_gate_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, int relu, const float* gate, float* out,
+                                int32_t* argmax, void* stream) {
   RSP_REQUIRE(rsp_bn_act_maxpool_applicable(d), "rsp_bn_act_maxpool_fwd: 3x3x3 / 1x3x3 windows, channels and pitches multiples of 4");
   RSP_REQUIRE(y && scale_shift && out, "rsp_bn_act_maxpool_fwd: null pointer");
-  RSP_REQUIRE(rsp_aligned16(y) && rsp_aligned16(out) && rsp_aligned16(scale_shift) && (!argmax || rsp_aligned16(argmax)),
+  RSP_REQUIRE(rsp_aligned16(y) && rsp_aligned16(out) && rsp_aligned16(scale_shift) && (!argmax || rsp_aligned16(argmax)) &&
+                  (!gate || rsp_aligned16(gate)),
               "rsp_bn_act_maxpool_fwd: pointers must be 16-byte aligned");
   MPParams p;
   memset(&p, 0, sizeof p);
@@ -769,13 +779,18 @@ int rsp_bn_act_maxpool_fwd(const rsp_pool3d_desc* d, const float* y, const float
   const dim3 grid(grid_for((long long)d->N * d->Do * d->Ho * d->Wo * (d->C / 4)));
   hipStream_t st = (hipStream_t)stream;
   if (d->kT == 3) {
-    if (argmax) hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<true, 3, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
-    else hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<false, 3, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
+    if (argmax) hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<true, 3, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu, gate);
+    else hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<false, 3, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu, gate);
   } else {
-    if (argmax) hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<true, 1, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
-    else hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<false, 1, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu);
+    if (argmax) hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<true, 1, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu, gate);
+    else hipLaunchKernelGGL((bn_maxpool_fwd_vec_kernel<false, 1, 3, 3>), grid, dim3(256), 0, st, p, scale_shift, relu, gate);
   }
   return rsp_check_launch("bn_maxpool_fwd_vec_kernel");
+}
+
+int rsp_bn_act_maxpool_fwd(const rsp_pool3d_desc* d, const float* y, const float* scale_shift, int relu, float* out, int32_t* argmax,
+                           void* stream) {
+  return rsp_bn_act_maxpool_gate_fwd(d, y, scale_shift, relu, nullptr, out, argmax, stream);
 }
 
 int rsp_maxpool3d_bwd(const rsp_pool3d_desc* d, const float* dout, const int32_t* argmax, float* dx, void* stream) {

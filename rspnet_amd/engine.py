@@ -447,6 +447,9 @@ def _gate_fusion(plan: "Plan"):
     return table
 
 
+GATE_POOL_APART = bool(os.environ.get("RSP_NO_GATE_POOL_KEEP"))      # (A/B switch: the kept forward of a gated unit runs its max-pool apart)
+
+
 def _pool_fusion(plan: "Plan"):
     """{index of a ConvBN: index of the Pool that is the only reader of its output} — the ResNet stems (conv1 -> bn1 -> relu ->
     MaxPool3d(3, 2, 1), models/resnet.py:124-139,203-207).  A forward that keeps nothing for a backward (the two key passes) applies
@@ -605,16 +608,26 @@ def run_forward(plan: Plan, x: torch.Tensor, packed: PackedWeights, keep: bool, 
             # passes over y: see _gate_fusion
             gi, pi = gated
             gnode = plan.nodes[gi]
-            pnode = plan.nodes[pi] if (pi is not None and not keep) else None
+            pnode = plan.nodes[pi] if pi is not None else None
             pg = PoolGeom(N, do, ho, wo, cg.Cout)
-            out = None
-            if gnode.into is not None:
-                out = _view(_slice_of(slots, gnode.into, (N, do, ho, wo), xin.device), gnode.into, cg.Cout)
             pool = PoolGeom(N, do, ho, wo, cg.Cout, pnode.k, pnode.s, pnode.p) if pnode is not None else None
             # (a backward recomputes the activation from y: nothing but the (sample, channel) means and gates is kept)
             keep_act = keep and not GATE_BWD_FUSED
-            o, a, mean, gate = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, keep_act, pool=pool,
-                                                  out=out)
+            # a forward a backward follows pools in the same pass only if that pass can also write the pool's arg-max
+            with_idx = (keep and pool is not None and not keep_act and getattr(be, "gate_pool_keep", False) and not GATE_POOL_APART
+                        and be.bn_act_gate_pool_idx_ok(pool, y, ss))
+            if keep and not with_idx:
+                pnode = pool = None
+            out = None
+            if gnode.into is not None:
+                out = _view(_slice_of(slots, gnode.into, (N, do, ho, wo), xin.device), gnode.into, cg.Cout)
+            if with_idx:
+                o, a, mean, gate, idx = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, False,
+                                                           pool=pool, out=out, pool_idx=True)
+                ctx.saved[pi] = (pool, idx)
+            else:
+                o, a, mean, gate = be.bn_act_gate_fwd(pg, y, ss, node.relu, gnode.conv.weight.data, gnode.conv.bias.data, keep_act,
+                                                      pool=pool, out=out)
             if pnode is not None:
                 slots[pnode.dst] = o
                 skipped.add(pi)

@@ -485,8 +485,10 @@ class HipOps:
                    "rsp_gate_fwd")
         return out, mean, gate
 
+    gate_pool_keep = True      # bn_act_gate_fwd(pool=..., pool_idx=True): the pooled form can also write the pool's arg-max
+
     def bn_act_gate_fwd(self, pg: PoolGeom, y, scale_shift, relu: bool, w, b, keep_act: bool, pool: Optional[PoolGeom] = None,
-                        out=None):
+                        out=None, pool_idx: bool = False):
         """BatchNorm-apply (+ReLU) and the self-gating unit behind it as one op (models/s3dg.py:52-72; pg: the unit-window
         geometry of y).  a = act(y*scale + shift); gate = sigmoid(W mean(a) + b); out = a * gate — through `pool` (a max-pool
         geometry over a's dims, models/s3dg.py:105-109) when given.  keep_act: also materialise a for the backward (then no pool).
@@ -509,11 +511,24 @@ class HipOps:
         if keep_act:
             _lib.check(self.lib.rsp_gate_apply(_ptr(a), N, P, Cc, Cc, _ptr(gate), _ptr(out), _rows_ld(out, "out"), _stream()),
                        "rsp_gate_apply")
+        elif pool_idx:
+            # the pooled form for a forward a backward follows: the max-pool's arg-max written by the same pass (returned fifth);
+            # the caller has checked bn_act_gate_pool_idx_ok
+            d, dref, _, _ = _pool_plan(0, og, y_ld, _rows_ld(out, "out"), None)
+            idx = torch.empty(tuple(out.shape), dtype=torch.int32, device=y.device)
+            _lib.check(self.lib.rsp_bn_act_maxpool_gate_fwd(dref, _ptr(y), _ptr(scale_shift), int(relu), _ptr(gate), _ptr(out), _ptr(idx),
+                                                            _stream()), "rsp_bn_act_maxpool_gate_fwd")
+            return out, a, mean, gate, idx
         else:
             d, dref, _, _ = _pool_plan(0, og, y_ld, _rows_ld(out, "out"), None)
             _lib.check(self.lib.rsp_bn_act_pool_gate_fwd(dref, _ptr(y), _ptr(scale_shift), None, int(relu), _ptr(gate), _ptr(out),
                                                          _stream()), "rsp_bn_act_pool_gate_fwd")
         return out, a, mean, gate
+
+    def bn_act_gate_pool_idx_ok(self, pool: PoolGeom, y, scale_shift) -> bool:
+        """Whether bn_act_gate_fwd(pool=pool, pool_idx=True) is available for this shape (rsp_bn_act_maxpool_applicable)."""
+        d = pool.desc(in_ld=_rows_ld(y, "y"))
+        return bool(self.lib.rsp_bn_act_maxpool_applicable(C.byref(d))) and y.data_ptr() % 16 == 0 and scale_shift.data_ptr() % 16 == 0
 
     def bn_act_gate_bwd(self, pg: PoolGeom, y, dout, gamma, mean_invstd, scale_shift, relu: bool, w, mean, gate,
                         dgamma_out, dbeta_out, dw_out, db_out):

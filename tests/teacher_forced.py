@@ -74,6 +74,7 @@ def _pool_unsafe(z_ncdhw, pg, relu):
 class Recorder:
     """Op backend that forwards to `inner` and records each call."""
     name = "recorder"
+    gate_pool_keep = False         # (the kept forward of a gated front-end unit is recorded as its primitives: pool apart)
 
     def __init__(self, inner):
         self.inner = inner

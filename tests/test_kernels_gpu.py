@@ -756,6 +756,14 @@ def test_bn_act_gate_fused_is_bit_identical_to_the_three_ops(hip, N, D, H, W, C,
         p_ref, _ = hip.maxpool_fwd(pp, o_ref, False)
         p3, _, _, _ = hip.bn_act_gate_fwd(pg, y, ss, True, w, b, False, pool=pp)
         assert torch.equal(p3, p_ref)
+        # ... and for a forward a backward follows: the pool's arg-max from the same pass (first maximum in scan order)
+        if hip.bn_act_gate_pool_idx_ok(pp, y, ss):
+            assert C % 4 == 0
+            p_k, i_k = hip.maxpool_fwd(pp, o_ref, True)
+            p4, a4, m4, g4, i4 = hip.bn_act_gate_fwd(pg, y, ss, True, w, b, False, pool=pp, pool_idx=True)
+            assert a4 is None and torch.equal(p4, p_k) and torch.equal(i4, i_k) and torch.equal(m4, mean_ref) and torch.equal(g4, gate_ref)
+        else:
+            assert C % 4 != 0
     # and the checker agrees to rounding
     oc, ac, mc, gc = CPU.bn_act_gate_fwd(pg, y.cpu(), ss.cpu(), True, w.cpu(), b.cpu(), True)
     close(o, oc, 2e-5, "gated output")
