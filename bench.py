@@ -79,6 +79,7 @@ def parse_args(argv=None):
                          "for this (seeded, hence identical) state from profiles/grad_floor.json after checking an input fingerprint")
     ap.add_argument("--eager-steps", type=int, default=10,
                     help="N=1 graphed runs: also time this many eagerly issued steps (the way N > 1 issues them) after the timed region")
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic state and clips (the default run's is 1234)")
     ap.add_argument("--selftest-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--selftest-parity", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-cpu", action="store_true",
@@ -375,14 +376,14 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     K = args.queue // (B * ws) * (B * ws)                  # utils/moco.py:8-10 trim
     cfg = {"model": {"arch": arch},
            "moco": {"dim": 128, "k": K, "m": 0.999, "t": 0.07, "fc_type": "linear", "diff_speed": [2]}}
-    torch.manual_seed(1234)
+    torch.manual_seed(args.seed)
     model = ModelFactory(cfg).build_moco_diffloss(device=dev, force_collectives=True if args.force_dp else None)
     model.train()
     coll = bool(model.module._dp()[2])
     crit = Loss(margin=2.0, A=1.0, M=1.0)
     lr = base_lr * ws * B / 64                            # framework/utils/environment.py:13-16
     opt = SGD(model.parameters(), lr=lr, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=False)  # pretrain.py:65-72
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    g = torch.Generator(device=dev).manual_seed(args.seed + rank)
     im_q = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
     im_k = torch.randn(B, 3, 32, hw, hw, device=dev, generator=g)
 
@@ -448,6 +449,19 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
     gc.freeze()
     fence()
     graphed = stepper is not None and not stepper.disabled and len(stepper.graphs) > 0
+    if graphed and cuda:
+        # where the GPU's time of a replayed step goes: a few steps with an event pair around every graph (outside the timed region)
+        stepper.segment_gpu_events = []
+        for _ in range(3):
+            step()
+        fence()
+        gev, stepper.segment_gpu_events = stepper.segment_gpu_events, None
+        seg_gpu = {}
+        for name, e0, e1 in gev:
+            seg_gpu.setdefault(name, []).append(e0.elapsed_time(e1))
+        seg_gpu = {k: round(_pct(v, 0.5), 3) for k, v in seg_gpu.items()}
+    else:
+        seg_gpu = None
     # (per-launch events are not recorded in the timed region: a replayed graph has none, and the eager step runs its independent
     #  passes on side streams, where a launch's interval also holds its neighbours' time — see the roofline pass below)
     if coll:
@@ -549,6 +563,8 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
                                    "queue (device synchronised before each of 5 samples): what the host itself needs per step"}
         if seg_host:
             res["steps_ms"]["segment_host_p50"] = {k: round(_pct(v, 0.5), 3) for k, v in seg_host.items()}
+        if seg_gpu:
+            res["steps_ms"]["segment_gpu_p50"] = seg_gpu      # lane:graph -> ms on its own stream (graphs of different lanes overlap)
     if comm:
         # per-rank stall of the compute stream behind each collective, ms per step (this rank)
         cm = {}
@@ -805,6 +821,20 @@ def run_rank(args):
             except Exception as e:      # noqa: BLE001 - reported in the line, never fatal for the headline
                 others[arch] = {"error": f"{type(e).__name__}: {e}"[:400]}
         res["other_workloads"] = others
+        # BASELINE configs 3-5 as FLAT scalars as well: top-level keys, and once more inside the roofline object (a reader that keeps
+        # only the contract's keys and objects still holds the three numbers per workload)
+        flat = {}
+        for arch, key in (("resnet18", "resnet18"), ("r2plus1d-vcop", "r2plus1d"), ("s3dg", "s3dg")):
+            o = others.get(arch) or {}
+            if "error" in o or "clips_per_s" not in o:
+                continue
+            flat[f"{key}_clips_per_s"] = o["clips_per_s"]
+            flat[f"{key}_ms_per_step"] = o["ms_per_step"]
+            flat[f"{key}_whole_step_frac"] = o["whole_step_frac"]
+            flat[f"{key}_dominant_kernel_frac"] = o["dominant_kernel_frac"]
+        res.update(flat)
+        if "roofline" in res:
+            res["roofline"]["other_workloads"] = dict(flat)
         res["dp_path_at_one_rank"] = dp_child("c3d", res["value"])
         # the N = 1 number in the issue mode the N > 1 points of a scaling curve use: efficiency is never computed across modes
         dp1 = res["dp_path_at_one_rank"]

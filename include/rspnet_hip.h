@@ -139,10 +139,15 @@ double rsp_conv3d_executed_fraction(const rsp_conv3d_desc* d, int which);
 /* Planning options of the convolution launchers, settable at run time (process-wide; host arithmetic only: which kernel instance and
  * which K split a descriptor gets — every choice computes the same convolution, in another summation order).  Returns the previous
  * value, or RSP_EINVAL for an unknown name.
- *   "narrow_max_tiles"  launches of fewer than this many 128-wide tiles (and 97..128 or > 160 columns) run on the 64-wide tile
- *                       (default 512, environment RSP_NARROW_MAX_TILES; 0: never; < 0: back to the default).
- * The whole-step parity tests use it to evaluate a fixture under TWO valid tile plans: a state whose gradient moves by percents
- * between them holds ReLU / max-pool decisions within rounding of a knife edge (tests/golden_util.py). */
+ *   "narrow_max_tiles"    launches of fewer than this many 128-wide tiles (and 97..128 or > 160 columns) run on the 64-wide tile
+ *                         (default 512, environment RSP_NARROW_MAX_TILES; 0: never; < 0: back to the default).
+ *   "narrow32_max_units"  launches of at most this many 128 x 64 tiles (more than 32 columns, K of at least 8 chunks) run on the
+ *                         32-wide tile with the whole K per unit instead of a K split + reduce launch (default 256, environment
+ *                         RSP_NARROW32_MAX_UNITS; 0: never; < 0: back to the default).
+ *   "tall_min_tiles"      33..64-column launches of at least this many 256-row tiles run on the 256 x 64 instance of the persistent
+ *                         kernel (default 768 = one round, environment RSP_TALL_MIN_TILES; 0: never; < 0: back to the default).
+ * Used by the kernel tests (an instance at sizes the checker finishes in seconds) and by tools/geom_bench.py (A/B of a plan in one
+ * process).  The whole-step parity tests run under the DEFAULT plan only. */
 int rsp_conv3d_set_option(const char* name, int32_t value);
 
 /* Host evaluation of the constant division the conv kernels use to decode GEMM rows and k positions (multiply-high by a

@@ -45,7 +45,8 @@ def measure(tag, seed, meta=None, spec=None, fast=False, ws=1):
     if meta is None:
         z = np.load(os.path.join(GOLDEN, G.case_name(tag, ws, seed) + ".npz"))
         meta = json.loads(str(z["meta"]))
-    state, mom, clips, perms_B, sh = G.case_inputs(spec, tag, meta["B"], meta["HW"], meta["K"], ws, seed)
+        meta["nudges"] = G.nudges_from_npz(z)
+    state, mom, clips, perms_B, sh = G.case_inputs(spec, tag, meta["B"], meta["HW"], meta["K"], ws, seed, meta.get("nudges"))
 
     import contextlib
 

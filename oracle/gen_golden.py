@@ -1,7 +1,8 @@
 """Generate tests/golden/*.npz from the REAL reference.  TEST INFRASTRUCTURE ONLY.
 
 Run in the build container only:  ``python -m oracle.gen_golden``  (needs /root/reference).
-Every fixture is *data*: inputs are re-derived from ``oracle/portable.py`` seeds, the file keeps the
+Every fixture is *data*: inputs are re-derived from ``oracle/portable.py`` seeds (plus the fixture's guard band: the BatchNorm
+bias values oracle/guard.py moved away from ReLU knife edges, kept in the file), the file keeps the
 reference's outputs for one teacher-forced pretext step (free-running trajectories
 are chaotic, so each "step" is its own seeded pre-step state with non-zero SGD momentum buffers,
 non-zero queue_ptr and non-trivial BN running stats).
@@ -40,17 +41,6 @@ CASES = [
     ("c3d:linear:4", 4, 32, 64, (1, 2), 1),
     ("c3d:linear:1", 4, 32, 64, (1,), 1),
 ]
-# see ref_harness.run_reference_step "knife-edge guard"; the wide (921/1152-channel) R(2+1)D and S3D-G late layers
-# have too many elements for 1e-5 to be findable, 3e-6 is still > the ~1e-6 rounding band of z.
-DEFAULT_MARGIN = 3e-6
-MARGIN_BY_ARCH = {}
-# Conditioning screen (on top of the margin guard) for the deeper BasicBlock stacks, whose forward values differ by ~1e-5
-# between correct fp32 implementations: a seed is kept only if the oracle restatement evaluated in two other fp32 orders
-# (native convolution; folded scale/shift BatchNorm with fp32 statistics partials — oracle/gen_conditioning.py) reproduces the
-# default run's gradients to SCREEN_TOL, i.e. no ReLU / arg-max of a small late layer is decided by rounding.  The screen
-# only uses CPU evaluations of the oracle, never a GPU result.
-SCREEN_ARCHS = ()          # (tried for resnet34: none of 24 seeds passes both the margin guard and this screen)
-SCREEN_TOL = 5e-3
 LR = 0.05
 T_IN = 32
 
@@ -75,9 +65,14 @@ def case_name(arch, ws, seed):
     return f"{tag_file(arch)}_ws{ws}_s{seed}"
 
 
-def case_inputs(spec, arch, B, HW, K, ws, seed):
-    """Everything a consumer needs to replay the step: state, momentum, clips, permutations."""
+def case_inputs(spec, arch, B, HW, K, ws, seed, nudges=None):
+    """Everything a consumer needs to replay the step: state, momentum, clips, permutations.  `nudges`: the fixture's guard band
+    (oracle/guard.py: {bias key: (channel indices, values)} written over fill_state's draw; tests/golden_util.py:load_case puts
+    the fixture's into meta["nudges"])."""
     state = P.fill_state(spec, seed)
+    if nudges:
+        for key, (idx, val) in nudges.items():
+            state[key][np.asarray(idx, dtype=np.int64)] = np.asarray(val, dtype=np.float32)
     state["queue_ptr"][:] = (B * ws * (seed % 3 + 1)) % K
     tk = [k for k in spec if k.startswith("encoder_q.") and not k.endswith(
         ("running_mean", "running_var", "num_batches_tracked"))]
@@ -113,6 +108,20 @@ def pack(res: Dict, rank: int, out: Dict[str, np.ndarray]):
         out[pre + "momproj." + k] = P.projections(k, v)
 
 
+def nudges_from_npz(z):
+    """{bias key: (indices, values)} of a fixture file's guard band (oracle/guard.py), or {}."""
+    pre = "nudge.idx."
+    return {name[len(pre):]: (np.asarray(z[name]), np.asarray(z["nudge.val." + name[len(pre):]])) for name in z.files if name.startswith(pre)}
+
+
+def _load_nudges(tmpdir):
+    path = os.path.join(tmpdir, "nudges.npz")
+    if not os.path.exists(path):
+        return None
+    with np.load(path) as z:
+        return nudges_from_npz(z)
+
+
 def _worker(rank, ws, arch, B, HW, K, seed, port, tmpdir):
     import torch
     from oracle import ref_harness as R
@@ -120,16 +129,34 @@ def _worker(rank, ws, arch, B, HW, K, seed, port, tmpdir):
     R.ensure_process_group(rank, ws, port)
     model = R.build_reference_model(split_arch(arch)[0], K=K, fc_type=split_arch(arch)[1])
     spec = R.state_spec(model)
-    state, mom, clips, perms_B, sh = case_inputs(spec, arch, B, HW, K, ws, seed)
+    state, mom, clips, perms_B, sh = case_inputs(spec, arch, B, HW, K, ws, seed, _load_nudges(tmpdir))
     res = R.run_reference_step(model, state, clips[rank][0], clips[rank][1], [perms_B[rank], sh[0], sh[1]],
                                tag_speed(arch), lr=LR, momentum_buffers=mom, ddp=(ws > 1))
     out: Dict[str, np.ndarray] = {}
     pack(res, rank, out)
     out[f"r{rank}.relu_margin"] = np.array(res["relu_margin"])
+    out[f"r{rank}.pool_margin"] = np.array(res["pool_margin"])
     np.savez(os.path.join(tmpdir, f"r{rank}.npz"), **out)
     if rank == 0:
         with open(os.path.join(tmpdir, "spec.json"), "w") as f:
             json.dump({k: [list(s), d] for k, (s, d) in spec.items()}, f)
+
+
+def reference_spec(arch, K):
+    from oracle import ref_harness as R
+    model = R.build_reference_model(split_arch(arch)[0], K=K, fc_type=split_arch(arch)[1])
+    return dict(R.state_spec(model))
+
+
+def guard_for(arch, spec, B, HW, K, ws, seed, verbose=False):
+    """The guard band of one case (oracle/guard.py): settled on the restatement's fp64 query pass of every rank."""
+    import torch
+    from oracle import guard
+    from oracle import restatement as S
+    state, _, clips, perms_B, _ = case_inputs(spec, arch, B, HW, K, ws, seed)
+    q = [S.diff_speed(torch.from_numpy(clips[r][0]), torch.from_numpy(clips[r][1]), torch.from_numpy(perms_B[r]), tag_speed(arch))[0].numpy()
+         for r in range(ws)]
+    return guard.guard_band(split_arch(arch)[0], split_arch(arch)[1], state, q, verbose=verbose)
 
 
 def checker_grad_error(arch, meta, spec, out):
@@ -141,7 +168,7 @@ def checker_grad_error(arch, meta, spec, out):
     from cpu_ops import CpuOps
     from model_util import run_model_step
     from rspnet_amd import ops
-    inputs = case_inputs(spec, arch, meta["B"], meta["HW"], meta["K"], 1, meta["seed"])
+    inputs = case_inputs(spec, arch, meta["B"], meta["HW"], meta["K"], 1, meta["seed"], meta.get("nudges"))
     prev = ops.set_backend(CpuOps())
     try:
         _, _, _, grads = run_model_step(arch, meta, inputs, 0, torch.device("cpu"), "fused")
@@ -155,11 +182,14 @@ def checker_grad_error(arch, meta, spec, out):
     return worst
 
 
-def run_case(arch, B, HW, K, ws, seed):
+def run_case(arch, B, HW, K, ws, seed, nudges=None):
     import torch.multiprocessing as mp
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:
         port = _free_port()
+        if nudges:
+            np.savez(os.path.join(tmp, "nudges.npz"), **{f"nudge.idx.{k}": v[0] for k, v in nudges.items()},
+                     **{f"nudge.val.{k}": v[1] for k, v in nudges.items()})
         mp.spawn(_worker, args=(ws, arch, B, HW, K, seed, port, tmp), nprocs=ws, join=True)
         out: Dict[str, np.ndarray] = {}
         for r in range(ws):
@@ -167,10 +197,33 @@ def run_case(arch, B, HW, K, ws, seed):
                 out.update({k: z[k] for k in z.files})
         with open(os.path.join(tmp, "spec.json")) as f:
             spec = json.load(f)
+    for k, (idx, val) in (nudges or {}).items():
+        out[f"nudge.idx.{k}"] = np.asarray(idx, dtype=np.int32)
+        out[f"nudge.val.{k}"] = np.asarray(val, dtype=np.float32)
     out["meta"] = np.array(json.dumps(dict(arch=split_arch(arch)[0], fc_type=split_arch(arch)[1], B=B, HW=HW, K=K, ws=ws, seed=seed, lr=LR, speed=tag_speed(arch),
                                            T_in=T_IN, m=0.999, T=0.07, sgd_momentum=0.9, weight_decay=1e-4,
                                            margin=2.0, A=1.0, M=1.0)))
     return out, spec
+
+
+# Seed acceptance (on top of the guard band, which every seed gets):
+#   * the band holds in the REFERENCE's own fp32 forward: smallest |ReLU input| / channel sigma >= RELU_CHECK (asserted);
+#   * max-pool arg-max of the small disjoint-window layers: top-2 gap >= POOL_MARGIN (a bias cannot open it: seed selection);
+#   * the ranking hinge max(0, margin - (p - n)) is not within HINGE_MARGIN of its kink for any sample;
+#   * conditioning screen: the oracle restatement evaluated in two other fp32 orders (native convolution; folded scale/shift
+#     BatchNorm with fp32 statistics partials) and the product's host logic on the torch checker backend reproduce the
+#     fixture's gradients to SCREEN_TOL (worst tensor, relative L2).  What is left after the guard band are arg-max decisions
+#     of the overlapping / large-layer pools; the screen keeps the seeds on which none of them sits within rounding of a tie.
+#     Only CPU evaluations of the oracle and of the reference take part, never a GPU result.
+# The first seed that meets all of them is kept; if none of MAX_SEEDS does, the one with the smallest screen value among those
+# that meet the hard limits (POOL_FLOOR, HINGE_MARGIN).
+RELU_CHECK = 1.5e-5
+POOL_MARGIN = 1.5e-5
+POOL_FLOOR = 3e-6
+HINGE_MARGIN = 1e-3
+SCREEN_TOL = 3e-4
+MAX_SEEDS = {"c3d": 10}
+MAX_SEEDS_DEFAULT = 6
 
 
 def main():
@@ -181,41 +234,62 @@ def main():
     for arch, B, HW, K, wss, nseeds in CASES:
         if only and arch not in only:
             continue
+        for e in [e for e in index if e[0] == arch]:
+            stale = os.path.join(GOLDEN, case_name(*e) + ".npz")
+            if os.path.exists(stale):
+                os.remove(stale)
         index = [e for e in index if e[0] != arch]
+        spec0 = {k: (tuple(s_), d) for k, (s_, d) in reference_spec(arch, K).items()}
+        max_seeds = MAX_SEEDS.get(split_arch(arch)[0], MAX_SEEDS_DEFAULT) + nseeds - 1
         for ws in wss:
             seed, kept = 0, 0
+            fallback = []          # (screen value, seed, out, spec): seeds inside the hard limits that missed a soft one
             while kept < nseeds:
                 seed += 1
-                assert seed <= 24, "no knife-edge-free seed found"
-                out, spec = run_case(arch, B, HW, K, ws, seed)
-                margin = min(float(out[f"r{r}.relu_margin"]) for r in range(ws))
-                # S3D-G at 2 ranks has ~150 small ReLU'd layers per rank, the 16- / 33-block ResNet-34 / -50 stacks a forward
-                # difference of ~1e-5 between correct fp32 implementations: no seed clears the guard, so these fixtures are
-                # kept unguarded and their whole-step gradient gate comes from the measured conditioning floor
-                # (oracle/gen_conditioning.py, tests/golden_util.py:grad_tol)
-                guard = 0.0 if ((arch == "s3dg" and ws > 1) or arch in ("resnet50", "resnet34")) else MARGIN_BY_ARCH.get(arch, DEFAULT_MARGIN)   # (wide / deep late layers)
-                if margin < guard:
-                    print(f"skip {arch} ws{ws} seed {seed}: ReLU knife-edge |z|min = {margin:.2e}", flush=True)
+                if seed > max_seeds:
+                    assert len(fallback) >= nseeds - kept, f"{arch} ws{ws}: no acceptable seed among {max_seeds}"
+                    fallback.sort(key=lambda t: t[0])
+                    for worst, sd_, out, spec in fallback[:nseeds - kept]:
+                        print(f"{arch} ws{ws}: keeping seed {sd_}, the best of {max_seeds}: screen value {worst:.2e}", flush=True)
+                        _write(arch, ws, sd_, out, spec, index, index_path)
+                        kept += 1
+                    break
+                nudges, rep = guard_for(arch, spec0, B, HW, K, ws, seed)
+                out, spec = run_case(arch, B, HW, K, ws, seed, nudges)
+                relu = min(float(out[f"r{r}.relu_margin"]) for r in range(ws))
+                pool = min(float(out[f"r{r}.pool_margin"]) for r in range(ws))
+                hinge = min(float(np.abs(2.0 - (out[f"r{r}.l_pos_M"] - out[f"r{r}.l_neg_M"])).min()) for r in range(ws))
+                print(f"{arch} ws{ws} seed {seed}: guard {rep}; reference: relu margin {relu:.2e} sigma, pool gap {pool:.2e}, hinge {hinge:.2e}",
+                      flush=True)
+                assert relu >= RELU_CHECK, "the guard band settled on the restatement does not hold in the reference"
+                if pool < POOL_FLOOR or hinge < HINGE_MARGIN:
+                    print(f"skip {arch} ws{ws} seed {seed}: arg-max / hinge knife edge", flush=True)
                     continue
-                if arch in SCREEN_ARCHS and ws == 1:
-                    from oracle.gen_conditioning import measure
-                    meta = json.loads(str(out["meta"]))
-                    spec_t = {k: (tuple(s_), d) for k, (s_, d) in spec.items()}
-                    m = measure(arch, seed, meta=meta, spec=spec_t, fast=True)
-                    worst = max(m["grad_rel_l2_max"], checker_grad_error(arch, meta, spec_t, out))
-                    if worst > SCREEN_TOL:
-                        print(f"skip {arch} ws{ws} seed {seed}: gradient moves by {worst:.1e} between fp32 evaluation orders",
-                              flush=True)
-                        continue
-                name = case_name(arch, ws, seed)
-                np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
-                with open(os.path.join(GOLDEN, f"state_spec_{tag_file(arch)}.json"), "w") as f:
-                    json.dump(spec, f, indent=0)
-                index.append([arch, ws, seed])
+                from oracle.gen_conditioning import measure
+                meta = json.loads(str(out["meta"]))
+                meta["nudges"] = nudges
+                spec_t = {k: (tuple(s_), d) for k, (s_, d) in spec.items()}
+                m = measure(arch, seed, meta=meta, spec=spec_t, fast=True, ws=ws)
+                worst = m["grad_rel_l2_max"]
+                if ws == 1:
+                    worst = max(worst, checker_grad_error(arch, meta, spec_t, out))
+                print(f"     screen: worst tensor {worst:.2e} between fp32 evaluation orders", flush=True)
+                if worst > SCREEN_TOL or pool < POOL_MARGIN:
+                    fallback.append((worst * (1.0 if pool >= POOL_MARGIN else 3.0), seed, out, spec))
+                    continue
+                _write(arch, ws, seed, out, spec, index, index_path)
                 kept += 1
-                print("wrote", name, "loss", out["r0.loss"], "relu margin", margin, flush=True)
-                with open(index_path, "w") as f:
-                    json.dump(sorted(index), f)
+
+
+def _write(arch, ws, seed, out, spec, index, index_path):
+    name = case_name(arch, ws, seed)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+    with open(os.path.join(GOLDEN, f"state_spec_{tag_file(arch)}.json"), "w") as f:
+        json.dump(spec, f, indent=0)
+    index.append([arch, ws, seed])
+    print("wrote", name, "loss", out["r0.loss"], flush=True)
+    with open(index_path, "w") as f:
+        json.dump(sorted(index), f)
 
 
 if __name__ == "__main__":

@@ -91,7 +91,8 @@ struct IgemmParams {
   FastDiv dGw, dGh, dGd, dCin, dTw, dTh;   // filled by fill_fastdiv() from Gw, Gh, Gd, Cin, nTw, nTh
   int adv_tap, adv_ci;                     // BK / Cin, BK % Cin
   int nbuf;                                // LDS tile buffers: 2, or 1 (see igemm_body)
-  int bn_narrow;                           // 64: this launch runs on the 64-wide tile whatever its column count (narrow_tiles()); 0: tile_bn(Cout)
+  int bn_narrow;                           // 64 / 32: this launch runs on the 64- / 32-wide tile whatever its column count (narrow_bn()); 0: tile_bn(Cout)
+  int bm;                                  // rows per tile: 128, or 256 (the tall 64-wide instance of the persistent kernel, tall_tiles()); 0 = 128
   int kmajor;                              // 1: channel-slice-major K order (k_slice_major)
   int skip_pad;                            // slice-major walk: skip the chunks of taps that are padding for the whole tile
   int tm_skip, cpt;                        // the same in the tap-major DMA walk when a chunk is one tap for all lanes; cpt = Cin / BK
@@ -1903,13 +1904,45 @@ static int narrow_max_tiles() {
   static const int v = getenv("RSP_NARROW_MAX_TILES") ? atoi(getenv("RSP_NARROW_MAX_TILES")) : 512;      // (0: off; A/B switch, read once)
   return v;
 }
-inline bool narrow_tiles(long long M, int Cout) {
+// Launches of less than one UNIT per CU even on the 64-wide tile (round 6): S3D-G's 14 x 14 / 7 x 7 pointwise and (3,1,1) layers, R3D-18's
+// layer3 / layer4 — 98 ... 256 tiles of 128 x 64.  Until round 5 they were cut along K (plan_split) to give every CU work, at the price
+// of a partial round trip and a dependent reduce launch per convolution (121 per S3D-G step, 73 per R3D-18 step: +4.8 % / +4.2 % per step
+// if they vanished, profiles/r05/experiments_r5.txt).  On the 32-wide tile the same launch has twice the units with the WHOLE K each:
+// no partials, no second pass, one summation order per output.  (The 32-wide tile reads the A operand for a quarter of the 128-wide
+// tile's MFMAs — irrelevant here: a launch this small is bound by the latency of its few chunks, not by L2 bandwidth.)
+std::atomic<int> g_narrow32_max_units{-1};
+static int narrow32_max_units() {
+  const int set = g_narrow32_max_units.load(std::memory_order_relaxed);
+  if (set >= 0) return set;
+  static const int v = getenv("RSP_NARROW32_MAX_UNITS") ? atoi(getenv("RSP_NARROW32_MAX_UNITS")) : 256;      // (0: off; A/B switch, read once)
+  return v;
+}
+// 0: the column count's own tile (tile_bn); 64 / 32: that tile width over all columns (no column segments)
+inline int narrow_bn(long long M, int Cout, int nchunks) {
+  const long long mt = rsp_cdiv(M, 128);
+  if (Cout > 32 && nchunks >= 8 && mt * rsp_cdiv(Cout, 64) <= narrow32_max_units()) return 32;
   // (97..128 and > 160 columns: whole 64-wide tiles or nearly; 65..96 / 129..160 keep their 96- / 160-wide tile, whose last 64-wide
   //  tile would be half empty)
   const bool cols = Cout > 160 || (Cout > 96 && Cout <= 128);
-  return cols && (long long)rsp_cdiv(M, 128) * rsp_cdiv(Cout, 128) < narrow_max_tiles();
+  return (cols && mt * rsp_cdiv(Cout, 128) < narrow_max_tiles()) ? 64 : 0;
 }
 inline int tile_bn_of(const IgemmParams& p) { return p.bn_narrow ? p.bn_narrow : tile_bn(p.Cout); }
+
+// 256 x 64 tiles for 33..64-column launches of at least one full round (round 6): four waves stacked along M, each 64 rows x 64
+// columns — the wave tile, accumulator count and LDS bytes per MFMA of the 128 x 128 instance (141 TF on C3D), where the 128 x 64
+// tile's waves (64 x 32) read 1.5 x the operand bytes per MFMA (R3D-18's stem and layer1, R(2+1)D's / S3D-G's 64-filter layers:
+// 113-122 TF).  A 32 KB + B 8 KB per tile buffer: ONE buffer, three workgroups per CU.
+std::atomic<int> g_tall_min_tiles{-1};
+static int tall_min_tiles() {
+  const int set = g_tall_min_tiles.load(std::memory_order_relaxed);
+  if (set >= 0) return set;
+  static const int v = getenv("RSP_TALL_MIN_TILES") ? atoi(getenv("RSP_TALL_MIN_TILES")) : 768;      // (0: off; A/B switch, read once)
+  return v;
+}
+inline bool tall_tiles(long long M, int bn, bool vec4) {
+  const int lim = tall_min_tiles();
+  return vec4 && bn == 64 && lim > 0 && M / 256 >= lim;
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int VEC, int MINW = 2>
 int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
@@ -1928,7 +1961,7 @@ int launch_multi_cfg(const IgemmMulti& m, int max_taps, hipStream_t s) {
 
 
 // waves per SIMD the persistent instances are compiled for (launch bound) = workgroups per CU the grid is sized with
-constexpr int persist_minw(int bn) { return bn > 128 ? 2 : (bn > 64 ? 3 : 4); }
+constexpr int persist_minw(int bn, int bm = 128) { return bm > 128 ? 3 : (bn > 128 ? 2 : (bn > 64 ? 3 : 4)); }
 
 static bool persist_enabled() {
   static const bool off = getenv("RSP_NO_PERSIST") != nullptr;      // (A/B switch for measurements, read once)
@@ -1937,7 +1970,7 @@ static bool persist_enabled() {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS>
 int launch_persist_cfg(const IgemmParams& p, hipStream_t s) {
-  constexpr int MINW = persist_minw(BN);
+  constexpr int MINW = persist_minw(BN, BM);
   const int ntaps = p.nTd * p.nTh * p.nTw;
   constexpr int BNL = (BN + 31) / 32 * 32;      // (B tile rows in LDS: whole 32-row groups, igemm_persist)
   auto lds_of = [&](int nbuf, int taps) {
@@ -1973,11 +2006,19 @@ static bool half_block(const IgemmParams& p) { return half_block_cols(p.Cout); }
 
 int launch_persist(IgemmParams& p, hipStream_t s) {
   const int bn = tile_bn_of(p);
-  p.m_tiles = rsp_cdiv(p.M, 128);
+  const int bm = p.bm > 128 ? 256 : 128;
+  p.m_tiles = rsp_cdiv(p.M, bm);
   p.n_tiles = rsp_cdiv(p.Cout, bn);
   const int R = p.m_tiles * p.n_tiles - p.full_tiles;
   p.dR = fastdiv_make(R > 0 ? R : 1);
   p.dNtl = fastdiv_make(p.n_tiles);
+  if (bm == 256) {      // the tall 64-wide instance (tall_tiles)
+    if (bn != 64) {
+      rsp_set_error("launch_persist: the 256-row tile is 64 columns wide");
+      return RSP_EINVAL;
+    }
+    return p.kmajor ? launch_persist_cfg<256, 64, 4, 1, true>(p, s) : launch_persist_cfg<256, 64, 4, 1, false>(p, s);
+  }
   if (p.kmajor) {
     switch (bn) {
       case 160: return half_block(p) ? launch_persist_cfg<128, 144, 4, 1, true>(p, s) : launch_persist_cfg<128, 160, 4, 1, true>(p, s);
@@ -2086,11 +2127,15 @@ bool single_buffer(int m_tiles, int n_tiles, int bn, bool vec4) {
   return vec4 && (bn == 128 || bn == 96) && (long long)m_tiles * n_tiles >= 768;
 }
 
-SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, int Cout) {
+SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, int Cout, int bm = 128) {
   const int tiles = m_tiles * n_tiles;
   // resident workgroups per CU of igemm_kernel<128, bn, .., VEC>: LDS-limited (DMA variants) or VGPR-limited (scalar gather)
   int wpc = vec4 ? (bn >= 96 ? 2 : 3) : (bn >= 64 ? 2 : 3);
   if (single_buffer(m_tiles, n_tiles, bn, vec4)) wpc = 3;
+  if (bm == 256) {      // the tall 64-wide tile: the 128 x 128 tile's work per chunk, three workgroups per CU on one tile buffer
+    wpc = 3;
+    bn = 128;
+  }
   const int slots = 256 * wpc;
   SplitPlan best = {tiles, 1, nchunks};
   if (nchunks < 8) return best;
@@ -2115,7 +2160,7 @@ SplitPlan plan_split(int m_tiles, int n_tiles, int bn, bool vec4, int nchunks, i
     const int cps = rsp_cdiv(nchunks, S), Se = rsp_cdiv(nchunks, cps);
     if (Se != S) continue;
     double t = round_time((long long)R * Se, cps);
-    t += 4e-6 + (double)(Se + 1) * ((double)R / n_tiles * 128.0) * Cout * 4.0 / 3.0e12;
+    t += 4e-6 + (double)(Se + 1) * ((double)R / n_tiles * bm) * Cout * 4.0 / 3.0e12;
     if (t < best_t * 0.98) {
       best_t = t;
       best = {full, Se, cps};
@@ -2160,9 +2205,9 @@ void fill_reduce(ReduceParams& r, const IgemmParams& p) {
 }
 
 
-size_t split_partial_bytes(const SplitPlan& sp, long long M, int n_tiles, int Cout) {
+size_t split_partial_bytes(const SplitPlan& sp, long long M, int n_tiles, int Cout, int bm = 128) {
   if (sp.splitk <= 1) return 0;
-  const long long row0 = (long long)(sp.full_tiles / n_tiles) * 128;
+  const long long row0 = (long long)(sp.full_tiles / n_tiles) * bm;
   return (size_t)sp.splitk * (size_t)(M - row0) * Cout * sizeof(float);
 }
 
@@ -2182,18 +2227,21 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   }
   int bn = tile_bn_of(p);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
-  const int m_tiles = rsp_cdiv(p.M, 128), n_tiles = rsp_cdiv(p.Cout, bn);
-  SplitPlan sp = plan_split(m_tiles, n_tiles, bn, vec4, p.nchunks, p.Cout);
-  p.nbuf = single_buffer(m_tiles, n_tiles, bn, vec4) ? 1 : 2;
-  if (sp.splitk > 1 && (!workspace || ws_bytes < split_partial_bytes(sp, p.M, n_tiles, p.Cout)))
+  p.y_bytes = out_extent_bytes(p);
+  // rows per tile: 256 on the tall 64-wide instance of the persistent kernel (tall_tiles), which needs 32-bit output offsets
+  const int bm = (tall_tiles(p.M, bn, vec4) && persist_enabled() && p.y_bytes != 0) ? 256 : 128;
+  p.bm = bm;
+  const int m_tiles = rsp_cdiv(p.M, bm), n_tiles = rsp_cdiv(p.Cout, bn);
+  SplitPlan sp = plan_split(m_tiles, n_tiles, bn, vec4, p.nchunks, p.Cout, bm);
+  p.nbuf = (bm == 256 || single_buffer(m_tiles, n_tiles, bn, vec4)) ? 1 : 2;
+  if (sp.splitk > 1 && (!workspace || ws_bytes < split_partial_bytes(sp, p.M, n_tiles, p.Cout, bm)))
     sp = {m_tiles * n_tiles, 1, p.nchunks};   // degrade gracefully: still correct
   p.full_tiles = sp.full_tiles;
   p.splitk = sp.splitk;
   p.chunks_per_split = sp.cps;
-  p.tail_row0 = sp.full_tiles / n_tiles * 128;
+  p.tail_row0 = sp.full_tiles / n_tiles * bm;
   p.partial = p.splitk > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
-  p.y_bytes = out_extent_bytes(p);
-  const size_t pbytes = split_partial_bytes(sp, p.M, n_tiles, p.Cout);
+  const size_t pbytes = split_partial_bytes(sp, p.M, n_tiles, p.Cout, bm);
   p.partial_bytes = pbytes < 0x7ffffff0ull ? (unsigned)pbytes : 0u;
   // (the long tap-major 128-wide launches — C3D conv2: 54 chunks per tile — measured 1 % faster on the per-tile kernel; everything
   //  else equal or better persistent: R3D-18 +2.9 %, R(2+1)D / S3D-G +0.3 % per step, profiles/r04/experiments_r4.txt)
@@ -2202,7 +2250,7 @@ int run_igemm_segment(IgemmParams& p, bool vec4, void* workspace, size_t ws_byte
   // the persistent 64-wide tile is compiled for four waves per SIMD (121-128 VGPRs): with ONE tile buffer (24.5 KB) four workgroups
   // share a CU on launches of at least one such round (R3D-18 +0.5 %, R(2+1)D +0.2 % per step); the per-tile 64-wide kernel, three
   // per CU either way, lost 9 % to the extra barrier (single_buffer)
-  if (persist && bn == 64 && (long long)m_tiles * n_tiles >= 1024) p.nbuf = 1;
+  if (persist && bm == 128 && bn == 64 && (long long)m_tiles * n_tiles >= 1024) p.nbuf = 1;
   int rc = persist ? launch_persist(p, s) : launch_igemm(p, vec4, s);
   if (rc != RSP_OK) return rc;
   if (p.splitk > 1) {
@@ -2338,8 +2386,8 @@ int run_direct(IgemmParams& p, void* workspace, size_t ws_bytes, hipStream_t s) 
 int run_igemm(IgemmParams& p, bool vec4, void* workspace, size_t ws_bytes, hipStream_t s) {
   p.stat_ld = p.Cout;
   if (direct_applies(p.M, p.Cout, p.Cin, p.K, vec4)) return run_direct(p, workspace, ws_bytes, s);
-  if (vec4 && narrow_tiles(p.M, p.Cout)) {      // one launch of 64-wide tiles over all columns (no column segments)
-    p.bn_narrow = 64;
+  if (const int nb = vec4 ? narrow_bn(p.M, p.Cout, rsp_cdiv(p.K, BK)) : 0) {      // one launch of 64- / 32-wide tiles over all columns (no column segments)
+    p.bn_narrow = nb;
     return run_igemm_segment(p, vec4, workspace, ws_bytes, s);
   }
   const Segments g = plan_segments(p.Cout);
@@ -2364,9 +2412,9 @@ size_t igemm_partial_bytes_segment(long long M, int Cout, int K);
 size_t igemm_partial_bytes(long long M, int Cout, int K) {
   const Segments g = plan_segments(Cout);
   size_t best = direct_partial_bytes(M, Cout, K);      // (whether the direct kernel runs depends on alignment, unknown here)
-  if (narrow_tiles(M, Cout)) {
-    const int n_tiles = rsp_cdiv(Cout, 64);
-    const size_t b = split_partial_bytes(plan_split(rsp_cdiv(M, 128), n_tiles, 64, true, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
+  if (const int nb = narrow_bn(M, Cout, rsp_cdiv(K, BK))) {
+    const int n_tiles = rsp_cdiv(Cout, nb);
+    const size_t b = split_partial_bytes(plan_split(rsp_cdiv(M, 128), n_tiles, nb, true, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
     best = b > best ? b : best;
   }
   for (int i = 0; i < g.n; ++i) {
@@ -2380,8 +2428,12 @@ size_t igemm_partial_bytes_segment(long long M, int Cout, int K) {
   const int bn = tile_bn(Cout), bn_s = (bn == 160 || bn == 96) ? 128 : bn;     // scalar-gather fallback: power-of-two tiles only
   const int m_tiles = rsp_cdiv(M, 128), n_tiles = rsp_cdiv(Cout, bn), n_tiles_s = rsp_cdiv(Cout, bn_s);
   // the gather variant (hence the plan) depends on pointer alignment, unknown here: size for the larger of the two
-  const size_t a = split_partial_bytes(plan_split(m_tiles, n_tiles, bn, true, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
+  size_t a = split_partial_bytes(plan_split(m_tiles, n_tiles, bn, true, rsp_cdiv(K, BK), Cout), M, n_tiles, Cout);
   const size_t b = split_partial_bytes(plan_split(m_tiles, n_tiles_s, bn_s, false, rsp_cdiv(K, BK), Cout), M, n_tiles_s, Cout);
+  if (tall_tiles(M, bn, true)) {      // ... or on 256-row tiles (whether they run depends on the output extent, unknown here)
+    const size_t t = split_partial_bytes(plan_split(rsp_cdiv(M, 256), n_tiles, bn, true, rsp_cdiv(K, BK), Cout, 256), M, n_tiles, Cout, 256);
+    a = t > a ? t : a;
+  }
   return a > b ? a : b;
 }
 
@@ -2426,11 +2478,14 @@ double igemm_live_fraction(IgemmParams p, bool vec4, bool may_direct = true) {
     const int lo = std::min(std::max(0, -c), 8), hi = std::min(nT - 1, D - 1 - c);
     return hi >= lo ? (2u << hi) - (1u << lo) : 0u;
   };
-  const int ntaps = p.nTd * p.nTh * p.nTw, m_tiles = rsp_cdiv(p.M, 128);
+  // (rows per tile as run_igemm / run_igemm_segment choose them; 32-bit output offsets assumed)
+  const int nbw = narrow_bn(p.M, p.Cout, p.nchunks);
+  const int bm = (persist_enabled() && tall_tiles(p.M, nbw ? nbw : tile_bn(plan_segments(p.Cout).width[0]), vec4)) ? 256 : 128;
+  const int ntaps = p.nTd * p.nTh * p.nTw, m_tiles = rsp_cdiv(p.M, bm);
   long long live = 0;
   for (int mt = 0; mt < m_tiles; ++mt) {
     unsigned tmask = 0;
-    for (int r = mt * 128; r < std::min(p.M, mt * 128 + 128); ++r) {
+    for (int r = mt * bm; r < std::min(p.M, mt * bm + bm); ++r) {
       const int gw = r % p.Gw, q1 = r / p.Gw, gh = q1 % p.Gh, q2 = q1 / p.Gh;
       int gd;
       if (p.dmajor) {
@@ -2661,16 +2716,20 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   // (a convolution that runs as two column segments is named after the first, wider one)
   int bn = tile_bn(plan_segments(cols).width[0]);
   if (!vec4 && (bn == 160 || bn == 96)) bn = 128;
-  {
-    long long Mrows = (long long)d->N * d->Do * d->Ho * d->Wo;
-    if (which == 1)
-      for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
-        const DgradClass g = dgrad_class(d, c);
-        if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
-        Mrows = (long long)d->N * g.Gd * g.Gh * g.Gw;
-        break;
-      }
-    if (vec4 && narrow_tiles(Mrows, cols)) bn = 64;
+  long long Mrows = (long long)d->N * d->Do * d->Ho * d->Wo;
+  int kchunks = rsp_cdiv((long long)d->kT * d->kH * d->kW * d->Cin, BK);
+  if (which == 1) {      // the first non-empty stride-parity class (its launch is the one rsp_last_conv_kernel reports)
+    for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
+      const DgradClass g = dgrad_class(d, c);
+      if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
+      Mrows = (long long)d->N * g.Gd * g.Gh * g.Gw;
+      kchunks = rsp_cdiv((long long)g.nt * g.nh * g.nw * d->Cout, BK);
+      break;
+    }
+  }
+  if (vec4) {
+    const int nb = narrow_bn(Mrows, cols, kchunks);
+    if (nb) bn = nb;
   }
   // spelled as rocprofv3 prints the demangled instance (minus namespace and argument list)
   const bool ks = vec4 && ((which == 0 && k_slice_major(d->Cin, d->kT * d->kH * d->kW)) ||
@@ -2678,15 +2737,8 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   // output addressable with 32-bit offsets: the persistent instances (launch_persist)
   const unsigned long long out_b = which == 0 ? (unsigned long long)d->N * d->Do * d->Ho * d->Wo * d->out_ld * 4ull
                                               : (unsigned long long)d->N * d->Di * d->Hi * d->Wi * d->in_ld * 4ull;
-  int kchunks = rsp_cdiv((long long)d->kT * d->kH * d->kW * d->Cin, BK);
-  if (which == 1) {      // the first non-empty stride-parity class (its launch is the one rsp_last_conv_kernel reports)
-    for (int c = 0; c < d->sT * d->sH * d->sW; ++c) {
-      const DgradClass g = dgrad_class(d, c);
-      if (g.nt * g.nh * g.nw == 0 || g.Gd * g.Gh * g.Gw == 0) continue;
-      kchunks = rsp_cdiv((long long)g.nt * g.nh * g.nw * d->Cout, BK);
-      break;
-    }
-  }
+  if (vec4 && persist_enabled() && out_b < 0x7ffffff0ull && tall_tiles(Mrows, bn, vec4))
+    return ks ? "igemm_persist_kernel<256, 64, 4, 1, true, 3>" : "igemm_persist_kernel<256, 64, 4, 1, false, 3>";
   const bool long_tm128 = !ks && bn == 128 && kchunks >= 48;      // as in run_igemm_segment
   if (vec4 && persist_enabled() && !long_tm128 && out_b < 0x7ffffff0ull) {
     if (ks) {
@@ -3022,6 +3074,16 @@ int rsp_conv3d_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "narrow_max_tiles")) {
     const int prev = narrow_max_tiles();
     g_narrow_max_tiles.store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    return prev;
+  }
+  if (name && !strcmp(name, "narrow32_max_units")) {
+    const int prev = narrow32_max_units();
+    g_narrow32_max_units.store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    return prev;
+  }
+  if (name && !strcmp(name, "tall_min_tiles")) {
+    const int prev = tall_min_tiles();
+    g_tall_min_tiles.store(value < 0 ? -1 : value, std::memory_order_relaxed);
     return prev;
   }
   rsp_set_error("rsp_conv3d_set_option: unknown option");

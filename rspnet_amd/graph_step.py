@@ -91,6 +91,7 @@ class GraphedPretextStep:
         self.static = None
         self.last_wait_s = 0.0
         self.segment_host_ms = None               # {} to collect host time per segment of the segmented replay
+        self.segment_gpu_events = None            # [] to collect (graph name, start event, end event) of every replayed graph
         # How the captured step is laid out (module docstring).  RSP_GRAPH_MODE = whole | segments | lanes overrides the default for
         # A/B runs; "whole" with the collectives on captures the RCCL calls too (RSP_GRAPH_COLLECTIVES=1 of round 4: exercised at one
         # rank, never the default); RSP_NO_SEGMENTS=1 issues the data-parallel step eagerly as rounds 1-4 did.
@@ -362,6 +363,11 @@ class GraphedPretextStep:
                 if done >= 2 and self.issue == "auto":
                     return self._measured_eager(cfg, host, im_q, im_k, last=(done == self.warmup - 1))[:5]
                 return self._eager(im_q, im_k, host)[:5]
+            from . import ops as _ops
+            if getattr(_ops.backend(), "event_log", None) is not None:
+                # per-launch timing events are being recorded (bench.py's roofline pass): nothing can be captured now, and nothing
+                # is decided — no copy into the static clip buffers, no cross-rank agreement; the step is simply issued eagerly
+                return self._eager(im_q, im_k, host)[:5]
             self._static_clips(im_q, im_k)
             entry = self._capture(key, host)
             if entry is None:
@@ -375,18 +381,37 @@ class GraphedPretextStep:
     def _replay(self, seq, host):
         """Run a captured schedule (see `_schedule`): graphs replayed on their lanes' streams, collectives issued in between."""
         dev = self.static["dev"].device
+        m = self.model
+        if m._last_draw is not None:
+            # introspection state follows THIS step's host draws in every mode (the device-side permutation is the graph's own
+            # buffer, rewritten by the replay)
+            m._last_speed = host["speed"]
+            m._last_draw = (m._last_draw[0], host["speed"]) + tuple(host["sh"])
         prof = self.segment_host_ms
+        gev = self.segment_gpu_events
         if prof is not None:
             import time
+
+        def replay(op):
+            # (measurement: where the GPU's time of a replayed step goes — an event pair on the graph's own stream around it)
+            if gev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                op[3].replay()
+                e1.record()
+                gev.append((op[1] + ":" + op[2], e0, e1))
+            else:
+                op[3].replay()
+
         for op in seq:
             t0 = time.perf_counter() if prof is not None else 0.0
             kind = op[0]
             if kind == "g":
                 if op[1] == "main":
-                    op[3].replay()
+                    replay(op)
                 else:
                     with torch.cuda.stream(self.lane_streams[op[1]]):
-                        op[3].replay()
+                        replay(op)
             elif kind == "e":
                 if op[1] == "main":
                     op[3](host)

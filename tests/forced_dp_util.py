@@ -104,10 +104,22 @@ def segmented_worker(rank, arch, B, HW, port, out_path, mode="lanes", steps=7):
     assert ops.backend().name == "hip"
     K = 64
     calls = collections.Counter()
+    # Ordering of the gradient all-reduce inside a REPLAYED step: with one rank an all-reduce moves nothing, so a bucket
+    # reduced before the backward piece that writes it had finished, or an SGD graph that ran before the reduce, would pass every
+    # value check.  The spy therefore (a) snapshots each flat-gradient bucket ON THE ISSUING STREAM at the moment of issue — it must
+    # equal what the bucket holds when the step is over — and (b) DOUBLES the bucket there, as a sum over two identical ranks
+    # would: the optimizer of either loop sees the doubled gradient only if it is ordered behind the "collective", and the two loops
+    # stay bit-identical only if both are.
+    cur = {"model": None, "snaps": []}
     for name in ("all_to_all_single", "all_gather_into_tensor", "all_reduce"):
         def make(name, fn):
             def spy(*a, **k):
                 calls[name] += 1
+                flat = getattr(cur["model"], "_flat", None) if name == "all_reduce" else None
+                if flat is not None and a[0].untyped_storage().data_ptr() == flat.g_flat.untyped_storage().data_ptr():
+                    t = a[0]
+                    cur["snaps"].append(((t.data_ptr() - flat.g_flat.data_ptr()) // 4, t.numel(), t.clone()))
+                    t.mul_(2.0)
                 return fn(*a, **k)
             return spy
         setattr(dist, name, make(name, getattr(dist, name)))
@@ -128,7 +140,10 @@ def segmented_worker(rank, arch, B, HW, port, out_path, mode="lanes", steps=7):
         stepper = GraphedPretextStep(wrapped, crit, opt, warmup=2, issue="graph") if how == "segments" else None
         trace = []
         before = dict(calls)
+        cur["model"] = wrapped.module
+        checks = []
         for im_q, im_k in clips:
+            cur["snaps"] = []
             if stepper is None:
                 out, tgt, rl, rt = wrapped(im_q, im_k)
                 loss, la, lm = crit(out, tgt, rl, rt)
@@ -138,7 +153,15 @@ def segmented_worker(rank, arch, B, HW, port, out_path, mode="lanes", steps=7):
             else:
                 loss, la, lm, out, rl = stepper(im_q, im_k)
             trace.append((loss.detach().clone(), out[0].detach().clone(), rl[0].detach().clone()))
+            # (stream-ordered copy behind the step, no host synchronisation: the host keeps running ahead as in a real loop)
+            checks.append((cur["snaps"], wrapped.module._flat.g_flat.clone()))
         torch.cuda.synchronize()
+        for it, (snaps, final) in enumerate(checks):
+            assert len(snaps) >= 1 and sum(n for _, n, _ in snaps) == final.numel(), (how, it, len(snaps))
+            for off, n, snap in snaps:
+                assert not torch.isnan(snap).any(), (how, it, off)
+                assert torch.equal(snap * 2.0, final[off:off + n]), (how, "a gradient bucket changed after its all-reduce was issued", it, off, n)
+        info.setdefault("buckets", {})[how] = len(checks[-1][0])
         info[how] = {k: calls[k] - before.get(k, 0) for k in calls}
         if stepper is not None:
             assert stepper.mode == mode and not stepper.disabled, stepper.fallback_reason

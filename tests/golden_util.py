@@ -7,7 +7,7 @@ import torch
 
 from oracle import portable as P
 from oracle import restatement as S
-from oracle.gen_golden import case_inputs, case_name
+from oracle.gen_golden import case_inputs, case_name, nudges_from_npz
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -21,17 +21,17 @@ def cases_for(arch, ws=None):
 
 
 # Gradient / post-SGD tolerance of the WHOLE-STEP comparison.  Forward quantities (loss, logits, features, queue, BN
-# statistics) are compared at 1e-3 or tighter (they agree to ~1e-6).  Whole-step weight gradients have a floor that no
-# implementation can go under: the backward pass of a ReLU / max-pool network is discontinuous in the forward values, so two
-# correct fp32 implementations whose activations differ by a relative delta decide ~delta of the masks / arg-maxes
-# differently, each flip changing its gradient contribution by O(1) -> a whole-gradient distance ~sqrt(delta), independent
-# of the fixture size.  tests/golden/conditioning.json (oracle/gen_conditioning.py) holds that floor per fixture family,
-# measured as the distance of the oracle restatement in fp32 from fp64 (and from two other fp32 evaluation orders) on the
-# fixture's own inputs: 2e-5 for the guarded head variants, 1.8-3.9e-3 for C3D / R3D-18 / R(2+1)D (a fixture with ONE flip sits
-# there), 1.7e-2 for S3D-G, 3.5e-2 for ResNet-34 / -50 (deep stacks, forward delta ~3e-5).
-# The gate is THREE floors per family, never below 1e-3 (round 5; a flat 2e-2 until then: a backward bug of 1-2 % on one small
-# tensor passed every whole-step gate of the first three families) -> C3D 6.3e-3, R3D-18 8.1e-3, R(2+1)D 5.4e-3, the guarded
-# C3D head variants 1e-3 at one rank (2-rank fixtures: the larger of their own and the 1-rank floor, grad_tol).  Measured on the HIP path (tools/grad_report.py, profiles/r05): 1e-5 ... 2.3e-3 on those families.
+# statistics) are compared at 1e-3 or tighter (they agree to ~1e-6).  The backward pass of a ReLU / max-pool network is
+# discontinuous in the forward values: an element within rounding of a ReLU's kink, or two window elements within rounding of a
+# tie, takes its decision from the summation order of whoever evaluates it, and each such flip moves its layer's gradient by
+# O(1 / sqrt(elements)).  Since round 6 every fixture carries a GUARD BAND (oracle/guard.py): the BatchNorm bias values in front
+# of encoder_q's ReLUs are moved, per channel and only where needed, so that no ReLU input of the query pass lies within
+# 2e-5 ... 5e-5 channel-sigmas of zero — 10-30 x the forward distance of two correct fp32 evaluations — and seeds are screened
+# for arg-max ties (oracle/gen_golden.py).  What remains is measured per fixture family in tests/golden/conditioning.json
+# (oracle/gen_conditioning.py): the distance of the oracle restatement in fp32 from fp64 and from two other fp32 evaluation
+# orders on the fixture's own inputs.
+# The gate is THREE floors per family, never below 1e-3, under the library's DEFAULT tile plan only (rounds 3-5: a flat 2e-2,
+# then per-family gates up to 1e-1 and a second tile plan as a witness for fixtures whose knife edges a kernel change re-rolled).
 # The exact check of the backward composition, unit by unit at 2e-5, is the teacher-forced replay
 # (tests/test_teacher_forced_gpu.py).
 GRAD_TOL_MIN = 1e-3
@@ -66,12 +66,13 @@ def load_spec(arch):
 def load_case(arch, ws, seed):
     z = np.load(os.path.join(GOLDEN, case_name(arch, ws, seed) + ".npz"))
     meta = json.loads(str(z["meta"]))
+    meta["nudges"] = nudges_from_npz(z)      # the fixture's guard band (oracle/guard.py): part of its pre-step state
     return z, meta
 
 
 def build_inputs(arch, meta):
     spec = load_spec(arch)
-    return spec, case_inputs(spec, arch, meta["B"], meta["HW"], meta["K"], meta["ws"], meta["seed"])
+    return spec, case_inputs(spec, arch, meta["B"], meta["HW"], meta["K"], meta["ws"], meta["seed"], meta.get("nudges"))
 
 
 def rel_err(a, b, floor=1e-5):
@@ -186,45 +187,14 @@ def compare_to_golden(z, rank, out, post_state, mom_post, tol, tol_grad=None, ch
     return errs
 
 
-GRAD_LOOSE = 1e-1
-
-
 def check_step_gradients(arch, ws, rank, z, step_fn, tol, gate=None):
-    """Whole-step check of one rank against its golden case, robust to knife edges.  step_fn() -> (res, post, mom_post, grads) runs
-    the fixture's step on the active backend.  Forward quantities and the queue are held to `tol`; the gradient-derived tensors
-    (gradients, post-SGD parameters, momentum buffers) to `gate` (default: three floors, grad_tol) —
-
-    * under the library's default tile plan, or
-    * when that fails on the HIP backend: under the ALTERNATIVE plan (`narrow_max_tiles = 0`: every launch on its wide tile), with
-      the default plan's numbers still below GRAD_LOOSE and its forward quantities within `tol`.
-
-    Why a second plan is a legitimate witness.  Both plans compute every convolution exactly, per op, at 2e-5 against the checker
-    (tests/test_kernels_gpu.py, tests/test_teacher_forced_gpu.py) and sit at the same distance from an fp64 convolution
-    (tools/narrow_check.py: 2.5e-7 either way) — they differ in the ORDER of the K-split partial sums, i.e. by rounding.  A
-    fixture whose whole gradient moves by percents between them (resnet18 seed 3: 2.5e-3 wide, 3.5e-2 narrow; s3dg: 1.8e-2 /
-    5.2e-2) holds ReLU / max-pool decisions within that rounding of a knife edge; its golden gradients are ONE of the valid
-    answers.  A wiring bug in the backward shows under both plans.  Returns (errs, worst, plan)."""
-    from rspnet_amd import ops as _ops
+    """Whole-step check of one rank against its golden case.  step_fn() -> (res, post, mom_post, grads) runs the fixture's step on
+    the active backend — under the library's default tile plan: there is no second evaluation.  Forward quantities and the queue
+    are held to `tol`; the gradient-derived tensors (gradients, post-SGD parameters, momentum buffers) to `gate` (default: three
+    conditioning floors of the fixture family, grad_tol).  Returns (errs, worst gradient error, "default", post state)."""
     gate = gate if gate is not None else grad_tol(arch, ws)
-
-    def measure():
-        res, post, mom_post, grads = step_fn()
-        errs = compare_to_golden(z, rank, res, post, mom_post, tol=tol, tol_grad=1e9)
-        wkey, worst = worst_grad_err(z, rank, grads)
-        top = max(worst, errs.get("post_state", 0.0), errs.get("momentum_post", 0.0))
-        return errs, (wkey, worst), top, post
-
-    errs, (wkey, worst), top, post = measure()
-    if top <= gate:
-        return errs, worst, "default", post
-    be = _ops.backend()
-    assert be.name == "hip" and top <= GRAD_LOOSE, (arch, ws, wkey, worst, errs)
-    prev = be.set_option("narrow_max_tiles", 0)
-    try:
-        errs2, (wkey2, worst2), top2, post2 = measure()
-    finally:
-        be.set_option("narrow_max_tiles", -1 if prev == 512 else prev)
-    assert top2 <= gate, (arch, ws, "default plan", wkey, worst, "wide-tile plan", wkey2, worst2, errs2)
-    print(f"\n{arch} ws{ws} rank {rank}: gradient-derived tensors {top:.2e} under the default tile plan (> {gate:.1e}: {wkey}), "
-          f"{top2:.2e} under the wide-tile plan: knife-edge decisions")
-    return errs2, worst2, "wide", post
+    res, post, mom_post, grads = step_fn()
+    errs = compare_to_golden(z, rank, res, post, mom_post, tol=tol, tol_grad=gate)
+    wkey, worst = worst_grad_err(z, rank, grads)
+    assert worst <= gate, (arch, ws, wkey, worst, gate, errs)
+    return errs, worst, "default", post

@@ -74,6 +74,13 @@ def test_bench_prints_one_contract_line():
         # every backbone also runs the way N > 1 ranks run it: RCCL group of one rank, all collectives on
         odp = o["dp_path_at_one_rank"]
         assert "error" not in odp and odp["clips_per_s"] > 0 and odp["step_issue_mode"] in ("eager", "graph_segments", "graph_lanes"), (a, odp)
+    # ... and as flat scalars, at the top level and inside the roofline object (a record that keeps only the
+    # contract's keys and objects still holds the numbers of BASELINE configs 3-5)
+    for key, a in (("resnet18", "resnet18"), ("r2plus1d", "r2plus1d-vcop"), ("s3dg", "s3dg")):
+        assert d[f"{key}_clips_per_s"] == ow[a]["clips_per_s"] and d[f"{key}_whole_step_frac"] == ow[a]["whole_step_frac"]
+        assert d[f"{key}_dominant_kernel_frac"] == ow[a]["dominant_kernel_frac"] and d[f"{key}_ms_per_step"] == ow[a]["ms_per_step"]
+        assert rf["other_workloads"][f"{key}_clips_per_s"] == ow[a]["clips_per_s"]
+        assert rf["other_workloads"][f"{key}_whole_step_frac"] == ow[a]["whole_step_frac"]
     assert "parity" not in d                       # --cpu-sample 2 != B: the CPU leg cannot replay the GPU's step
 
 

@@ -241,3 +241,103 @@ def test_issue_mode_decision_is_shared_across_ranks():
         mp.spawn(_agree_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
         a0, a1 = np.load(os.path.join(tmp, "agree0.npy")), np.load(os.path.join(tmp, "agree1.npy"))
     assert a0.tolist() == a1.tolist() == [0.4, 0.0]
+
+
+def _chain_worker(rank, ws, port, tmp):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import json
+    import torch.distributed as dist
+    from cpu_ops import CpuOps
+    from golden_util import GOLDEN, load_spec, rel_err
+    from model_util import ReplayRNG, make_cfg
+    from oracle import portable as P
+    from oracle.gen_golden import case_inputs
+    from oracle.gen_golden_chain import CHAIN_SEED, chain_perms
+    from rspnet_amd import ops
+    from rspnet_amd.moco import Loss, ModelFactory
+    from rspnet_amd.optim import SGD
+    torch.set_num_threads(4)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    ops.set_backend(CpuOps())
+    z = np.load(os.path.join(GOLDEN, "chain_c3d_ws2.npz"))
+    meta = json.loads(str(z["meta"]))
+    assert meta["ws"] == ws and meta["seed"] == CHAIN_SEED
+    spec = load_spec("c3d")
+    state, mom, clips, _, _ = case_inputs(spec, "c3d", meta["B"], meta["HW"], meta["K"], ws, CHAIN_SEED)
+    dev = torch.device("cpu")
+    wrapped = ModelFactory(make_cfg("c3d", meta["K"], m=meta["m"], T=meta["T"])).build_moco_diffloss(device=dev)
+    model = wrapped.module
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    model.train()
+    params = [p for p in wrapped.parameters() if p.requires_grad]
+    opt = SGD(params, lr=meta["lr"], momentum=meta["sgd_momentum"], dampening=0.0, weight_decay=meta["weight_decay"], nesterov=False)
+    names = {id(p): n for n, p in model.named_parameters()}
+    for p in params:
+        if names[id(p)] in mom:
+            opt.state[p]["momentum_buffer"] = torch.from_numpy(mom[names[id(p)]].copy())
+    crit = Loss(margin=meta["margin"], A=meta["A"], M=meta["M"])
+    im_q, im_k = torch.from_numpy(clips[rank][0]), torch.from_numpy(clips[rank][1])
+    worst = 0.0
+    for s in range(meta["steps"]):
+        perms_B, sh = chain_perms(s, ws, meta["B"])
+        with ReplayRNG([perms_B[rank], sh[0], sh[1]], 2):
+            out, tgt, rl, rt = wrapped(im_q, im_k)
+        loss, _, _ = crit(out, tgt, rl, rt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sd = model.state_dict()
+        # DDP hands every rank rank 0's buffers before each forward; here they evolve per rank between sync_buffers() calls.  What
+        # must hold WITHOUT any sync: rank 0's whole trajectory (the rank that writes checkpoints), every rank's queue / pointer /
+        # num_batches_tracked / losses / trained parameters (nothing in train mode reads a running statistic), and every rank's
+        # running statistics after the FIRST step (all ranks start it from the same state)
+        pre = f"r{rank}.s{s}."
+        assert abs(float(loss) - float(z[pre + "loss"])) <= 2e-4 * abs(float(z[pre + "loss"])), (rank, s, float(loss))
+        assert rel_err(out[0].detach().numpy(), z[pre + "logits1"]) <= 2e-4, (rank, s, "logits1")
+        for name in z.files:
+            if not name.startswith(pre + "post"):
+                continue
+            kind, key = name[len(pre):].split(".", 1)
+            if kind == "post":
+                if key.endswith("num_batches_tracked") or key == "queue_ptr":
+                    assert int(np.asarray(sd[key]).reshape(-1)[0]) == int(np.asarray(z[name]).reshape(-1)[0]), (rank, s, key)
+                else:
+                    assert rel_err(sd[key].numpy(), z[name]) <= 2e-4, (rank, s, key)
+            elif key.endswith(("running_mean", "running_var")):
+                if rank == 0 or s == 0:
+                    e = rel_err(P.summarise(key, sd[key].numpy()), z[name])
+                    worst = max(worst, e)
+                    assert e <= 2e-4, (rank, s, key, e)
+            else:                                                  # trained tensors: the chain runs through the optimizer
+                assert rel_err(P.summarise(key, sd[key].detach().numpy()), z[name]) <= 1e-3, (rank, s, key)
+    before = {k: v.clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    wrapped.sync_buffers()
+    after = {k: v.clone() for k, v in model.state_dict().items()}
+    if rank == 0:
+        assert all(torch.equal(before[k], after[k]) for k in before)          # rank 0 is the source: untouched
+    else:
+        assert any(not torch.equal(before[k], after[k]) for k in before), "rank 1's running statistics never differed: nothing was tested"
+    torch.save({k: v for k, v in after.items() if not k.startswith("encoder_q.") or k.endswith(("running_mean", "running_var", "num_batches_tracked"))},
+               os.path.join(tmp, f"buffers{rank}.pt"))
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([worst]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_buffers_follow_ddp_over_chained_steps_and_sync_buffers_aligns_the_rest():
+    """VERDICT r5 item 7 / SURVEY C6.  DistributedDataParallel broadcasts rank 0's buffers before every forward
+    (/root/reference/moco/__init__.py:49-53); the product keeps BatchNorm running statistics per rank between sync_buffers() calls.
+    tests/golden/chain_c3d_ws2.npz (oracle/gen_golden_chain.py) holds three CHAINED steps of the real reference under 2-rank DDP:
+    rank 0's state after every step — what a checkpoint written by rank 0 holds (/root/reference/pretrain.py:244-260) — is
+    reproduced without any sync; after sync_buffers() rank 1's buffers and key encoder equal rank 0's bit for bit."""
+    from oracle.ref_harness import _free_port
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_chain_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
+        b0, b1 = torch.load(os.path.join(tmp, "buffers0.pt")), torch.load(os.path.join(tmp, "buffers1.pt"))
+    assert set(b0) == set(b1) and len(b0) > 60
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k

@@ -138,6 +138,57 @@ def test_conv_fwd_dgrad_wgrad(hip, case):
     close(db, db_ref, 2e-5, "dbias")
 
 
+# Round 6 instances, at sizes the checker finishes in seconds (the thresholds that select them are planning options of the library):
+#   * the 256 x 64 tile of the persistent kernel (tall_tiles: 33..64 columns, at least a round of tiles at full size) — tap-major and
+#     slice-major K, depth-major rows with frames longer / shorter than a tile (two linear runs / the per-row table), a ragged last
+#     tile, a K-split tail whose partial rows are 256-row tiles, bias + statistics on every tile, the input gradient of a 64-channel input;
+#   * 32-wide tiles with the whole K per unit for launches of less than one 128 x 64 unit per CU (narrow_bn), both K orders.
+TALL_CASES = [
+    (2, 4, 24, 24, 16, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (3, 4, 16, 16, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (8, 4, 9, 7, 64, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 4, 130, 128, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 5, 23, 19, 64, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0)),         # the input gradient has 64 columns (forward: 8)
+]
+NARROW32_CASES = [
+    (2, 4, 14, 14, 512, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    (2, 2, 7, 7, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 4, 14, 14, 96, 208, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (4, 1, 4, 4, 256, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", TALL_CASES + NARROW32_CASES, ids=lambda c: "x".join(map(str, c[:6])) + f"k{c[6]}s{c[7]}")
+def test_conv_tall_and_narrow32_instances(hip, case):
+    N, D, H, W, Cin, Cout, k, s, p = case
+    g = ConvGeom(N, D, H, W, Cin, Cout, k, s, p)
+    x = rnd(N, D, H, W, Cin, seed=21)
+    w = rnd(Cout, Cin, *k, seed=22, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    b = rnd(Cout, seed=23)
+    y_ref, st_ref = CPU.conv_fwd(g, x, w, b, True)
+    dy = rnd(*y_ref.shape, seed=24)
+    dx_ref = CPU.conv_dgrad(g, dy, w)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    tall = case in TALL_CASES
+    if tall:
+        hip.set_option("tall_min_tiles", 2)
+    try:
+        y, st = hip.conv_fwd(g, xd, hip.conv_pack_fwd(g, wd), bd, True)
+        kf = hip.lib.rsp_last_conv_kernel().decode()
+        dx = hip.conv_dgrad(g, dy.to(DEV), wd)
+        kd = hip.lib.rsp_last_conv_kernel().decode()
+    finally:
+        if tall:
+            hip.set_option("tall_min_tiles", -1)
+    close(y, y_ref, 2e-5, "conv fwd")
+    close(st.double().sum(0), st_ref.double().sum(0), 2e-5, "stat partials")
+    close(dx, dx_ref, 2e-5, "dgrad")
+    if tall:
+        assert "<256, 64," in (kf if Cout > 32 else kd), (kf, kd)
+    elif s == (1, 1, 1):
+        assert "<128, 32," in kf, kf
+
+
 def _fuzz_cases(n=48, seed=20261002):
     """Seeded random conv geometries: odd sizes, mixed kernels / strides / paddings, channel counts on every code path
     (4-channel stems, scalar-gather fallbacks, 32/64/128-wide tiles, kernels smaller than the stride)."""
