@@ -145,7 +145,11 @@ double rsp_conv3d_executed_fraction(const rsp_conv3d_desc* d, int which);
  *                         32-wide tile with the whole K per unit instead of a K split + reduce launch (default 256, environment
  *                         RSP_NARROW32_MAX_UNITS; 0: never; < 0: back to the default).
  *   "tall_min_tiles"      33..64-column launches of at least this many 256-row tiles run on the 256 x 64 instance of the persistent
- *                         kernel (default 768 = one round, environment RSP_TALL_MIN_TILES; 0: never; < 0: back to the default).
+ *                         kernel (default 0 = never: measured neutral-to-negative per step in round 6; environment
+ *                         RSP_TALL_MIN_TILES; < 0: back to the default).
+ *   "two_level_min_chunks" slice-major 128-wide launches of at least this many 32-deep K chunks sum K in panels of 512 products
+ *                         (a second accumulator set, two waves per SIMD): the CPU convolution's error level on the long-K layers
+ *                         (default 0 = never: priced in round 6; environment RSP_TWO_LEVEL_MIN_CHUNKS).
  * Used by the kernel tests (an instance at sizes the checker finishes in seconds) and by tools/geom_bench.py (A/B of a plan in one
  * process).  The whole-step parity tests run under the DEFAULT plan only. */
 int rsp_conv3d_set_option(const char* name, int32_t value);

@@ -207,7 +207,9 @@ def run_case(arch, B, HW, K, ws, seed, nudges=None):
 
 
 # Seed acceptance (on top of the guard band, which every seed gets):
-#   * the band holds in the REFERENCE's own fp32 forward: smallest |ReLU input| / channel sigma >= RELU_CHECK (asserted);
+#   * the band holds in fp32: smallest |ReLU input| / channel sigma in the restatement's fp32 forward, in units of each ReLU's
+#     band, and in the REFERENCE's own forward, in units of the band's floor (oracle/guard.py:band_eps), both >= RELU_CHECK
+#     (asserted: the band was settled on the restatement in fp64; 1.0 = at the band's edge);
 #   * max-pool arg-max of the small disjoint-window layers: top-2 gap >= POOL_MARGIN (a bias cannot open it: seed selection);
 #   * the ranking hinge max(0, margin - (p - n)) is not within HINGE_MARGIN of its kink for any sample;
 #   * conditioning screen: the oracle restatement evaluated in two other fp32 orders (native convolution; folded scale/shift
@@ -217,7 +219,7 @@ def run_case(arch, B, HW, K, ws, seed, nudges=None):
 #     Only CPU evaluations of the oracle and of the reference take part, never a GPU result.
 # The first seed that meets all of them is kept; if none of MAX_SEEDS does, the one with the smallest screen value among those
 # that meet the hard limits (POOL_FLOOR, HINGE_MARGIN).
-RELU_CHECK = 1.5e-5
+RELU_CHECK = 0.6
 POOL_MARGIN = 1.5e-5
 POOL_FLOOR = 3e-6
 HINGE_MARGIN = 1e-3
@@ -234,11 +236,11 @@ def main():
     for arch, B, HW, K, wss, nseeds in CASES:
         if only and arch not in only:
             continue
-        for e in [e for e in index if e[0] == arch]:
+        for e in [e for e in (json.load(open(index_path)) if os.path.exists(index_path) else []) if e[0] == arch]:
             stale = os.path.join(GOLDEN, case_name(*e) + ".npz")
             if os.path.exists(stale):
                 os.remove(stale)
-        index = [e for e in index if e[0] != arch]
+        index = [e for e in index if e[0] != arch and (not only or e[0] in only)]
         spec0 = {k: (tuple(s_), d) for k, (s_, d) in reference_spec(arch, K).items()}
         max_seeds = MAX_SEEDS.get(split_arch(arch)[0], MAX_SEEDS_DEFAULT) + nseeds - 1
         for ws in wss:
@@ -259,9 +261,9 @@ def main():
                 relu = min(float(out[f"r{r}.relu_margin"]) for r in range(ws))
                 pool = min(float(out[f"r{r}.pool_margin"]) for r in range(ws))
                 hinge = min(float(np.abs(2.0 - (out[f"r{r}.l_pos_M"] - out[f"r{r}.l_neg_M"])).min()) for r in range(ws))
-                print(f"{arch} ws{ws} seed {seed}: guard {rep}; reference: relu margin {relu:.2e} sigma, pool gap {pool:.2e}, hinge {hinge:.2e}",
+                print(f"{arch} ws{ws} seed {seed}: guard {rep}; reference: relu margin {relu:.2f} bands, pool gap {pool:.2e}, hinge {hinge:.2e}",
                       flush=True)
-                assert relu >= RELU_CHECK, "the guard band settled on the restatement does not hold in the reference"
+                assert relu >= RELU_CHECK and rep["fp32_margin_in_bands"] >= RELU_CHECK, "the guard band settled on the restatement does not hold in fp32"
                 if pool < POOL_FLOOR or hinge < HINGE_MARGIN:
                     print(f"skip {arch} ws{ws} seed {seed}: arg-max / hinge knife edge", flush=True)
                     continue
@@ -288,8 +290,12 @@ def _write(arch, ws, seed, out, spec, index, index_path):
         json.dump(spec, f, indent=0)
     index.append([arch, ws, seed])
     print("wrote", name, "loss", out["r0.loss"], flush=True)
+    # (two generator processes may work on different architectures side by side: merge with what is on disk)
+    on_disk = json.load(open(index_path)) if os.path.exists(index_path) else []
+    mine = {e[0] for e in index}
+    merged = [e for e in on_disk if e[0] not in mine] + [e for e in index if e[0] in mine and os.path.exists(os.path.join(GOLDEN, case_name(*e) + ".npz"))]
     with open(index_path, "w") as f:
-        json.dump(sorted(index), f)
+        json.dump(sorted(merged), f)
 
 
 if __name__ == "__main__":

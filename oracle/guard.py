@@ -10,7 +10,7 @@ a second tile plan as a witness).  Rejecting seeds cannot fix that: a fixture ha
 What.  The fixture's pre-step state stays what oracle/portable.py:fill_state draws — except that the additive per-channel term in
 front of each ReLU of encoder_q (a BatchNorm bias; the bias of the 'mlp' / 'conv' heads' first layer) is moved, channel by channel
 and only where needed, by the smallest amount that leaves NO element of that channel's ReLU input closer to zero than
-`eps` x (the channel's standard deviation) — for every rank's query clips at once.  A bias shifts its channel's ReLU input
+`band_eps` x (the channel's standard deviation) — for every rank's query clips at once.  A bias shifts its channel's ReLU input
 exactly and leaves the layer's normalised values alone, so the layers are settled one after the other in evaluation order, each
 with one fp64 forward of the restatement (pinned to the reference at 2e-5; fp64 makes the band independent of anyone's rounding).
 Typically 1-5 % of the channels of a layer move, by ~1e-4 of their scale; the moved values are kept in the fixture
@@ -28,12 +28,16 @@ import torch
 
 from oracle import restatement as S
 
-# band half-width in units of the channel's standard deviation.  The forward values of two correct fp32 evaluations differ by
-# 1e-6 ... 2e-6 relative (1.4e-6 for one fp32 chain at K = 13 824), accumulating to <= 1e-5 through the
-# deepest stacks: 5e-5 leaves a factor of 5 ... 30.  Channels with so many elements that no gap of that width is near (> 64k
-# values: the first layers) take the narrower band — they are the layers in front of which no error has accumulated yet, and a
-# flipped element there weighs 1 / sqrt(elements) of its layer's gradient.
-EPS_WIDE, EPS_NARROW, MANY = 5e-5, 2e-5, 1 << 16
+# FLOOR of the band half-width in units of the channel's standard deviation, by the number of values a channel holds (all ranks
+# together); the band of a ReLU is this or DRIFT_FACTOR x the measured fp32 drift at its depth, whichever is larger (guard_band).
+# The forward values of two correct fp32 evaluations differ by 1e-6 ... 2e-6 channel-sigmas per layer (1.4e-6 for
+# one fp32 chain at K = 13 824) and the differences accumulate with depth: measured on S3D-G's 77 units, the reference's own fp32
+# forward sits up to 3.6e-5 sigmas from the restatement's fp64 values at a late layer.  The band therefore widens where it can — the
+# small late layers, which are also the ones where a single flipped element weighs most: 2e-4 up to 4k values per channel, 5e-5 up to
+# 64k, 2e-5 beyond (the first layers, in front of which nothing has accumulated yet and where a flipped element weighs
+# 1 / sqrt(elements) of its layer's gradient).
+def band_eps(values_per_channel: int) -> float:
+    return 2e-4 if values_per_channel <= 4096 else (5e-5 if values_per_channel <= (1 << 16) else 2e-5)
 
 
 def _trace_query(arch: str, fc_type: str, states64: List[dict], q_clips: List[torch.Tensor]):
@@ -69,7 +73,7 @@ def _shift_for(vals: np.ndarray, band: float) -> float:
 
 
 def relu_margins(events_per_rank) -> List[Tuple[int, str, float]]:
-    """[(event index, bias key, smallest |z| / std over the channels and ranks)] for every ReLU of the traced pass."""
+    """[(event index, bias key, smallest |z| / std over the channels and ranks, in units of the layer's band)] for every ReLU."""
     out = []
     ev0 = events_per_rank[0]
     last_shift = None
@@ -79,25 +83,43 @@ def relu_margins(events_per_rank) -> List[Tuple[int, str, float]]:
         elif e[0] == "relu":
             rows = np.concatenate([_channel_rows(ev[i][1]) for ev in events_per_rank], axis=1)
             sd = np.maximum(rows.std(axis=1), 1e-30)
-            out.append((i, last_shift, float((np.abs(rows).min(axis=1) / sd).min())))
+            out.append((i, last_shift, float((np.abs(rows).min(axis=1) / sd).min() / band_eps(rows.shape[1]))))
     return out
+
+
+DRIFT_FACTOR = 6.0
 
 
 def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: List[np.ndarray], verbose: bool = False):
     """Returns ({bias key: (channel indices int32, NEW values float32)}, report).  `state`: the fixture's pre-step state (numpy,
-    not modified); q_clips: the query clips of every rank as encoder_q sees them (after _diff_speed)."""
+    not modified); q_clips: the query clips of every rank as encoder_q sees them (after _diff_speed).
+
+    Band of a ReLU = max(band_eps(values per channel), DRIFT_FACTOR x drift), drift = the largest distance, in channel sigmas,
+    between this ReLU's input in the restatement's fp32 forward and in its fp64 forward — the MEASURED size of what separates two
+    correct evaluations at this depth (1e-5 at the first layers, 1e-4 ... 5e-4 at the end of ResNet-50's 49 units: the differences
+    of every layer pass through all the BatchNorms behind it)."""
     st = {k: torch.from_numpy(np.array(v)) for k, v in state.items()}
     st64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in st.items()}
     clips64 = [torch.from_numpy(np.asarray(c)).double() for c in q_clips]
+    clips32 = [c.float() for c in clips64]
     ws = len(clips64)
     prev = torch.get_default_dtype()
-    torch.set_default_dtype(torch.float64)
     moved: Dict[str, Dict[int, float]] = {}
     settled = 0          # ReLU events before this index are settled
     passes = 0
+    bands: Dict[int, float] = {}
+
+    def traces():
+        torch.set_default_dtype(torch.float64)
+        e64 = _trace_query(arch, fc_type, [st64] * ws, clips64)
+        torch.set_default_dtype(torch.float32)
+        st32 = {k: (v.float() if v.dtype == torch.float64 else v) for k, v in st64.items()}
+        e32 = _trace_query(arch, fc_type, [st32] * ws, clips32)
+        return e64, e32
+
     try:
         while True:
-            evs = _trace_query(arch, fc_type, [st64] * ws, clips64)
+            evs, evs32 = traces()
             passes += 1
             ev0 = evs[0]
             last_shift, fixed = None, False
@@ -108,8 +130,11 @@ def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: L
                 if e[0] != "relu" or i < settled:
                     continue
                 rows = np.concatenate([_channel_rows(ev[i][1]) for ev in evs], axis=1)
-                eps = EPS_WIDE if rows.shape[1] <= MANY else EPS_NARROW
+                rows32 = np.concatenate([_channel_rows(ev[i][1]) for ev in evs32], axis=1).astype(np.float64)
                 sd = np.maximum(rows.std(axis=1), 1e-30)
+                drift = float((np.abs(rows32 - rows).max(axis=1) / sd).max())
+                eps = max(band_eps(rows.shape[1]), DRIFT_FACTOR * drift)
+                bands[i] = eps
                 bad = np.nonzero(np.abs(rows).min(axis=1) < eps * sd)[0]
                 if bad.size == 0:
                     settled = i + 1
@@ -123,19 +148,27 @@ def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: L
                     st64[key][c] = float(new)
                     moved.setdefault(key, {})[int(c)] = float(new)
                 if verbose:
-                    print(f"  guard: {key}: {bad.size} of {rows.shape[0]} channels moved ({rows.shape[1]} values each)", flush=True)
+                    print(f"  guard: {key}: {bad.size} of {rows.shape[0]} channels moved ({rows.shape[1]} values each, band {eps:.1e} sigma, "
+                          f"fp32 drift {drift:.1e})", flush=True)
                 settled = i          # this event is checked again (fp32 rounding of the new values), then the walk goes on
                 fixed = True
                 break
             if not fixed:
                 break
             assert passes < 400, "guard band does not converge"
-        margins = relu_margins(evs)
+        # smallest |z| over the fp32 forward, in units of each ReLU's band: what another fp32 evaluation has left of the band
+        worst32 = 1e9
+        for i, e in enumerate(ev0):
+            if e[0] == "relu":
+                rows = np.concatenate([_channel_rows(ev[i][1]) for ev in evs], axis=1)
+                rows32 = np.concatenate([_channel_rows(ev[i][1]) for ev in evs32], axis=1).astype(np.float64)
+                sd = np.maximum(rows.std(axis=1), 1e-30)
+                worst32 = min(worst32, float((np.abs(rows32).min(axis=1) / sd).min() / bands[i]))
     finally:
         torch.set_default_dtype(prev)
     nudges = {k: (np.array(sorted(v), dtype=np.int32), np.array([v[c] for c in sorted(v)], dtype=np.float32)) for k, v in moved.items()}
-    report = {"passes": passes, "relus": len(margins), "min_margin": min(m for _, _, m in margins),
-              "channels_moved": int(sum(len(v) for v in moved.values())), "biases_touched": len(moved)}
+    report = {"passes": passes, "relus": len(bands), "band_min": min(bands.values()), "band_max": max(bands.values()),
+              "fp32_margin_in_bands": worst32, "channels_moved": int(sum(len(v) for v in moved.values())), "biases_touched": len(moved)}
     return nudges, report
 
 

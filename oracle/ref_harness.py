@@ -156,22 +156,26 @@ def run_reference_step(model, state: Dict[str, np.ndarray], im_q: np.ndarray, im
         return fn
 
     # knife-edge guards, measured on the reference's own fp32 forward of encoder_q.
-    #  * ReLU inputs: smallest |z| / (standard deviation of z's channel) over EVERY ReLU of the query pass.  The fixture's state
-    #    carries a guard band (oracle/guard.py: per-channel bias values moved so that no ReLU input is within 2e-5 ... 5e-5
-    #    channel-sigmas of zero, settled in fp64 on the restatement); this is the check that the band holds in the reference.
+    #  * ReLU inputs: smallest |z| / (standard deviation of z's channel) over EVERY ReLU of the query pass, in units of the layer's
+    #    band.  The fixture's state carries a guard band (oracle/guard.py: per-channel bias values moved so that no ReLU input is
+    #    within 2e-5 ... 2e-4 channel-sigmas of zero, settled in fp64 on the restatement); this is the check that the band holds
+    #    in the reference's fp32 forward (1.0 = exactly at the band's edge).
     #  * max-pool arg-max: top-2 gap per window of the small (<= 256 positions) disjoint-window layers, where one flipped
     #    arg-max moves a gradient tensor by a percent; gen_golden.py skips seeds whose gap is too small (a per-channel shift
     #    cannot open it).
     margins = []
     pool_margins = []
 
+    from oracle.guard import band_eps      # (margins are reported in units of the layer's band: >= ~0.5 means the band holds here too)
+
     def relu_hook(_mod, inp):          # pre-hook: several reference ReLUs are inplace
         x = inp[0].detach()
+        ws_ = dist.get_world_size() if dist.is_initialized() else 1
         if x.dim() == 5:
             sd = x.transpose(0, 1).reshape(x.shape[1], -1).std(dim=1).clamp_min(1e-30)
-            margins.append(float((x.abs().amin(dim=(0, 2, 3, 4)) / sd).min()))
+            margins.append(float((x.abs().amin(dim=(0, 2, 3, 4)) / sd).min()) / band_eps(ws_ * x.numel() // x.shape[1]))
         elif x.dim() == 2 and x.shape[0] > 1:
-            margins.append(float((x.abs().amin(dim=0) / x.std(dim=0).clamp_min(1e-30)).min()))
+            margins.append(float((x.abs().amin(dim=0) / x.std(dim=0).clamp_min(1e-30)).min()) / band_eps(ws_ * x.shape[0]))
 
     def pool_hook(mod, inp):           # top-2 gap per window
         x = inp[0].detach()

@@ -743,7 +743,11 @@ struct UnitPos {
   bool is_partial;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS>
+// FOLD > 0: two-level summation over K (round 6).  An MFMA tile accumulates all K products of an output in ONE fp32 chain, whose
+// rounding error grows with sqrt(K) (1.4e-6 relative at K = 13 824; the CPU reference's convolution sums K in panels: 3.4e-7 at every
+// K — DESIGN.md section 2).  With FOLD, the running accumulators are added into a second set every FOLD chunks (FOLD * 32 products per
+// panel) and cleared: two short chains instead of one long one, at the price of 64 more VGPRs (two waves per SIMD instead of three).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS, int FOLD = 0>
 __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg, const int nwg, const int n_units) {
   // HALF (BN = 32 * TN + 16, four waves stacked along M): the last 16 columns of the tile are two 16x16 blocks per wave on
   // v_mfma_f32_16x16x4_f32 — the same 64 flops per cycle and SIMD as the 32x32x2 form, so a 144-column segment (R(2+1)D's mid
@@ -1052,8 +1056,34 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
   };
 
   floatx16 acc[TM][TN];
+  floatx16 acc2[FOLD > 0 ? TM : 1][FOLD > 0 ? TN : 1];      // FOLD: the panels' sum
+  int fold_n = 0;                                           // chunks in the running panel
+  static_assert(FOLD == 0 || !HALF, "two-level summation: 32-wide column blocks only");
   floatx4 acch[2];      // HALF: rows 16*blk + 4*(lane / 16) + r of the wave's 32, column 32*TN + lane % 16
+  auto fold_panel = [&]() {      // running accumulators -> panel sum
+    if (FOLD > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            acc2[i][j][e] += acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+      fold_n = 0;
+    }
+  };
   auto zero_acc = [&]() {
+    if (FOLD > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+      fold_n = 0;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1327,6 +1357,7 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
       if (nbuf == 1) __syncthreads();    // every wave holds its fragments: the buffer may be overwritten
       load_chunk(nb);
       mfmas(af, bf, hf);
+      if (FOLD > 0 && ++fold_n == FOLD) fold_panel();
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       buf = nb;
@@ -1352,6 +1383,13 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
         if (next_have) load_chunk(nb);
       }
       mfmas(af, bf, hf);
+      if (FOLD > 0) {      // the unit's last chunk: the tile is the sum of its panels
+        fold_panel();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = acc2[i][j];
+      }
     } else {
       __syncthreads();
       if (has_next) {
@@ -1376,6 +1414,11 @@ __device__ __forceinline__ void igemm_persist(const IgemmParams& p, const int wg
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS, int MINW>
 __global__ __launch_bounds__(256, MINW) void igemm_persist_kernel(const IgemmParams p, const int n_units) {
   igemm_persist<BM, BN, WAVES_M, WAVES_N, KS>(p, (int)blockIdx.x, (int)gridDim.x, n_units);
+}
+// ... with two-level summation over K (see igemm_persist, FOLD): two waves per SIMD
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS, int FOLD>
+__global__ __launch_bounds__(256, 2) void igemm_persist_fold_kernel(const IgemmParams p, const int n_units) {
+  igemm_persist<BM, BN, WAVES_M, WAVES_N, KS, FOLD>(p, (int)blockIdx.x, (int)gridDim.x, n_units);
 }
 
 // Several independent problems of one tile shape in a single launch: the stride-parity classes of a strided convolution's
@@ -1928,15 +1971,21 @@ inline int narrow_bn(long long M, int Cout, int nchunks) {
 }
 inline int tile_bn_of(const IgemmParams& p) { return p.bn_narrow ? p.bn_narrow : tile_bn(p.Cout); }
 
-// 256 x 64 tiles for 33..64-column launches of at least one full round (round 6): four waves stacked along M, each 64 rows x 64
-// columns — the wave tile, accumulator count and LDS bytes per MFMA of the 128 x 128 instance (141 TF on C3D), where the 128 x 64
-// tile's waves (64 x 32) read 1.5 x the operand bytes per MFMA (R3D-18's stem and layer1, R(2+1)D's / S3D-G's 64-filter layers:
-// 113-122 TF).  A 32 KB + B 8 KB per tile buffer: ONE buffer, three workgroups per CU.
+// 256 x 64 tiles for 33..64-column launches (round 6): four waves stacked along M, each 64 rows x 64 columns — the
+// wave tile, accumulator count and LDS bytes per MFMA of the 128 x 128 instance (141 TF on C3D), where the 128 x 64 tile's waves
+// (64 x 32) read 1.5 x the operand bytes per MFMA.  A 32 KB + B 8 KB per tile buffer: ONE buffer, three workgroups per CU; 168 VGPRs with
+// 10-15 spilled (eight rows of loader state per thread instead of four).
+// MEASURED, OFF BY DEFAULT (profiles/r06/experiments_r6.txt): back to back, R3D-18's layer1 (slice-major K) gains 4 % (116.7 -> 121.3 TF
+// forward, 115.8 -> 120.5 input gradient), every tap-major candidate LOSES 1-2 % (the virtual-pixel stem 132.1 -> 131.0, R(2+1)D's
+// 144 -> 64 temporal convolution 108.8 -> 107.2, S3D-G's (7,1,1) 140.8 -> 138.4) and the 56 x 56 pointwise layer 22 %; per step R3D-18
+// 1325.7 -> 1320.4 clips/s, R(2+1)D 445.2 -> 442.0, S3D-G 418.5 -> 412.7, C3D 355.2 -> 354.1 (its 64-column input gradient of conv2:
+// 136.6 -> 135.1 TF).  The 128 x 64 tile is not LDS-bound: what it loses against the 128 x 128 tile is the per-tile fixed cost, and a tile
+// twice as tall pays the same cost per MFMA.  "tall_min_tiles" > 0 selects the instance (kernel tests, re-measurements).
 std::atomic<int> g_tall_min_tiles{-1};
 static int tall_min_tiles() {
   const int set = g_tall_min_tiles.load(std::memory_order_relaxed);
   if (set >= 0) return set;
-  static const int v = getenv("RSP_TALL_MIN_TILES") ? atoi(getenv("RSP_TALL_MIN_TILES")) : 768;      // (0: off; A/B switch, read once)
+  static const int v = getenv("RSP_TALL_MIN_TILES") ? atoi(getenv("RSP_TALL_MIN_TILES")) : 0;      // (0: off, the default; A/B switch, read once)
   return v;
 }
 inline bool tall_tiles(long long M, int bn, bool vec4) {
@@ -1996,6 +2045,42 @@ int launch_persist_cfg(const IgemmParams& p, hipStream_t s) {
   return rsp_check_launch("igemm_persist_kernel");
 }
 
+// Two-level summation over K on the long-K slice-major 128 x 128 launches (igemm_persist, FOLD): OFF by default — measured in round 6
+// (profiles/r06/experiments_r6.txt), see DESIGN.md section 2.  "two_level_min_chunks" (rsp_conv3d_set_option / RSP_TWO_LEVEL_MIN_CHUNKS):
+// launches of at least that many K chunks take the instance; 0: never.
+constexpr int FOLD_CHUNKS = 16;      // 512 products per panel
+std::atomic<int> g_two_level_min_chunks{-1};
+static int two_level_min_chunks() {
+  const int set = g_two_level_min_chunks.load(std::memory_order_relaxed);
+  if (set >= 0) return set;
+  static const int v = getenv("RSP_TWO_LEVEL_MIN_CHUNKS") ? atoi(getenv("RSP_TWO_LEVEL_MIN_CHUNKS")) : 0;
+  return v;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KS, int FOLD>
+int launch_persist_fold_cfg(const IgemmParams& p, hipStream_t s) {
+  const int ntaps = p.nTd * p.nTh * p.nTw;
+  auto lds_of = [&](int nbuf, int taps) {
+    return (size_t)nbuf * (BM + BN) * BK * sizeof(float) + (size_t)(taps + 2) / 2 * sizeof(int4) + BM * sizeof(unsigned) +
+           (size_t)WAVES_M * BN * 2 * sizeof(float) + 4 * sizeof(unsigned) + sizeof(IgemmParams);
+  };
+  const size_t lds = lds_of(p.nbuf, ntaps);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_persist_fold_kernel<BM, BN, WAVES_M, WAVES_N, KS, FOLD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(2, MAX_TAPS));
+    attr_set = true;
+  }
+  const int n_units = p.full_tiles + (p.m_tiles * p.n_tiles - p.full_tiles) * p.splitk;
+  int wpc = (int)(160 * 1024 / lds);
+  wpc = wpc > 2 ? 2 : (wpc < 1 ? 1 : wpc);
+  int G = 256 * wpc;
+  if (n_units <= G) G = n_units;
+  rsp_note_kernel("igemm_persist_fold_kernel<%d, %d, %d, %d, %s, %d>", BM, BN, WAVES_M, WAVES_N, KS ? "true" : "false", FOLD);
+  hipLaunchKernelGGL((igemm_persist_fold_kernel<BM, BN, WAVES_M, WAVES_N, KS, FOLD>), dim3(G), dim3(256), lds, s, p, n_units);
+  return rsp_check_launch("igemm_persist_fold_kernel");
+}
+
 // Segments of 129..144 columns: the 160-wide tile's plan (one N tile, same splits) on the instance whose fifth column block is 16
 // wide (igemm_persist, HALF).  RSP_NO_HALF_BLOCK=1: the 160-wide instance (A/B switch, read once).
 static bool half_block_cols(int cols) {
@@ -2020,6 +2105,8 @@ int launch_persist(IgemmParams& p, hipStream_t s) {
     return p.kmajor ? launch_persist_cfg<256, 64, 4, 1, true>(p, s) : launch_persist_cfg<256, 64, 4, 1, false>(p, s);
   }
   if (p.kmajor) {
+    if (bn == 128 && two_level_min_chunks() > 0 && p.nchunks >= two_level_min_chunks())
+      return launch_persist_fold_cfg<128, 128, 2, 2, true, FOLD_CHUNKS>(p, s);
     switch (bn) {
       case 160: return half_block(p) ? launch_persist_cfg<128, 144, 4, 1, true>(p, s) : launch_persist_cfg<128, 160, 4, 1, true>(p, s);
       case 128: return launch_persist_cfg<128, 128, 2, 2, true>(p, s);
@@ -2742,6 +2829,7 @@ const char* rsp_conv3d_kernel_name(const rsp_conv3d_desc* d, int which) {
   const bool long_tm128 = !ks && bn == 128 && kchunks >= 48;      // as in run_igemm_segment
   if (vec4 && persist_enabled() && !long_tm128 && out_b < 0x7ffffff0ull) {
     if (ks) {
+      if (bn == 128 && two_level_min_chunks() > 0 && kchunks >= two_level_min_chunks()) return "igemm_persist_fold_kernel<128, 128, 2, 2, true, 16>";
       switch (bn) {
         case 160: return half_block_cols(cols) ? "igemm_persist_kernel<128, 144, 4, 1, true, 2>" : "igemm_persist_kernel<128, 160, 4, 1, true, 2>";
         case 128: return "igemm_persist_kernel<128, 128, 2, 2, true, 3>";
@@ -3079,6 +3167,11 @@ int rsp_conv3d_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "narrow32_max_units")) {
     const int prev = narrow32_max_units();
     g_narrow32_max_units.store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    return prev;
+  }
+  if (name && !strcmp(name, "two_level_min_chunks")) {
+    const int prev = two_level_min_chunks();
+    g_two_level_min_chunks.store(value < 0 ? -1 : value, std::memory_order_relaxed);
     return prev;
   }
   if (name && !strcmp(name, "tall_min_tiles")) {

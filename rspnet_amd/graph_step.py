@@ -176,12 +176,29 @@ class GraphedPretextStep:
                     ("g", "main", "update", update)], box
         return self._lanes(box, top, gather, tail, update), box
 
-    # Plan nodes per piece of the backward (lanes mode) when weight gradients are set aside for the "w" lane; 0 (default): they stay
-    # in line and the backward is cut only where a gradient bucket completes.  Measured (profiles/r05/experiments_r5.txt): every extra
-    # graph costs ~50 us on the GPU side — R3D-18 1 259 clips/s with the backward as one graph, 1 235 with 8-node pieces + "w" lane,
-    # S3D-G 402 vs 398 — more than the weight gradients gain beside the input gradients.  RSP_BWD_PIECE for sweeps.
+    # Plan nodes per piece of the backward (lanes mode) when weight gradients are set aside for the "w" lane.  History: round 5 measured
+    # 8-node pieces everywhere at one rank — every extra graph costs ~50 us on the GPU side, R3D-18 1 259 -> 1 235, S3D-G 402 -> 398 — and
+    # kept the backward in one graph; round 6 re-measured with three pieces per backward, see `_backward_piece`.
     import os as _os
-    BACKWARD_PIECE = int(_os.environ.get("RSP_BWD_PIECE", "0"))
+    BACKWARD_PIECE = int(_os.environ.get("RSP_BWD_PIECE", "-1"))      # -1: the default policy of `_backward_piece`
+
+    def _backward_piece(self, coll: bool) -> int:
+        """Plan nodes per backward piece of the "lanes" schedule; 0: the backward is not cut (beyond the gradient-bucket boundaries).
+        Round 6, same-box A/Bs (profiles/r06/experiments_r6.txt r6b / r6c).  With the data-parallel collectives ON, pieces of about a
+        third of the plan with each piece's small weight gradients on the "w" lane beside the next piece: S3D-G 412.4 -> 422.5 clips/s
+        (40 of ~130 nodes; 25: 422.2), R3D-18 1282.9 -> 1319.0 (12 of 28 nodes; 6: 1315.7) — above the one-rank lines of the same box
+        (418.9 / 1315.8), and the gradient buckets leave from the "w" lane as they complete instead of after the whole backward.  At ONE
+        rank without collectives the same cut buys nothing (S3D-G 418.6 / 421.6 uncut vs 420.9 / 418.4 at 40 nodes: the backward is
+        throughput-bound) and costs three graphs: not cut.  RSP_BWD_PIECE overrides (sweeps)."""
+        if self.BACKWARD_PIECE >= 0:
+            return self.BACKWARD_PIECE
+        if not coll:
+            return 0
+        try:
+            n = len(self.model.encoder_q.plan().nodes)
+        except Exception:      # noqa: BLE001 - an encoder without a layer plan: no cut
+            return 0
+        return max(6, -(-n // 3))
 
     def _lanes(self, box, top, gather, tail, update):
         """The "lanes" schedule (see `_schedule`), a generator consumed by `_capture`."""
@@ -196,7 +213,9 @@ class GraphedPretextStep:
             m._last_draw = (m._last_draw[0], host["speed"]) + tuple(host["sh"])
 
         coll = bool(m._dp()[2])
-        if not coll:
+        piece_nodes = self._backward_piece(coll)
+        pieces = piece_nodes > 0
+        if not coll and not pieces:
             # One rank, no process group: no collective points, so the main lane needs only three graphs (every graph boundary
             # costs ~50 us on the GPU side, profiles/r05/experiments_r5.txt): top | key_kneg | everything behind the joins
             def rest(host):
@@ -218,28 +237,39 @@ class GraphedPretextStep:
         yield ("g", "main", "top", top)
         yield ("fork", "q")
         yield ("g", "q", "query", lambda host: m._pass_query(box["st"]))
-        yield ("e", "main", "all_to_all", exchange)
+        if coll:
+            yield ("e", "main", "all_to_all", exchange)
         yield ("fork", "k")
-        yield ("e", "k", "all_to_all_k", lambda host: m._wait_exchange(box["st"], 1))
+        if coll:
+            yield ("e", "k", "all_to_all_k", lambda host: m._wait_exchange(box["st"], 1))
         yield ("g", "k", "key_k", lambda host: m._pass_key(box["st"], 1))
         yield ("g", "main", "key_kneg", lambda host: m._pass_key(box["st"], 0))
         yield ("join", "k")
-        yield ("g", "main", "keys_join", lambda host: m._passes_join(box["st"]))
-        yield ("e", "main", "all_gather", gather)
-        yield ("join", "q")
-        yield ("g", "main", "tail", tail)      # ... up to the gradient of the query features (`_defer_backward`)
+        if coll:
+            yield ("g", "main", "keys_join", lambda host: m._passes_join(box["st"]))
+            yield ("e", "main", "all_gather", gather)
+            yield ("join", "q")
+            yield ("g", "main", "tail", tail)      # ... up to the gradient of the query features (`_defer_backward`)
+        else:
+            # one rank with the backward in pieces (BACKWARD_PIECE > 0): the joins and the tail share a graph
+            def joined_tail(host):
+                m._passes_join(box["st"])
+                tail(host)
+
+            yield ("join", "q")
+            yield ("g", "main", "tail", joined_tail)
         # the encoder's backward: pieces of the node chain on the main lane; the weight gradients a piece set aside
         # (engine.BranchStreams.deferred) as one graph on the "w" lane, beside the next piece; a gradient bucket whose last
         # parameter has been issued is all-reduced from the "w" lane's stream — behind everything that writes into it
         # (buckets of 64 MiB here: each one ends a graph, and an extra graph costs about what 10 MB of all-reduce do)
-        buckets = m._flat.buckets(2 * BUCKET_FLOATS)
+        buckets = m._flat.buckets(2 * BUCKET_FLOATS) if coll else []
         bw = {"it": None, "done": False, "tasks": [], "keep": [], "handed": set(), "launched": set(), "handles": []}
         box["backward"] = bw
 
         def piece(host):
             if bw["it"] is None:
                 bw["it"] = m._backward_iter()
-            BranchStreams.deferred = bw["tasks"] if self.BACKWARD_PIECE > 0 else None
+            BranchStreams.deferred = bw["tasks"] if pieces else None
             try:
                 n = 0
                 for handed in bw["it"]:
@@ -249,7 +279,7 @@ class GraphedPretextStep:
                     # (a cut where a bucket has just completed — unless every bucket has: what is left then is the end of the
                     #  chain, and the flush behind the loop takes the rest)
                     ready = not all(done_now) and any(d and bi not in bw["launched"] for bi, d in enumerate(done_now))
-                    if ready or (self.BACKWARD_PIECE > 0 and n >= self.BACKWARD_PIECE and bw["tasks"]):
+                    if ready or (pieces and n >= piece_nodes and bw["tasks"]):
                         return
                 bw["done"] = True
             finally:
@@ -276,28 +306,32 @@ class GraphedPretextStep:
                         h.wait()
 
         j = 0
+        used_w = False
         while not bw["done"]:
             yield ("g", "main", f"backward{j}", piece)
             forked = False
             if bw["tasks"]:
                 yield ("fork", "w")
-                forked = True
+                forked = used_w = True
                 yield ("g", "w", f"wgrad{j}", wgrads)
             for bi, (s, e, ids) in enumerate(buckets):
                 if bi not in bw["launched"] and all(pid in bw["handed"] for pid in ids):
                     bw["launched"].add(bi)
                     if not forked:
                         yield ("fork", "w")
-                        forked = True
+                        forked = used_w = True
                     yield ("e", "w", f"all_reduce{bi}", reducer(s, e))
             j += 1
         for bi, (s, e, ids) in enumerate(buckets):
             if bi not in bw["launched"]:
                 bw["launched"].add(bi)
                 yield ("fork", "w")
+                used_w = True
                 yield ("e", "w", f"all_reduce{bi}", reducer(s, e))
-        yield ("join", "w")
-        yield ("e", "main", "all_reduce_wait", reduce_wait)
+        if used_w:
+            yield ("join", "w")
+        if coll:
+            yield ("e", "main", "all_reduce_wait", reduce_wait)
         yield ("g", "main", "update", update)
         del bw["keep"][:]
         bw["it"] = None

@@ -99,11 +99,11 @@ def test_tile_plan_option_changes_the_dispatch_not_the_interface():
     # launches of at least a round of 256-row tiles take the 256 x 64 instance
     tiny = _lib.ConvDesc(16, 4, 14, 14, 512, 4, 14, 14, 64, 1, 1, 1, 1, 1, 1, 0, 0, 0, 512, 64)       # S3D-G branch3 pointwise: 98 tiles
     tall = _lib.ConvDesc(32, 8, 28, 28, 64, 8, 28, 28, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1, 64, 64)         # R3D-18 layer1: 784 tiles of 256 rows
-    assert name(tiny).startswith("igemm_persist_kernel<128, 32,") and name(tall) == "igemm_persist_kernel<256, 64, 4, 1, true, 3>"
-    assert lib.rsp_conv3d_set_option(b"narrow32_max_units", 0) == 256 and lib.rsp_conv3d_set_option(b"tall_min_tiles", 0) == 768
+    assert name(tiny).startswith("igemm_persist_kernel<128, 32,") and name(tall) == "igemm_persist_kernel<128, 64, 2, 2, true, 4>"
+    assert lib.rsp_conv3d_set_option(b"narrow32_max_units", 0) == 256 and lib.rsp_conv3d_set_option(b"tall_min_tiles", 768) == 0
     try:
-        assert name(tiny).startswith("igemm_persist_kernel<128, 64,") and name(tall) == "igemm_persist_kernel<128, 64, 2, 2, true, 4>"
+        assert name(tiny).startswith("igemm_persist_kernel<128, 64,") and name(tall) == "igemm_persist_kernel<256, 64, 4, 1, true, 3>"
     finally:
-        assert lib.rsp_conv3d_set_option(b"narrow32_max_units", -1) == 0 and lib.rsp_conv3d_set_option(b"tall_min_tiles", -1) == 0
-    assert name(tiny).startswith("igemm_persist_kernel<128, 32,") and name(tall).startswith("igemm_persist_kernel<256, 64,")
+        assert lib.rsp_conv3d_set_option(b"narrow32_max_units", -1) == 0 and lib.rsp_conv3d_set_option(b"tall_min_tiles", -1) == 768
+    assert name(tiny).startswith("igemm_persist_kernel<128, 32,") and name(tall).startswith("igemm_persist_kernel<128, 64,")
     assert lib.rsp_conv3d_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.rsp_last_error()

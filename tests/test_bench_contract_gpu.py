@@ -86,20 +86,18 @@ def test_bench_prints_one_contract_line():
 
 def test_bench_parity_object_replays_the_first_gpu_step():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
-                        "--hw", "32", "--queue", "64", "--cpu-sample", "4", "--cpu-steps", "1"],
+                        "--hw", "32", "--queue", "64", "--cpu-sample", "4", "--cpu-steps", "1", "--seed", "4"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
     p = d["parity"]
     assert p["forward_ok"] is True and p["grad_floor_rel_l2"] is not None and p["grad_ok"] is not None, p
     assert max(p["loss_rel"], p["logits_rel"], p["features_rel"], p["queue_slab_rel"]) <= 1e-3, p
-    # The whole gradient of this 4-clip state: its floor is 4.8e-6 (three alternative evaluations, none of which flips a mask), and
-    # the line's own rule (3 floors, never below 1e-4) holds as long as the HIP path flips none either — measured 8e-6.  ONE element
-    # of conv3a's output sits within rounding of zero, though: when round 5's 64-wide tiles changed that layer's K split, its ReLU
-    # mask flipped and the gradient moved by 6.1e-4 (bn3a.bias and everything below it by 1e-3, bn3a.weight untouched: x_hat = 0
-    # there — the signature of a knife edge, tools/grad_dump.py).  Either outcome is a correct evaluation; a backward BUG would not
-    # stay under 5e-3 on a state this small.
-    assert p["grad_ok"] is True or p["grad_rel_l2"] <= 5e-3, p
+    # The whole gradient of a 4-clip state whose floor is 6e-6 (no evaluation order flips a ReLU mask or an arg-max on it) under the
+    # line's own rule: 3 floors, never below 1e-4 — measured 1.1e-5.  The seed is chosen (profiles/r06/experiments_r6.txt, r6a (d):
+    # of eight seeds three are free of knife edges on both sides, on two the GPU flips one mask, on three the CPU oracle does); the
+    # default seed 1234 of this size has an element of conv3a's output within rounding of zero, which is why rounds 4-5 accepted 5e-3 here.
+    assert p["grad_ok"] is True and p["ok"] is True and p["grad_rel_l2"] <= 1e-4, p
     assert "other_workloads" not in d
 
 

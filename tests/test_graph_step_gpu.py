@@ -28,11 +28,16 @@ def _build(arch, K, speeds=(2,)):
 
 
 @pytest.mark.parametrize("arch,B,HW,mode", [("c3d", 4, 32, "lanes"), ("s3dg", 4, 64, "lanes"), ("resnet18", 8, 64, "lanes"),
-                                            ("s3dg", 4, 64, "whole"), ("r2plus1d-vcop", 4, 32, "lanes")])
+                                            ("s3dg", 4, 64, "whole"), ("r2plus1d-vcop", 4, 32, "lanes"),
+                                            ("s3dg", 4, 64, "lanes+pieces"), ("resnet18", 8, 64, "lanes+pieces")])
 def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
     """mode "lanes" (default): seven linear graphs, the three forward passes replayed side by side on three streams; "whole": one graph
-    with the forks inside the capture (rounds 2-4)."""
+    with the forks inside the capture (rounds 2-4); "lanes+pieces": the lanes with the backward cut into pieces of 30 plan nodes, the
+    small weight gradients of each piece replayed as a graph of their own on the "w" lane beside the next piece (round 6)."""
     from rspnet_amd.graph_step import GraphedPretextStep
+    pieces = mode.endswith("+pieces")
+    mode = mode.split("+")[0]
+    monkeypatch.setattr(GraphedPretextStep, "BACKWARD_PIECE", 30 if pieces else -1)
     monkeypatch.setenv("RSP_GRAPH_MODE", mode)
     K, steps = 64, 6
     clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(10 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
@@ -59,7 +64,11 @@ def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
             assert not stepper.disabled and stepper.mode == mode, stepper.fallback_reason
             assert len(stepper.graphs) == 1                      # warm-up steps ran eagerly, the rest replayed one captured schedule
             seq = next(iter(stepper.graphs.values()))[3]
-            assert sum(1 for op in seq if op[0] == "g") == (5 if mode == "lanes" else 1)      # (one rank: no collective points to cut at)
+            ng = sum(1 for op in seq if op[0] == "g")
+            if pieces:
+                assert ng >= 8 and any(op[0] == "g" and op[1] == "w" for op in seq), [op[:3] for op in seq]
+            else:
+                assert ng == (5 if mode == "lanes" else 1)      # (one rank: no collective points to cut at)
         results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
     (te, se), (tg, sg) = results
     for i, ((l0, o0, r0), (l1, o1, r1)) in enumerate(zip(te, tg)):

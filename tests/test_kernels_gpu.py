@@ -139,7 +139,8 @@ def test_conv_fwd_dgrad_wgrad(hip, case):
 
 
 # Round 6 instances, at sizes the checker finishes in seconds (the thresholds that select them are planning options of the library):
-#   * the 256 x 64 tile of the persistent kernel (tall_tiles: 33..64 columns, at least a round of tiles at full size) — tap-major and
+#   * the 256 x 64 tile of the persistent kernel (tall_tiles: 33..64 columns; OFF by default — measured neutral-to-negative per step in
+#     round 6, profiles/r06/experiments_r6.txt — and selected here through "tall_min_tiles") — tap-major and
 #     slice-major K, depth-major rows with frames longer / shorter than a tile (two linear runs / the per-row table), a ragged last
 #     tile, a K-split tail whose partial rows are 256-row tiles, bias + statistics on every tile, the input gradient of a 64-channel input;
 #   * 32-wide tiles with the whole K per unit for launches of less than one 128 x 64 unit per CU (narrow_bn), both K orders.
@@ -172,6 +173,7 @@ def test_conv_tall_and_narrow32_instances(hip, case):
     tall = case in TALL_CASES
     if tall:
         hip.set_option("tall_min_tiles", 2)
+        hip.set_option("narrow32_max_units", 0)      # (at these sizes the launch would otherwise count as a tiny one)
     try:
         y, st = hip.conv_fwd(g, xd, hip.conv_pack_fwd(g, wd), bd, True)
         kf = hip.lib.rsp_last_conv_kernel().decode()
@@ -180,6 +182,7 @@ def test_conv_tall_and_narrow32_instances(hip, case):
     finally:
         if tall:
             hip.set_option("tall_min_tiles", -1)
+            hip.set_option("narrow32_max_units", -1)
     close(y, y_ref, 2e-5, "conv fwd")
     close(st.double().sum(0), st_ref.double().sum(0), 2e-5, "stat partials")
     close(dx, dx_ref, 2e-5, "dgrad")
@@ -187,6 +190,40 @@ def test_conv_tall_and_narrow32_instances(hip, case):
         assert "<256, 64," in (kf if Cout > 32 else kd), (kf, kd)
     elif s == (1, 1, 1):
         assert "<128, 32," in kf, kf
+
+
+def test_conv_two_level_summation_instance(hip):
+    """igemm_persist_fold_kernel (round 6, OFF by default: "two_level_min_chunks"): the long-K slice-major 128-wide launch with K summed
+    in panels of 512 products.  Same convolution as the one-chain instance at the checker's tolerance, forward / statistics / input
+    gradient, with a K-split tail; against an fp64 convolution its error is the smaller one (the point of the instance)."""
+    N, D, H, W, Cin, Cout, k, s, p = (8, 4, 32, 32, 128, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1))      # 512 tiles of 128 x 128, K = 3456
+    g = ConvGeom(N, D, H, W, Cin, Cout, k, s, p)
+    x = rnd(N, D, H, W, Cin, seed=31)
+    w = rnd(Cout, Cin, *k, seed=32, scale=(Cin * 27) ** -0.5)
+    y_ref, st_ref = CPU.conv_fwd(g, x, w, None, True)
+    y64 = torch.nn.functional.conv3d(x[:1].double().permute(0, 4, 1, 2, 3), w.double(), None, s, p).permute(0, 2, 3, 4, 1)      # (first sample)
+    dy = rnd(*y_ref.shape, seed=34)
+    dx_ref = CPU.conv_dgrad(g, dy, w)
+    xd, wd = x.to(DEV), w.to(DEV)
+    wp = hip.conv_pack_fwd(g, wd)
+    y1, _ = hip.conv_fwd(g, xd, wp, None, True)
+    k1 = hip.lib.rsp_last_conv_kernel().decode()
+    hip.set_option("two_level_min_chunks", 8)
+    try:
+        y2, st2 = hip.conv_fwd(g, xd, wp, None, True)
+        k2 = hip.lib.rsp_last_conv_kernel().decode()
+        dx2 = hip.conv_dgrad(g, dy.to(DEV), wd)
+        kd = hip.lib.rsp_last_conv_kernel().decode()
+    finally:
+        hip.set_option("two_level_min_chunks", -1)
+    assert "fold" not in k1 and "igemm_persist_fold_kernel<128, 128" in k2, (k1, k2, kd)
+    close(y2, y_ref, 2e-5, "conv fwd (two-level)")
+    close(st2.double().sum(0), st_ref.double().sum(0), 2e-5, "stat partials (two-level)")
+    close(dx2, dx_ref, 2e-5, "dgrad (two-level)")
+    e1 = float((y1[:1].cpu().double() - y64).pow(2).mean().sqrt())
+    e2 = float((y2[:1].cpu().double() - y64).pow(2).mean().sqrt())
+    print(f"\nrms error against fp64 at K = {Cin * 27}: one chain {e1:.3e}, panels of 512 {e2:.3e}")
+    assert e2 < e1
 
 
 def _fuzz_cases(n=48, seed=20261002):
