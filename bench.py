@@ -619,6 +619,9 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
             "traffic_source": traffic_src,
             "kernel": dom, "launches": dn, "avg_launch_ms": round(dms / max(dn, 1), 4),
             "share_of_step": round(dms / roof_steps / step_ms, 4),
+            "share_of_conv_time": round(dms / ms, 4) if ms > 0 else None,
+            "share_note": "share_of_step = this kernel's SERIALISED time (one-stream roofline pass) over the TIMED step, whose passes overlap "
+                          "on side streams / lanes: an upper bound of the share; share_of_conv_time = over all convolution launches of the same pass",
             "algorithmic_gflop_per_launch": round(dflops / max(dn, 1) / 1e9, 2),
             "whole_step": {"algorithmic_conv_gflop_per_clip": round(flops / roof_steps / B / 1e9, 2),
                            "achieved": round(whole, 2), "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4),

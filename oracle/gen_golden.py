@@ -224,7 +224,7 @@ POOL_MARGIN = 1.5e-5
 POOL_FLOOR = 3e-6
 HINGE_MARGIN = 1e-3
 SCREEN_TOL = 3e-4
-MAX_SEEDS = {"c3d": 10}
+MAX_SEEDS = {"c3d": 10, "s3dg": 2}      # (an S3D-G seed takes ~10 minutes: 77 units to settle, 4 evaluations of the screen)
 MAX_SEEDS_DEFAULT = 6
 
 

@@ -122,7 +122,7 @@ def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: L
             evs, evs32 = traces()
             passes += 1
             ev0 = evs[0]
-            last_shift, fixed = None, False
+            last_shift, first_fixed = None, None
             for i, e in enumerate(ev0):
                 if e[0] == "shift":
                     last_shift = e[1]
@@ -137,7 +137,8 @@ def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: L
                 bands[i] = eps
                 bad = np.nonzero(np.abs(rows).min(axis=1) < eps * sd)[0]
                 if bad.size == 0:
-                    settled = i + 1
+                    if first_fixed is None:
+                        settled = i + 1
                     continue
                 assert last_shift is not None, "a ReLU without an additive per-channel term in front of it"
                 key = last_shift
@@ -150,9 +151,14 @@ def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: L
                 if verbose:
                     print(f"  guard: {key}: {bad.size} of {rows.shape[0]} channels moved ({rows.shape[1]} values each, band {eps:.1e} sigma, "
                           f"fp32 drift {drift:.1e})", flush=True)
-                settled = i          # this event is checked again (fp32 rounding of the new values), then the walk goes on
-                fixed = True
-                break
+                # Every violating ReLU of this pass is moved with the values of this pass: units that do not read one another (the
+                # branches of an inception block) settle together; a unit downstream of a moved one is simply checked — and, where its
+                # inputs have shifted onto a new near-zero element, moved — again in the next pass, which starts at the first moved one.
+                if first_fixed is None:
+                    first_fixed = i
+            fixed = first_fixed is not None
+            if fixed:
+                settled = first_fixed
             if not fixed:
                 break
             assert passes < 400, "guard band does not converge"
