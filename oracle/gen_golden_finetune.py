@@ -3,7 +3,8 @@ TEST INFRASTRUCTURE ONLY.
 
     python -m oracle.gen_golden_finetune
 
-Per backbone: portable state (oracle.portable.fill_state over the reference model's own state-dict spec), portable clips, labels
+Per backbone: portable state (oracle.portable.fill_state over the reference model's own state-dict spec, with the guard band of
+oracle/guard.py around the encoder's ReLU decisions: the moved BatchNorm bias values travel in the file), portable clips, labels
 -> eval-mode logits, train-mode logits, CrossEntropyLoss, summaries of every parameter gradient, post-forward BN buffers.
 The restatement (oracle.restatement.finetune_step / finetune_forward) is checked against the same run before writing."""
 import json
@@ -23,7 +24,7 @@ from oracle import restatement as S
 CASES = [("c3d", 4, 16, 32, 11, 4), ("resnet18", 4, 16, 64, 11, 9), ("r2plus1d-vcop", 4, 16, 32, 11, 1), ("s3dg", 4, 16, 64, 11, 8)]
 # S3D-G's deep stack decides some ReLU masks / pool arg-maxes by rounding on every seed (same situation as its pretext
 # fixtures: tests/golden_util.py, oracle/gen_conditioning.py); its screen is looser
-SEED_GATE = {"s3dg": 1e-2}
+SEED_GATE = {"s3dg": 2e-2}
 
 
 def product_grad_error(arch, ncls, state, x, target, grads):
@@ -58,15 +59,19 @@ def main():
             continue
         model = R.build_reference_finetune(arch, ncls)
         spec = R.state_spec(model)
+        from oracle import guard
         for seed in range(seed0, seed0 + 24):
             state = P.fill_state(spec, seed)
             x = P.clips(seed, 0, (B, 3, T, HW, HW))[0]
             target = ((np.arange(B) * 3 + seed) % ncls).astype(np.int64)
+            nudges, rep = guard.guard_band(arch, "linear", state, [x], forward=lambda sd, xx: S.finetune_forward(arch, sd, xx, training=True))
+            guard.apply_nudges(state, nudges)
+            print(f"{arch} seed {seed}: guard {rep}", flush=True)
             le, lt, loss, grads, post = R.run_reference_finetune(model, state, x, target)
             margin = float(post.pop("__margin__"))
             perr = product_grad_error(arch, ncls, state, x, target, grads)
             print(f"{arch} seed {seed}: checker-backend gradient error {perr:.1e}, ReLU / pool margin {margin:.1e}")
-            if perr <= SEED_GATE.get(arch, 2e-3) and (margin >= 3e-6 or arch == "s3dg"):
+            if perr <= SEED_GATE.get(arch, 3e-4) and (margin >= 3e-6 or arch == "s3dg"):
                 break
         else:
             raise SystemExit(f"{arch}: no well-conditioned seed found")
@@ -90,6 +95,9 @@ def main():
         for k, v in post.items():
             if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
                 out["post." + k] = P.summarise(k, v) if v.ndim else np.asarray(v)
+        for k, (idx, val) in nudges.items():
+            out["nudge.idx." + k] = np.asarray(idx, dtype=np.int32)
+            out["nudge.val." + k] = np.asarray(val, dtype=np.float32)
         tag = arch.replace("-", "_")
         with open(os.path.join(ROOT, "tests", "golden", f"finetune_spec_{tag}.json"), "w") as f:
             json.dump({k: [list(s), d] for k, (s, d) in spec.items()}, f)

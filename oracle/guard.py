@@ -40,15 +40,18 @@ def band_eps(values_per_channel: int) -> float:
     return 2e-4 if values_per_channel <= 4096 else (5e-5 if values_per_channel <= (1 << 16) else 2e-5)
 
 
-def _trace_query(arch: str, fc_type: str, states64: List[dict], q_clips: List[torch.Tensor]):
-    """One traced fp64 forward of encoder_q per rank -> per-rank event lists."""
+def _trace_query(arch: str, fc_type: str, states64: List[dict], q_clips: List[torch.Tensor], forward=None):
+    """One traced forward of encoder_q (or of `forward(state, clips)`: the fine-tune model) per rank -> per-rank event lists."""
     out = []
     for sd, x in zip(states64, q_clips):
         scratch = {k: (v.clone() if not v.is_floating_point() or k.endswith(("running_mean", "running_var")) else v) for k, v in sd.items()}
         S._TRACE[0] = ev = []
         try:
             with torch.no_grad():
-                S.encoder_forward(arch, scratch, "encoder_q", x, fc_type)
+                if forward is not None:
+                    forward(scratch, x)
+                else:
+                    S.encoder_forward(arch, scratch, "encoder_q", x, fc_type)
         finally:
             S._TRACE[0] = None
         out.append(ev)
@@ -90,9 +93,10 @@ def relu_margins(events_per_rank) -> List[Tuple[int, str, float]]:
 DRIFT_FACTOR = 6.0
 
 
-def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: List[np.ndarray], verbose: bool = False):
+def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: List[np.ndarray], verbose: bool = False, forward=None):
     """Returns ({bias key: (channel indices int32, NEW values float32)}, report).  `state`: the fixture's pre-step state (numpy,
-    not modified); q_clips: the query clips of every rank as encoder_q sees them (after _diff_speed).
+    not modified); q_clips: the query clips of every rank as encoder_q sees them (after _diff_speed).  forward(state, clips):
+    another traced forward than encoder_q's — the fine-tune model of oracle/gen_golden_finetune.py.
 
     Band of a ReLU = max(band_eps(values per channel), DRIFT_FACTOR x drift), drift = the largest distance, in channel sigmas,
     between this ReLU's input in the restatement's fp32 forward and in its fp64 forward — the MEASURED size of what separates two
@@ -111,10 +115,10 @@ def guard_band(arch: str, fc_type: str, state: Dict[str, np.ndarray], q_clips: L
 
     def traces():
         torch.set_default_dtype(torch.float64)
-        e64 = _trace_query(arch, fc_type, [st64] * ws, clips64)
+        e64 = _trace_query(arch, fc_type, [st64] * ws, clips64, forward)
         torch.set_default_dtype(torch.float32)
         st32 = {k: (v.float() if v.dtype == torch.float64 else v) for k, v in st64.items()}
-        e32 = _trace_query(arch, fc_type, [st32] * ws, clips32)
+        e32 = _trace_query(arch, fc_type, [st32] * ws, clips32, forward)
         return e64, e32
 
     try:

@@ -20,6 +20,9 @@ def load(arch):
     with open(os.path.join(GOLDEN, f"finetune_spec_{tag}.json")) as f:
         spec = {k: (tuple(s), d) for k, (s, d) in json.load(f).items()}
     state = P.fill_state(spec, meta["seed"])
+    from oracle.gen_golden import nudges_from_npz
+    for key, (idx, val) in nudges_from_npz(z).items():      # the fixture's guard band (oracle/guard.py): part of its state
+        state[key][np.asarray(idx, dtype=np.int64)] = np.asarray(val, dtype=np.float32)
     x = P.clips(meta["seed"], 0, (meta["B"], 3, meta["T"], meta["HW"], meta["HW"]))[0]
     return z, meta, spec, state, x
 
@@ -66,9 +69,9 @@ def check_case(arch, device, fwd_tol):
                 worst = max(worst, P.proj_rel_err(n, mine, z["gradproj." + n]), abs(l2 - g[0]) / g[0])
             else:
                 worst = max(worst, summary_err(n, mine, g))
-    # (the fine-tune fixtures have no conditioning floor of their own in tests/golden/conditioning.json: the pretext family's gate,
-    #  but not below the 2e-2 these fixtures were generated against)
-    assert worst <= max(grad_tol(arch), 2e-2), worst
+    # (the fine-tune fixtures carry the same guard band as the pretext ones and are screened against the checker backend at 3e-4
+    #  — S3D-G 2e-2 —: the pretext family's gate)
+    assert worst <= grad_tol(arch), worst
     post = model.state_dict()
     for name in z.files:
         if name.startswith("post."):

@@ -40,6 +40,17 @@ with open(os.path.join(GOLDEN, "conditioning.json")) as _f:
 FWD_TOL_BY_ARCH = {"s3dg": 1e-3}
 
 
+# S3D-G is the exception: the whole-step gate of its family has a minimum of its own.  A guard band removes the ReLU knife edges, but
+# S3D-G also has nine OVERLAPPING 3x3x3 stride-1 max-pools (models/s3dg.py:92-96) behind 30-70 units of depth, where the forward values
+# of two correct fp32 evaluations have drifted 1e-4 channel-sigmas apart (oracle/guard.py measures 4e-4 at the last unit): at the
+# 4x4x4 stage ~100 windows per evaluation pair hold their top two within that drift, each routing its gradient to another position,
+# and a per-channel shift cannot separate two elements of one channel.  Measured: the oracle's own fp32 evaluation orders differ by
+# 1.2e-3 ... 1.2e-1 (median 1.4e-2) in the worst tensor over the 13 S3D-G seeds round 6 generated (profiles/r06/experiments_r6.txt), the
+# HIP path sits 5.3e-3 (1 rank) / 2.4e-2 (2 ranks) from the two committed fixtures.  The family's gate therefore stays at round 5's
+# 5e-2 — now under ONE plan; its exact check is the teacher-forced replay of every op at 2e-5 (tests/test_teacher_forced_gpu.py).
+FAMILY_TOL_MIN = {"s3dg": 5e-2}
+
+
 def grad_tol(arch, ws=1):
     """Three floors.  A 1-rank fixture is held to its family's 1-rank floor; a multi-rank fixture to the larger of its own floor
     (`arch@wsN` in conditioning.json) and the family's 1-rank floor.  A floor is the worst of three alternative evaluations of ONE
@@ -49,7 +60,15 @@ def grad_tol(arch, ws=1):
     floor = CONDITIONING.get(arch, {}).get("grad_rel_l2_max", 0.0)
     if ws > 1:
         floor = max(floor, CONDITIONING.get(f"{arch}@ws{ws}", {}).get("grad_rel_l2_max", 0.0))
-    return max(GRAD_TOL_MIN, 3.0 * floor)
+    return max(GRAD_TOL_MIN, FAMILY_TOL_MIN.get(arch.split(":")[0], 0.0), 3.0 * floor)
+
+
+def checker_tol(arch, ws=1):
+    """The gate for runs of the product's HOST LOGIC on the torch checker backend (tests/cpu_ops.py: channels-last convolutions,
+    folded BatchNorm — tests of exchange plans, flat buffers, bucketed all-reduce, not of kernels).  The checker is one more fp32
+    evaluation order; the fixtures' seeds are screened against it at one rank only, and at two ranks it flips one arg-max of C3D's
+    pool1 on seed 8 (bn1.bias 1.8e-3, where the HIP path sits at 9e-6): 5e-3, or the family's gate."""
+    return max(grad_tol(arch, ws), 5e-3)
 
 
 def fwd_tol(arch, default):

@@ -19,7 +19,7 @@ def _worker(rank, ws, arch, seed, port, tmp, issue="eager"):
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
     from cpu_ops import CpuOps
-    from golden_util import build_inputs, compare_to_golden, load_case, worst_grad_err, fwd_tol, grad_tol
+    from golden_util import build_inputs, checker_tol, compare_to_golden, load_case, worst_grad_err, fwd_tol
     from model_util import run_model_step
     from rspnet_amd import ops
     torch.set_num_threads(4)
@@ -30,9 +30,9 @@ def _worker(rank, ws, arch, seed, port, tmp, issue="eager"):
     z, meta = load_case(arch, ws, seed)
     spec, inputs = build_inputs(arch, meta)
     res, post, mom_post, grads = run_model_step(arch, meta, inputs, rank, torch.device("cpu"), "fused", issue=issue)
-    errs = compare_to_golden(z, rank, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=grad_tol(arch, ws))
+    errs = compare_to_golden(z, rank, res, post, mom_post, tol=fwd_tol(arch, 2e-4), tol_grad=checker_tol(arch, ws))
     wkey, worst = worst_grad_err(z, rank, grads)
-    assert worst <= grad_tol(arch, ws), (wkey, worst)
+    assert worst <= checker_tol(arch, ws), (wkey, worst)
     np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([worst]))
     dist.barrier()
     dist.destroy_process_group()

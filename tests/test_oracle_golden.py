@@ -30,3 +30,24 @@ def test_portable_generator_is_stable():
     assert np.allclose(P.uniform01("x", 3, 4), u)
     p = P.permutation("perm:0", 1, 8)
     assert sorted(p.tolist()) == list(range(8))
+
+
+@pytest.mark.parametrize("arch,ws,seed", ALL_CASES)
+def test_fixture_carries_its_guard_band(arch, ws, seed):
+    """Every pretext fixture's pre-step state holds the guard band of oracle/guard.py: rebuilt from the portable seeds + the bias
+    values stored in the file, no ReLU input of the query pass (any rank) lies closer to zero than 0.6 of the band's floor (2e-5 ...
+    2e-4 channel-sigmas by channel size) in the restatement's fp32 forward — the decisions a whole-step gradient comparison is
+    discontinuous in are not left to anyone's rounding."""
+    import torch
+    from oracle import guard
+    from oracle import restatement as S
+    z, meta = load_case(arch, ws, seed)
+    assert meta["nudges"], "no guard band in the fixture"
+    spec, (state, mom, clips, perms_B, sh) = build_inputs(arch, meta)
+    q = [S.diff_speed(torch.from_numpy(clips[r][0]), torch.from_numpy(clips[r][1]), torch.from_numpy(perms_B[r]), meta["speed"])[0]
+         for r in range(ws)]
+    st = {k: torch.from_numpy(v.copy()) for k, v in state.items()}
+    evs = guard._trace_query(meta["arch"], meta.get("fc_type", "linear"), [st] * ws, q)
+    margins = guard.relu_margins(evs)
+    worst = min(margins, key=lambda t: t[2])
+    assert len(margins) >= 8 and worst[2] >= 0.6, worst
