@@ -21,9 +21,18 @@ def test_step_matches_golden(arch, seed, optimizer):
     assert ops.backend().name == "hip"
     z, meta = load_case(arch, 1, seed)
     spec, inputs = build_inputs(arch, meta)
-    from golden_util import check_step_gradients
-    errs, worst, plan, post = check_step_gradients(arch, 1, 0, z, lambda: run_model_step(arch, meta, inputs, 0, torch.device("cuda", 0),
-                                                                                      optimizer), TOL)
+    from golden_util import check_step_gradients, grad_stats
+    kept = {}
+
+    def step():
+        out = run_model_step(arch, meta, inputs, 0, torch.device("cuda", 0), optimizer)
+        kept["stats"] = grad_stats(z, 0, out[3])
+        st = kept["stats"]
+        print(f"\n{arch} seed {seed} gradient tensors vs golden: worst {st['worst'][1]:.2e} ({st['worst'][0]}), p90 {st['p90']:.2e}, "
+              f"median {st['median']:.2e}, whole gradient {st['whole']:.2e} ({st['n']} tensors)")
+        return out
+
+    errs, worst, plan, post = check_step_gradients(arch, 1, 0, z, step, TOL)
     assert list(post.keys()) == list(spec.keys())
     print(f"\n{arch} seed {seed} [{optimizer}] ({plan} tile plan) rel errs: " + ", ".join(f"{k}={v:.2e}" for k, v in errs.items())
           + f", grads={worst:.2e}")

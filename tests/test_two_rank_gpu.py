@@ -67,6 +67,8 @@ def _run_rank(rank, ws, arch, seed, lock, tls, out, dev):
         mom_post = {names[id(p)]: opt.state[p]["momentum_buffer"].detach().cpu().numpy() for p in params
                     if "momentum_buffer" in opt.state[p]}
         gate = grad_tol(arch, 2)
+        from golden_util import grad_stats
+        out[("stats", rank)] = grad_stats(z, rank, grads)
         errs = compare_to_golden(z, rank, res, post, mom_post, tol=TOL, tol_grad=gate)
         wkey, worst = worst_grad_err(z, rank, grads)
         assert worst <= gate, (wkey, worst)
@@ -142,6 +144,10 @@ def run_two_ranks(arch, seed, dev):
         torch._C._distributed_c10d._set_thread_isolation_mode(False)
         tpg._uninstall_threaded_pg()
     for r in range(ws):
+        if ("stats", r) in out:
+            st = out[("stats", r)]
+            print(f"\n{arch} rank {r} gradient tensors vs golden: worst {st['worst'][1]:.2e} ({st['worst'][0]}), p90 {st['p90']:.2e}, "
+                  f"median {st['median']:.2e}, whole gradient {st['whole']:.2e} ({st['n']} tensors)")
         if isinstance(out.get(r), BaseException):
             raise out[r]
         assert r in out, f"rank {r} produced nothing"
