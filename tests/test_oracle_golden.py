@@ -51,3 +51,20 @@ def test_fixture_carries_its_guard_band(arch, ws, seed):
     margins = guard.relu_margins(evs)
     worst = min(margins, key=lambda t: t[2])
     assert len(margins) >= 8 and worst[2] >= 0.6, worst
+
+
+def test_guard_shift_is_the_smallest_admissible_one():
+    """oracle/guard.py:_shift_for — the bias movement of one channel: after it no value lies inside the band, and no smaller movement
+    (either sign) would do (checked against a dense scan)."""
+    from oracle.guard import _shift_for, band_eps
+    rng = np.random.default_rng(5)
+    assert band_eps(32) == band_eps(4096) > band_eps(4097) == band_eps(1 << 16) > band_eps((1 << 16) + 1)
+    for n, band in ((32, 2e-4), (256, 2e-3), (2048, 3e-4), (20000, 5e-5)):
+        vals = rng.standard_normal(n)
+        vals[rng.integers(0, n, 3)] = rng.uniform(-band, band, 3)            # a few values inside the band
+        d = _shift_for(vals, band)
+        assert np.abs(vals + d).min() >= band * (1 - 1e-12)
+        scan = np.linspace(-abs(d), abs(d), 4001)[1:-1]                        # every strictly smaller |movement|
+        ok = np.abs(vals[None, :] + scan[:, None]).min(axis=1) >= band
+        assert not ok[np.abs(scan) < abs(d) * (1 - 1e-3)].any(), (n, band, d)
+    assert _shift_for(np.array([0.5, -0.7, 1.2]), 1e-3) == 0.0                 # nothing inside the band: nothing moves
