@@ -459,6 +459,11 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         seg_gpu = {}
         for name, e0, e1 in gev:
             seg_gpu.setdefault(name, []).append(e0.elapsed_time(e1))
+        # ... and between one graph's end and the next graph's start (consecutive replays in issue order; graphs of different lanes
+        # overlap, so a negative value means "started before the previous one ended")
+        for (n0, _, e1), (n1, e0, _) in zip(gev[:-1], gev[1:]):
+            if not n1.startswith("main:top"):
+                seg_gpu.setdefault(f"gap {n0} -> {n1}", []).append(e1.elapsed_time(e0))
         seg_gpu = {k: round(_pct(v, 0.5), 3) for k, v in seg_gpu.items()}
     else:
         seg_gpu = None
@@ -525,6 +530,11 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
             eager_step()
         fence()
         res["eager_ms_per_step"] = (time.perf_counter() - te) / args.eager_steps * 1e3
+    if cuda:
+        # do the side lanes (query pass / second key pass / weight gradients) really run beside the main stream?  (HIP multiplexes
+        # streams onto a few hardware queues: rspnet_amd/streams.py measures it)
+        from rspnet_amd import streams as _streams
+        res["lanes_overlap_main"] = _streams.lanes_overlap(dev)
     if stepper is not None and not graphed:
         why = stepper.fallback_reason or "not captured within the warm-up steps"
         res["issue_policy" if why.startswith("issued eagerly by policy") else "graph_fallback"] = why
@@ -771,7 +781,7 @@ def run_rank(args):
             res["issued_eagerly"] = {"ms_per_step": round(m["eager_ms_per_step"], 3),
                                      "clips_per_s": round(ws * B / m["eager_ms_per_step"] * 1e3, 2), "steps": args.eager_steps,
                                      "note": "same step, eager launches with the same side streams: how N > 1 ranks issue it"}
-        for k in ("steps_ms", "comm_ms", "roofline", "hbm_kernels", "graph_fallback", "issue_policy"):
+        for k in ("steps_ms", "comm_ms", "roofline", "hbm_kernels", "graph_fallback", "issue_policy", "lanes_overlap_main"):
             if k in m:
                 res[k] = m[k]
     # BASELINE.json configs 3-5 on the same box (N=1, default run only): the other three backbones at their own batch / clip

@@ -346,7 +346,14 @@ class BranchStreams:
         key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(), key)
         st = BranchStreams._streams.get(key)
         if st is None:
-            st = BranchStreams._streams[key] = torch.cuda.Stream(device=self.dev)
+            # the weight-gradient side task shares the process's "w" lane: one of three streams MEASURED to overlap with the
+            # main stream and with one another (rspnet_amd/streams.py: HIP multiplexes streams onto a few hardware queues)
+            if key[1] == "task":
+                from . import streams as _streams
+                st = _streams.lane(self.dev, "w")
+            else:
+                st = torch.cuda.Stream(device=self.dev)
+            BranchStreams._streams[key] = st
         return st
 
     def side_task(self, fn, keepalive):

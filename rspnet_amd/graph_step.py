@@ -184,21 +184,28 @@ class GraphedPretextStep:
 
     def _backward_piece(self, coll: bool) -> int:
         """Plan nodes per backward piece of the "lanes" schedule; 0: the backward is not cut (beyond the gradient-bucket boundaries).
-        Round 6, same-box A/Bs (profiles/r06/experiments_r6.txt r6b / r6c).  With the data-parallel collectives ON, pieces of about a
-        third of the plan with each piece's small weight gradients on the "w" lane beside the next piece: S3D-G 412.4 -> 422.5 clips/s
-        (40 of ~130 nodes; 25: 422.2), R3D-18 1282.9 -> 1319.0 (12 of 28 nodes; 6: 1315.7) — above the one-rank lines of the same box
-        (418.9 / 1315.8), and the gradient buckets leave from the "w" lane as they complete instead of after the whole backward.  At ONE
-        rank without collectives the same cut buys nothing (S3D-G 418.6 / 421.6 uncut vs 420.9 / 418.4 at 40 nodes: the backward is
-        throughput-bound) and costs three graphs: not cut.  RSP_BWD_PIECE overrides (sweeps)."""
+        Pieces of a ninth of the plan, at least 12 nodes (S3D-G: 15 of ~130, R3D-18: 12 of 28), each piece's small weight gradients
+        replayed as a graph of their own on the "w" lane beside the next piece (and, with a process group, the gradient buckets leaving from that lane as they complete) — WHEN the "w" lane
+        really runs beside the main lane.  Round 6 (profiles/r06/experiments_r6.txt r6b-j): HIP multiplexes streams onto four hardware
+        queues, and a "w" stream that shares the main lane's queue replays its graphs BETWEEN the pieces: three extra graphs for
+        nothing (S3D-G 420.2 uncut vs 419.0-420.9 cut, one rank).  With the lanes on queues of their own (rspnet_amd/streams.py
+        measures it) the cut gives S3D-G 427.1 at 15 nodes, 421.7 at 44, 417.4 uncut on one box (+2.3 %; another box, eight hardware
+        queues: 426.9 at 15, 425.5 at 25, 426.0 at 40, 422.2 at 60, 420.2 uncut); with the collectives on, where the
+        process group's streams had happened to shift the "w" lane onto a free queue, S3D-G 412.4 -> 422.5 and R3D-18 1282.9 -> 1319.0.
+        RSP_BWD_PIECE overrides (sweeps)."""
         if self.BACKWARD_PIECE >= 0:
             return self.BACKWARD_PIECE
-        if not coll:
-            return 0
         try:
             n = len(self.model.encoder_q.plan().nodes)
+            dev = self.model.queue.device
+            if dev.type != "cuda":
+                return max(12, -(-n // 9)) if coll else 0         # (host-logic tests on the checker backend: the data-parallel cut)
+            from . import streams as _streams
+            if not _streams.lanes_overlap(dev).get("w", False):
+                return 0                                         # the weight-gradient lane would only wait its turn
         except Exception:      # noqa: BLE001 - an encoder without a layer plan: no cut
             return 0
-        return max(6, -(-n // 3))
+        return max(12, -(-n // 9))
 
     def _lanes(self, box, top, gather, tail, update):
         """The "lanes" schedule (see `_schedule`), a generator consumed by `_capture`."""
@@ -558,7 +565,10 @@ class GraphedPretextStep:
                 for op in ops:
                     lane = op[1]
                     if lane != "main" and lane not in self.lane_streams:
-                        self.lane_streams[lane] = torch.cuda.Stream(device=dev)
+                        # (the process's three measured-to-overlap side streams: rspnet_amd/streams.py; assigned before the first
+                        #  capture of this call begins — `lane` never measures inside one)
+                        from . import streams as _streams
+                        self.lane_streams[lane] = _streams.lane(dev, lane) if lane in ("q", "k", "w") else torch.cuda.Stream(device=dev)
                     if op[0] != "g":
                         seq.append(op)
                         continue

@@ -24,6 +24,7 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 from .. import ops as _ops
+from .. import streams as _streams
 from ..engine import INPUT_CHANNEL_PAD
 from ..flat import FlatEncoderPair
 
@@ -679,7 +680,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         side = None
         if self.overlap_query and dev.type == "cuda" and (torch.cuda.is_current_stream_capturing() or self.overlap_query_eager):
             main = torch.cuda.current_stream(dev)
-            side = self._query_stream = self._query_stream or torch.cuda.Stream(device=dev)
+            side = self._query_stream = self._query_stream or _streams.lane(dev, "q")
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._pass_query(st)
@@ -690,7 +691,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         side_k = None
         if side is not None and self.overlap_keys:
             main = torch.cuda.current_stream(dev)
-            side_k = self._key_stream = self._key_stream or torch.cuda.Stream(device=dev)
+            side_k = self._key_stream = self._key_stream or _streams.lane(dev, "k")
             side_k.wait_stream(main)
             with torch.cuda.stream(side_k):
                 self._pass_key(st, 1)

@@ -29,15 +29,16 @@ def _build(arch, K, speeds=(2,)):
 
 @pytest.mark.parametrize("arch,B,HW,mode", [("c3d", 4, 32, "lanes"), ("s3dg", 4, 64, "lanes"), ("resnet18", 8, 64, "lanes"),
                                             ("s3dg", 4, 64, "whole"), ("r2plus1d-vcop", 4, 32, "lanes"),
-                                            ("s3dg", 4, 64, "lanes+pieces"), ("resnet18", 8, 64, "lanes+pieces")])
+                                            ("s3dg", 4, 64, "lanes+pieces"), ("resnet18", 8, 64, "lanes+pieces"), ("s3dg", 4, 64, "lanes+uncut")])
 def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
     """mode "lanes" (default): seven linear graphs, the three forward passes replayed side by side on three streams; "whole": one graph
     with the forks inside the capture (rounds 2-4); "lanes+pieces": the lanes with the backward cut into pieces of 30 plan nodes, the
     small weight gradients of each piece replayed as a graph of their own on the "w" lane beside the next piece (round 6)."""
     from rspnet_amd.graph_step import GraphedPretextStep
-    pieces = mode.endswith("+pieces")
+    pieces, uncut = mode.endswith("+pieces"), mode.endswith("+uncut")
     mode = mode.split("+")[0]
-    monkeypatch.setattr(GraphedPretextStep, "BACKWARD_PIECE", 30 if pieces else -1)
+    # ("lanes": the default policy — the backward in pieces when the "w" lane is on a hardware queue of its own, rspnet_amd/streams.py)
+    monkeypatch.setattr(GraphedPretextStep, "BACKWARD_PIECE", 30 if pieces else (0 if uncut else -1))
     monkeypatch.setenv("RSP_GRAPH_MODE", mode)
     K, steps = 64, 6
     clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(10 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
@@ -67,8 +68,10 @@ def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
             ng = sum(1 for op in seq if op[0] == "g")
             if pieces:
                 assert ng >= 8 and any(op[0] == "g" and op[1] == "w" for op in seq), [op[:3] for op in seq]
-            else:
+            elif uncut or mode == "whole":
                 assert ng == (5 if mode == "lanes" else 1)      # (one rank: no collective points to cut at)
+            else:
+                assert ng >= 5
         results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()}))
     (te, se), (tg, sg) = results
     for i, ((l0, o0, r0), (l1, o1, r1)) in enumerate(zip(te, tg)):
@@ -142,3 +145,26 @@ def test_issue_policy_graphs_only_the_host_bound_step():
             assert not stepper.graphs and len(stepper.eager_keys) == 1 and "by policy" in stepper.fallback_reason
         del stepper, wrapped, crit, opt
         torch.cuda.empty_cache()
+
+
+def test_side_lanes_are_on_hardware_queues_of_their_own():
+    """rspnet_amd/streams.py: the three side lanes (query pass, second key pass, weight gradients) are chosen by MEASUREMENT so that each
+    overlaps with the main stream and with the others — HIP multiplexes streams onto four hardware queues, and two lanes on one queue run
+    one after the other whatever the events say (round 6: the "w" lane of the replayed step sat on the main lane's queue).  Two spin
+    kernels, one per stream, must finish in the time of one for every pair; a pair known to share a stream must not."""
+    import time
+    from rspnet_amd import streams
+    main = torch.cuda.current_stream(DEV)
+    lanes = [streams.lane(DEV, n) for n in ("q", "k", "w")]
+    assert len({s.cuda_stream for s in lanes} | {main.cuda_stream}) == 4
+    assert streams.lanes_overlap(DEV) == {"q": True, "k": True, "w": True}
+    cycles = streams._spin_cycles(DEV)
+    one = min(streams._timed([main], DEV, cycles) for _ in range(3))
+    for i, a in enumerate([main] + lanes):
+        for b in lanes[i:]:
+            if a.cuda_stream == b.cuda_stream:
+                continue
+            both = min(streams._timed([a, b], DEV, cycles) for _ in range(3))
+            assert both < 1.5 * one, (i, both, one)
+    same = min(streams._timed([lanes[0], lanes[0]], DEV, cycles) for _ in range(3))
+    assert same > 1.7 * one, (same, one)          # (the measurement itself tells one queue from two)
