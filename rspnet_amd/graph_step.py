@@ -29,16 +29,22 @@ plain chain, and the concurrency lives BETWEEN graphs, on streams the stepper or
     main lane   top (momentum update, _diff_speed, the three clip gathers)              [clip all-to-all x2: eager RCCL calls]
     main | q | k   key_kneg | query | key_k   three linear graphs replayed side by side on three streams
     main lane   keys_join (deferred BatchNorm statistics, feature stack)                [key all-gather]
-    main lane   tail (un-shuffle, logits, losses, enqueue, the whole backward)          [gradient all-reduce, 32 MiB buckets]
+    main lane   tail (un-shuffle, logits, losses, enqueue, the heads' backward)
+    main | w    the encoder's backward in pieces (`_backward_piece`); each piece's small weight gradients replay as a graph of their
+                own on the "w" lane beside the NEXT piece                               [gradient all-reduce, 32 MiB buckets, from "w"]
     main lane   update (DDP's 1/ws average, SGD)
+
+The side lanes q / k / w are streams MEASURED to run beside the main stream and one another (rspnet_amd/streams.py): HIP maps a
+process's streams onto four hardware queues in creation order, and two lanes that share a queue run one after the other whatever the
+events say (round 6: the "w" lane sat on the main lane's queue and bought nothing until it was moved; profiles/r06/experiments_r6.txt).
 
 The collective points of the data-parallel step fall between graphs, so the SAME schedule serves one rank and N > 1 (RCCL calls
 cannot be captured on this stack: hipStreamEndCapture segfaults, profiles/r04/experiments_r4.txt); with one rank and no process
 group the collective slots are empty.  Each lane's graphs share a memory pool (they replay in capture order), different lanes have
-different pools.  What the lanes give up against the forked capture: weight gradients no longer run beside the input gradient inside
-the backward (engine.BranchStreams is off in a linear capture).  What the data-parallel step gives up against eager issue: the
-second clip exchange no longer hides under the first key pass and the bucket all-reduces no longer start inside the backward — a
-fraction of a millisecond each over xGMI, the price of not being Python-bound.  mode "segments": four graphs between
+different pools.  What the lanes give up against the forked capture: S3D-G's sibling branches run one after the other inside a
+lane (the three passes side by side fill the machine instead).  What the data-parallel step gives up against eager issue: the
+second clip exchange no longer hides under the first key pass — a fraction of a millisecond over xGMI, the price
+of not being Python-bound; the bucket all-reduces do start inside the backward, at piece boundaries.  mode "segments": four graphs between
 the collective points with the forks inside (round 5's first version); "whole": one graph, forks inside (rounds 2-4; N = 1 only).
 Any failure to capture falls back to the eager loop with a logged warning — the result is the same either way, kernel for kernel.
 
@@ -178,7 +184,7 @@ class GraphedPretextStep:
 
     # Plan nodes per piece of the backward (lanes mode) when weight gradients are set aside for the "w" lane.  History: round 5 measured
     # 8-node pieces everywhere at one rank — every extra graph costs ~50 us on the GPU side, R3D-18 1 259 -> 1 235, S3D-G 402 -> 398 — and
-    # kept the backward in one graph; round 6 re-measured with three pieces per backward, see `_backward_piece`.
+    # kept the backward in one graph; round 6 found why (the "w" lane shared the main lane's hardware queue), see `_backward_piece`.
     import os as _os
     BACKWARD_PIECE = int(_os.environ.get("RSP_BWD_PIECE", "-1"))      # -1: the default policy of `_backward_piece`
 
