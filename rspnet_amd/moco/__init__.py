@@ -26,16 +26,19 @@ class DataParallelPretext(nn.Module):
     Gradient averaging happens inside the model's own backward (bucketed RCCL all-reduce over the flat gradient
     buffer).
 
-    Deviation from DDP, stated: torch's DistributedDataParallel (default broadcast_buffers=True) re-broadcasts rank 0's
-    buffers (BN running statistics, num_batches_tracked, queue, queue_ptr) before EVERY forward.  Here the queue / queue_ptr
-    are identical on all ranks by construction (every rank enqueues the same all-gathered keys) and BN running statistics
-    evolve rank-locally between calls of `sync_buffers()` — train-mode numerics never read them and rank 0's checkpoint is
-    the same as under DDP; `sync_buffers()` (called by the pretrain driver at every epoch end) makes the other ranks'
-    copies equal to rank 0's, which is the state DDP leaves them in."""
+    Buffers: torch's DistributedDataParallel (default broadcast_buffers=True, which the reference keeps) re-broadcasts rank 0's
+    buffers (BN running statistics, num_batches_tracked, queue, queue_ptr) before EVERY forward.  Here the queue / queue_ptr /
+    num_batches_tracked are identical on all ranks by construction (every rank enqueues the same all-gathered keys), and the BN
+    running statistics — views into one flat buffer — are broadcast from rank 0 at the top of every forward, one small collective
+    (`MoCoDiffLossTwoFc._broadcast_running_stats`): every rank's `state_dict()` follows the one it has under DDP step by step
+    (tests/test_distributed_cpu.py, three chained steps against the reference under 2-rank DDP).  `broadcast_buffers=False` leaves
+    the statistics rank-local between `sync_buffers()` calls, as DDP(broadcast_buffers=False) would: train-mode numerics never read
+    them and rank 0's checkpoint is the same."""
 
-    def __init__(self, module: MoCoDiffLossTwoFc):
+    def __init__(self, module: MoCoDiffLossTwoFc, broadcast_buffers: bool = True):
         super().__init__()
         self.module = module
+        module.broadcast_buffers = bool(broadcast_buffers)
         if module._dp()[2]:
             module._prepare()
             with torch.no_grad():

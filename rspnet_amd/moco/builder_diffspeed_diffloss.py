@@ -192,6 +192,10 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._defer_reduce = False            # True: backward leaves the gradient all-reduce to `_reduce_gradients` (segmented replay)
         self._defer_backward = False          # True: loss.backward() stops at the query features; `_backward_iter` runs the encoder's part
         self._pending_bwd = None
+        # DistributedDataParallel(broadcast_buffers=True), the reference's default (moco/__init__.py:49-53): rank 0's BatchNorm
+        # running statistics reach every rank before each forward (`_broadcast_running_stats`).  DataParallelPretext sets it.
+        self.broadcast_buffers = True
+        self._bn_flat = None
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
 
     def _dp(self):
@@ -224,6 +228,7 @@ class MoCoDiffLossTwoFc(nn.Module):
             self._q_params = list(self.encoder_q.parameters())
         self._flat.ensure()
         self._tie_num_batches_tracked()
+        self._tie_running_stats()
         self._check_q_weights()
 
     def _bns(self, enc):
@@ -250,6 +255,42 @@ class MoCoDiffLossTwoFc(nn.Module):
             for i, b in enumerate(bns):
                 b._buffers["num_batches_tracked"] = flat[i]
             object.__setattr__(self, attr, flat)
+
+    def _tie_running_stats(self):
+        """All BatchNorm running means / variances of both encoders are views into ONE fp32 buffer (each on a 16-byte boundary): DDP's
+        per-forward buffer broadcast is then one small collective per step (`_broadcast_running_stats`) instead of one per tensor."""
+        bns = self._bns(self.encoder_q) + self._bns(self.encoder_k)
+        dev = self.queue.device
+        flat, off, ok = self._bn_flat, 0, self._bn_flat is not None and self._bn_flat.device == dev
+        offs = []
+        for b in bns:
+            for t in (b.running_mean, b.running_var):
+                offs.append(off)
+                ok = ok and t.data_ptr() == flat.data_ptr() + 4 * off
+                off += (t.numel() + 3) // 4 * 4
+        if ok:
+            return
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        it = iter(offs)
+        for b in bns:
+            for name in ("running_mean", "running_var"):
+                t, o = b._buffers[name], next(it)
+                v = flat[o:o + t.numel()]
+                v.copy_(t.to(dev))
+                b._buffers[name] = v
+        self._bn_flat = flat
+
+    @torch.no_grad()
+    def _broadcast_running_stats(self):
+        """What DistributedDataParallel does before every forward with the reference's default broadcast_buffers=True
+        (moco/__init__.py:49-53, torch's `_sync_buffers`): rank 0's buffers overwrite every rank's.  queue / queue_ptr /
+        num_batches_tracked are equal on all ranks by construction (every rank enqueues the same all-gathered keys and counts the same
+        passes); the BatchNorm running statistics are not — each rank's moving averages see its own half of every batch — so they
+        travel: one broadcast of the flat buffer, started here and awaited by the caller before the step's first BatchNorm.
+        Returns the work handle (None: nothing to do)."""
+        if not (self.broadcast_buffers and self._dp()[2]) or self._bn_flat is None or self._bn_flat.numel() == 0:
+            return None
+        return dist.broadcast(self._bn_flat, src=0, async_op=True)
 
     # ---- reference-named pieces -------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -652,11 +693,17 @@ class MoCoDiffLossTwoFc(nn.Module):
         first key pass's convolutions.  wait=False: the key passes wait for their clips themselves (`_key_pass`); True: the current
         stream waits for both; "first": for the k_negative clips only (`_wait_exchange(st, 1)` follows on the k pass's stream)."""
         _, _, coll = self._dp()
+        stats = self._broadcast_running_stats()        # (DDP's buffer broadcast sits in front of the forward: so does this)
         for i, plan in enumerate(host["plans"]):
             _, _, in_splits, out_splits, arrival = plan
             st["arrival"][i] = arrival
             if coll:
                 st["handles"][i] = dist.all_to_all_single(st["recv"][i], st["send"][i], out_splits, in_splits, async_op=True)
+        if stats is not None:
+            # every pass of the step starts from this stream (forks included): none reads or moves a running statistic before
+            # rank 0's have arrived
+            with self._comm("broadcast_buffers"):
+                stats.wait()
         if wait:
             self._wait_exchange(st, 0)
             if wait != "first":
