@@ -26,6 +26,7 @@ runtime: 3.2 us of host per node and 6-9 us per chain link — S3D-G's 1 800-nod
 its BatchNorm chains (reduce -> finalize -> apply -> ...) paid the longer link.  So the step is cut into graphs that are each a
 plain chain, and the concurrency lives BETWEEN graphs, on streams the stepper orders with events:
 
+                                                                                        [DDP's buffer broadcast: BN running statistics]
     main lane   top (momentum update, _diff_speed, the three clip gathers)              [clip all-to-all x2: eager RCCL calls]
     main | q | k   key_kneg | query | key_k   three linear graphs replayed side by side on three streams
     main lane   keys_join (deferred BatchNorm statistics, feature stack)                [key all-gather]
@@ -176,11 +177,15 @@ class GraphedPretextStep:
 
         if mode == "whole":
             return [("g", "main", "step", whole)], box
+        def sync_buffers(host):
+            m._broadcast_running_stats()         # DDP's per-forward buffer broadcast (a no-op without a process group)
+
         if mode == "segments":
-            return [("g", "main", "top", top), ("e", "main", "all_to_all", exchange), ("g", "main", "passes", passes),
+            pre = [("e", "main", "broadcast_buffers", sync_buffers)] if (m._dp()[2] and m.broadcast_buffers) else []
+            return pre + [("g", "main", "top", top), ("e", "main", "all_to_all", exchange), ("g", "main", "passes", passes),
                     ("e", "main", "all_gather", gather), ("g", "main", "tail", tail), ("e", "main", "all_reduce", reduce),
                     ("g", "main", "update", update)], box
-        return self._lanes(box, top, gather, tail, update), box
+        return self._lanes(box, top, gather, tail, update, sync_buffers), box
 
     # Plan nodes per piece of the backward (lanes mode) when weight gradients are set aside for the "w" lane.  History: round 5 measured
     # 8-node pieces everywhere at one rank — every extra graph costs ~50 us on the GPU side, R3D-18 1 259 -> 1 235, S3D-G 402 -> 398 — and
@@ -213,7 +218,7 @@ class GraphedPretextStep:
             return 0
         return max(12, -(-n // 9))
 
-    def _lanes(self, box, top, gather, tail, update):
+    def _lanes(self, box, top, gather, tail, update, sync_buffers):
         """The "lanes" schedule (see `_schedule`), a generator consumed by `_capture`."""
         from .engine import BranchStreams
         from .moco.builder_diffspeed_diffloss import BUCKET_FLOATS
@@ -226,7 +231,7 @@ class GraphedPretextStep:
             m._last_draw = (m._last_draw[0], host["speed"]) + tuple(host["sh"])
 
         coll = bool(m._dp()[2])
-        piece_nodes = self._backward_piece(coll)
+        piece_nodes = self._piece_agreed if getattr(self, "_piece_agreed", None) is not None else self._backward_piece(coll)
         pieces = piece_nodes > 0
         if not coll and not pieces:
             # One rank, no process group: no collective points, so the main lane needs only three graphs (every graph boundary
@@ -247,6 +252,8 @@ class GraphedPretextStep:
             yield ("join", "q")
             yield ("g", "main", "tail+update", rest)
             return
+        if coll and m.broadcast_buffers:
+            yield ("e", "main", "broadcast_buffers", sync_buffers)      # (in front of the query pass's fork: see `top` below)
         yield ("g", "main", "top", top)
         yield ("fork", "q")
         yield ("g", "q", "query", lambda host: m._pass_query(box["st"]))
@@ -531,6 +538,12 @@ class GraphedPretextStep:
         return float(t.item())
 
     def _capture(self, key, host):
+        # Where the backward is cut decides WHEN each gradient bucket's all-reduce is issued, and buckets that complete inside one piece
+        # leave in index order: ranks that cut differently (the cut follows a local MEASUREMENT of the "w" lane, `_backward_piece`)
+        # would issue the same buckets in different orders and pair up the wrong collectives.  The smallest answer wins everywhere.
+        self._piece_agreed = None
+        if self.model._dp()[2] and self.mode == "lanes":
+            self._piece_agreed = int(self._agree(float(self._backward_piece(True)), min))
         entry = self._capture_local(key, host)
         # a capture that failed on ONE rank (that rank would issue the eager step, with other collectives) is a failure everywhere
         if self.model._dp()[2] and self._agree(0.0 if entry is None else 1.0, min) < 0.5 and entry is not None:

@@ -286,11 +286,17 @@ class MoCoDiffLossTwoFc(nn.Module):
         (moco/__init__.py:49-53, torch's `_sync_buffers`): rank 0's buffers overwrite every rank's.  queue / queue_ptr /
         num_batches_tracked are equal on all ranks by construction (every rank enqueues the same all-gathered keys and counts the same
         passes); the BatchNorm running statistics are not — each rank's moving averages see its own half of every batch — so they
-        travel: one broadcast of the flat buffer, started here and awaited by the caller before the step's first BatchNorm.
-        Returns the work handle (None: nothing to do)."""
-        if not (self.broadcast_buffers and self._dp()[2]) or self._bn_flat is None or self._bn_flat.numel() == 0:
-            return None
-        return dist.broadcast(self._bn_flat, src=0, async_op=True)
+        travel: one broadcast of the flat buffer in front of the step (every pass of the step, forked ones included, starts from
+        this stream behind it: none reads or moves a running statistic before rank 0's have arrived)."""
+        if not (self.broadcast_buffers and self._dp()[2]):
+            return
+        if self._bn_flat is None:
+            self._prepare()
+        if self._bn_flat.numel() == 0:
+            return
+        h = dist.broadcast(self._bn_flat, src=0, async_op=True)
+        with self._comm("broadcast_buffers"):
+            h.wait()
 
     # ---- reference-named pieces -------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -640,6 +646,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         """The step's device work under the host decisions of `_host_part`: its phases back to back, the collectives between them
         issued asynchronously (the second clip exchange runs under the first key pass, the key all-gather under the tail of the
         query forward).  rspnet_amd/graph_step.py replays the same phases as HIP graphs with the collectives in between."""
+        self._broadcast_running_stats()
         st = self._phase_top(im_q, im_k, host)
         self._phase_exchange(st, host, wait=False)
         self._phase_passes(st, join_query=False)
@@ -693,17 +700,11 @@ class MoCoDiffLossTwoFc(nn.Module):
         first key pass's convolutions.  wait=False: the key passes wait for their clips themselves (`_key_pass`); True: the current
         stream waits for both; "first": for the k_negative clips only (`_wait_exchange(st, 1)` follows on the k pass's stream)."""
         _, _, coll = self._dp()
-        stats = self._broadcast_running_stats()        # (DDP's buffer broadcast sits in front of the forward: so does this)
         for i, plan in enumerate(host["plans"]):
             _, _, in_splits, out_splits, arrival = plan
             st["arrival"][i] = arrival
             if coll:
                 st["handles"][i] = dist.all_to_all_single(st["recv"][i], st["send"][i], out_splits, in_splits, async_op=True)
-        if stats is not None:
-            # every pass of the step starts from this stream (forks included): none reads or moves a running statistic before
-            # rank 0's have arrived
-            with self._comm("broadcast_buffers"):
-                stats.wait()
         if wait:
             self._wait_exchange(st, 0)
             if wait != "first":

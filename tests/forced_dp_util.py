@@ -111,9 +111,21 @@ def segmented_worker(rank, arch, B, HW, port, out_path, mode="lanes", steps=7):
     # would: the optimizer of either loop sees the doubled gradient only if it is ordered behind the "collective", and the two loops
     # stay bit-identical only if both are.
     cur = {"model": None, "snaps": []}
-    for name in ("all_to_all_single", "all_gather_into_tensor", "all_reduce"):
+    for name in ("all_to_all_single", "all_gather_into_tensor", "all_reduce", "broadcast"):
         def make(name, fn):
             def spy(*a, **k):
+                if name == "broadcast":
+                    # DDP's per-forward buffer broadcast: the flat tensor of all BatchNorm running statistics, from rank 0, on the
+                    # device group (the host-side message of the step's draws travels on the gloo side group: not counted here)
+                    bn = getattr(cur["model"], "_bn_flat", None)
+                    if bn is not None and a[0].data_ptr() == bn.data_ptr() and a[0].numel() == bn.numel():
+                        calls["broadcast_buffers"] += 1
+                        # with one rank the broadcast moves nothing: the spy scales the statistics on the issuing stream, as if rank
+                        # 0 had sent other values — (s * 1.25) moved by this step's batch is not (s moved by the batch) * 1.25, so
+                        # the final running statistics of the two loops agree only if BOTH order the broadcast in front of every
+                        # BatchNorm of the step (the replayed query pass forks before the clip exchange: rspnet_amd/graph_step.py)
+                        a[0].mul_(1.25)
+                    return fn(*a, **k)
                 calls[name] += 1
                 flat = getattr(cur["model"], "_flat", None) if name == "all_reduce" else None
                 if flat is not None and a[0].untyped_storage().data_ptr() == flat.g_flat.untyped_storage().data_ptr():

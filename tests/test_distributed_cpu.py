@@ -243,7 +243,7 @@ def test_issue_mode_decision_is_shared_across_ranks():
     assert a0.tolist() == a1.tolist() == [0.4, 0.0]
 
 
-def _chain_worker(rank, ws, port, tmp):
+def _chain_worker(rank, ws, port, tmp, broadcast_buffers=True, issue="eager"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import json
@@ -270,6 +270,7 @@ def _chain_worker(rank, ws, port, tmp):
     dev = torch.device("cpu")
     wrapped = ModelFactory(make_cfg("c3d", meta["K"], m=meta["m"], T=meta["T"])).build_moco_diffloss(device=dev)
     model = wrapped.module
+    model.broadcast_buffers = broadcast_buffers
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
     model.train()
     params = [p for p in wrapped.parameters() if p.requires_grad]
@@ -280,18 +281,36 @@ def _chain_worker(rank, ws, port, tmp):
             opt.state[p]["momentum_buffer"] = torch.from_numpy(mom[names[id(p)]].copy())
     crit = Loss(margin=meta["margin"], A=meta["A"], M=meta["M"])
     im_q, im_k = torch.from_numpy(clips[rank][0]), torch.from_numpy(clips[rank][1])
-    worst = 0.0
+    worst = apart = 0.0
     for s in range(meta["steps"]):
         perms_B, sh = chain_perms(s, ws, meta["B"])
-        with ReplayRNG([perms_B[rank], sh[0], sh[1]], 2):
-            out, tgt, rl, rt = wrapped(im_q, im_k)
-        loss, _, _ = crit(out, tgt, rl, rt)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+        if issue == "eager":
+            with ReplayRNG([perms_B[rank], sh[0], sh[1]], 2):
+                out, tgt, rl, rt = wrapped(im_q, im_k)
+            loss, _, _ = crit(out, tgt, rl, rt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        else:
+            # the step as the operation list GraphedPretextStep captures and replays ("lanes": the query pass is forked in front of
+            # the clip exchange — the buffer broadcast has to sit in front of THAT), every operation issued in order
+            from rspnet_amd.graph_step import GraphedPretextStep
+            stepper = GraphedPretextStep(wrapped, crit, opt)
+            ops_, box = stepper._schedule(im_q, im_k, issue)
+            model._defer_reduce, model._defer_backward = True, issue == "lanes"
+            try:
+                with ReplayRNG([perms_B[rank], sh[0], sh[1]], 2):
+                    host = model._host_part(im_q.shape[0], dev)
+                    ran = [op[2] for op in ops_ if op[0] in ("g", "e") and (op[3](host) or True)]
+            finally:
+                model._defer_reduce = model._defer_backward = False
+            assert ran[0] == ("broadcast_buffers" if broadcast_buffers else "top") and ran[-1] == "update", ran
+            loss, _, _, out, rl = box["outs"]
         sd = model.state_dict()
-        # DDP hands every rank rank 0's buffers before each forward; here they evolve per rank between sync_buffers() calls.  What
-        # must hold WITHOUT any sync: rank 0's whole trajectory (the rank that writes checkpoints), every rank's queue / pointer /
+        # DDP hands every rank rank 0's buffers before each forward, and so does the product (broadcast_buffers=True, the default):
+        # EVERY rank's state follows the one it has under DDP — rank 1's running statistics after step s are rank 0's after s - 1
+        # moved by rank 1's own batch.  With broadcast_buffers=False they evolve per rank between sync_buffers() calls; what must
+        # hold then WITHOUT any sync: rank 0's whole trajectory (the rank that writes checkpoints), every rank's queue / pointer /
         # num_batches_tracked / losses / trained parameters (nothing in train mode reads a running statistic), and every rank's
         # running statistics after the FIRST step (all ranks start it from the same state)
         pre = f"r{rank}.s{s}."
@@ -307,18 +326,25 @@ def _chain_worker(rank, ws, port, tmp):
                 else:
                     assert rel_err(sd[key].numpy(), z[name]) <= 2e-4, (rank, s, key)
             elif key.endswith(("running_mean", "running_var")):
-                if rank == 0 or s == 0:
-                    e = rel_err(P.summarise(key, sd[key].numpy()), z[name])
+                e = rel_err(P.summarise(key, sd[key].numpy()), z[name])
+                if broadcast_buffers or rank == 0 or s == 0:
                     worst = max(worst, e)
                     assert e <= 2e-4, (rank, s, key, e)
+                else:
+                    apart = max(apart, e)
             else:                                                  # trained tensors: the chain runs through the optimizer
                 assert rel_err(P.summarise(key, sd[key].detach().numpy()), z[name]) <= 1e-3, (rank, s, key)
+    if not broadcast_buffers and rank == 1:
+        # the fixture tells the two behaviours apart: without the per-forward broadcast rank 1 leaves DDP's trajectory
+        assert apart > 1e-3, apart
     before = {k: v.clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
     wrapped.sync_buffers()
     after = {k: v.clone() for k, v in model.state_dict().items()}
     if rank == 0:
         assert all(torch.equal(before[k], after[k]) for k in before)          # rank 0 is the source: untouched
     else:
+        # (either way rank 1's statistics differ from rank 0's before the sync: under DDP by its own last batch, without the
+        #  per-forward broadcast by all of them)
         assert any(not torch.equal(before[k], after[k]) for k in before), "rank 1's running statistics never differed: nothing was tested"
     torch.save({k: v for k, v in after.items() if not k.startswith("encoder_q.") or k.endswith(("running_mean", "running_var", "num_batches_tracked"))},
                os.path.join(tmp, f"buffers{rank}.pt"))
@@ -327,15 +353,19 @@ def _chain_worker(rank, ws, port, tmp):
     dist.destroy_process_group()
 
 
-def test_rank0_buffers_follow_ddp_over_chained_steps_and_sync_buffers_aligns_the_rest():
+@pytest.mark.parametrize("broadcast_buffers,issue", [(True, "eager"), (False, "eager"), (True, "lanes"), (True, "segments")])
+def test_buffers_follow_ddp_over_chained_steps_and_sync_buffers_aligns_the_rest(broadcast_buffers, issue):
     """VERDICT r5 item 7 / SURVEY C6.  DistributedDataParallel broadcasts rank 0's buffers before every forward
-    (/root/reference/moco/__init__.py:49-53); the product keeps BatchNorm running statistics per rank between sync_buffers() calls.
-    tests/golden/chain_c3d_ws2.npz (oracle/gen_golden_chain.py) holds three CHAINED steps of the real reference under 2-rank DDP:
-    rank 0's state after every step — what a checkpoint written by rank 0 holds (/root/reference/pretrain.py:244-260) — is
-    reproduced without any sync; after sync_buffers() rank 1's buffers and key encoder equal rank 0's bit for bit."""
+    (/root/reference/moco/__init__.py:49-53, default broadcast_buffers=True).  tests/golden/chain_c3d_ws2.npz
+    (oracle/gen_golden_chain.py) holds three CHAINED steps of the real reference under 2-rank DDP, both ranks' states after every step.
+    Default (True): the product broadcasts rank 0's BatchNorm running statistics at the top of every forward — BOTH ranks' states
+    are reproduced step by step.  False: the statistics stay per rank; rank 0's state after every step — what a checkpoint written
+    by rank 0 holds (/root/reference/pretrain.py:244-260) — is still reproduced without any sync.  Either way, after sync_buffers()
+    rank 1's buffers and key encoder equal rank 0's bit for bit.  issue "lanes" / "segments": the same chain through the operation
+    lists of the replayed step (rspnet_amd/graph_step.py), where the broadcast is an eager collective in front of the first graph."""
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_chain_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        mp.spawn(_chain_worker, args=(2, _free_port(), tmp, broadcast_buffers, issue), nprocs=2, join=True)
         assert os.path.exists(os.path.join(tmp, "ok0.npy")) and os.path.exists(os.path.join(tmp, "ok1.npy"))
         b0, b1 = torch.load(os.path.join(tmp, "buffers0.pt")), torch.load(os.path.join(tmp, "buffers1.pt"))
     assert set(b0) == set(b1) and len(b0) > 60

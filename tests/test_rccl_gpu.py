@@ -98,11 +98,14 @@ def test_rccl_one_rank_segmented_replay_equals_the_eager_dp_step(arch, B, HW, mo
         # slots: all-to-all (+ its wait on the k lane), all-gather, one all-reduce per bucket, the wait for them
         assert rep["lanes"] in (["k", "main", "q"], ["k", "main", "q", "w"]) and rep["graphs"] >= 8 and rep["collective_points"] >= 5, rep
     else:
-        assert (rep["graphs"], rep["lanes"], rep["collective_points"]) == (4, ["main"], 3), rep
-    # every step of either loop issues its 2 clip all-to-alls and its 1 key all-gather
+        # (collective points: DDP's buffer broadcast in front of the step, all-to-all, all-gather, all-reduce)
+        assert (rep["graphs"], rep["lanes"], rep["collective_points"]) == (4, ["main"], 4), rep
+    # every step of either loop issues its buffer broadcast (BN running statistics, one flat tensor), its 2 clip all-to-alls and its
+    # 1 key all-gather
     assert rep["buckets"]["eager"] >= 1 and rep["buckets"]["segments"] >= 1, rep
     for m in ("eager", "segments"):
         assert rep[m]["all_to_all_single"] == 2 * 7 and rep[m]["all_gather_into_tensor"] == 7 and rep[m]["all_reduce"] >= 7
+        assert rep[m]["broadcast_buffers"] == 7, rep
 
 
 def test_bucket_all_reduce_is_ordered_behind_the_side_stream_weight_gradients():
