@@ -763,7 +763,7 @@ def run_rank(args):
             "graph": "one replayed HIP graph (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
             "graph_segments": "four replayed HIP-graph segments between the step's collective points, RCCL calls issued eagerly in "
                               "between (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
-            "graph_lanes": "seven replayed LINEAR HIP graphs — the three forward passes side by side on three streams — with the step's "
+            "graph_lanes": "replayed LINEAR HIP graphs — the three forward passes side by side on three streams, the backward in pieces beside a weight-gradient lane (steps_ms.segment_gpu_p50 lists them) — with the step's "
                            "collective points between graphs (rspnet_amd/graph_step.py: the host cannot issue this step fast enough)",
             "eager": "eager launches (independent passes on side streams)"}[m["issue_mode"]] + \
             "; roofline numbers from a one-stream eager pass of the same step outside the timed region"

@@ -318,7 +318,7 @@ class BranchStreams:
     MID_WGRAD_BYTES = float(os.environ.get("RSP_WGRAD_MID_MB", "450")) * 1e6
     EAGER_TASKS = not os.environ.get("RSP_NO_EAGER_OVERLAP")
     # a list while rspnet_amd/graph_step.py captures a piece of the backward as a LINEAR graph: side tasks are not run but collected
-    # there as (fn, keepalive) — the stepper captures them as a graph of their own and replays it on the weight-gradient lane
+    # there as (fn, keepalive, FLOPs) — the stepper captures them as a graph of their own and replays it on the weight-gradient lane
     deferred = None
 
     def __init__(self, x: torch.Tensor):
@@ -356,13 +356,13 @@ class BranchStreams:
             BranchStreams._streams[key] = st
         return st
 
-    def side_task(self, fn, keepalive):
+    def side_task(self, fn, keepalive, cost: float = 0.0):
         """Run `fn` — a kernel sequence whose results nobody reads before the end of the pass: a SMALL weight gradient, which on
         its own leaves most of the machine idle — on a task stream beside the trunk (R3D-18 +1.2 %, R(2+1)D +1.1 %).  Only from
         the trunk (flat forks); one task outstanding, the previous one is joined first.  `keepalive`: the tensors it reads,
         held until the join so that the graph's memory pool does not hand their blocks out again underneath it."""
         if BranchStreams.deferred is not None:
-            BranchStreams.deferred.append((fn, keepalive))
+            BranchStreams.deferred.append((fn, keepalive, cost))      # (cost: FLOPs — rspnet_amd/graph_step.py places its cuts by it)
             return
         cur = torch.cuda.current_stream(self.dev) if self.on else None
         if cur is None or cur.cuda_stream != self.origin_h:
@@ -820,7 +820,7 @@ def run_backward_iter(plan: Plan, ctx: ForwardCtx, dfeat: torch.Tensor, grad_of,
         #  bucket go, see run_backward's docstring)
         if (sv.cg.flops < BranchStreams.SMALL_WGRAD_FLOPS or
                 (sv.cg.flops < BranchStreams.MID_WGRAD_FLOPS and sv.cg.bytes < BranchStreams.MID_WGRAD_BYTES)):
-            branches.side_task(lambda: be.conv_wgrad(sv.cg, sv.x, dy, gw), (sv.x, dy))
+            branches.side_task(lambda: be.conv_wgrad(sv.cg, sv.x, dy, gw), (sv.x, dy), cost=float(sv.cg.flops))
         else:
             be.conv_wgrad(sv.cg, sv.x, dy, gw)
         if after_param_grads is not None:

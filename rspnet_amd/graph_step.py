@@ -192,6 +192,10 @@ class GraphedPretextStep:
     # kept the backward in one graph; round 6 found why (the "w" lane shared the main lane's hardware queue), see `_backward_piece`.
     import os as _os
     BACKWARD_PIECE = int(_os.environ.get("RSP_BWD_PIECE", "-1"))      # -1: the default policy of `_backward_piece`
+    # ... and in the last TAIL_NODES plan nodes of the chain (-1: one piece's worth) a cut as soon as the weight gradients set aside
+    # since the last one add up to TAIL_CUT_FLOPS (0: off)
+    TAIL_CUT_FLOPS = float(_os.environ.get("RSP_BWD_TAIL_CUT_GFLOP", "0")) * 1e9
+    TAIL_NODES = int(_os.environ.get("RSP_BWD_TAIL_NODES", "-1"))
 
     def _backward_piece(self, coll: bool) -> int:
         """Plan nodes per backward piece of the "lanes" schedule; 0: the backward is not cut (beyond the gradient-bucket boundaries).
@@ -283,8 +287,10 @@ class GraphedPretextStep:
         # parameter has been issued is all-reduced from the "w" lane's stream — behind everything that writes into it
         # (buckets of 64 MiB here: each one ends a graph, and an extra graph costs about what 10 MB of all-reduce do)
         buckets = m._flat.buckets(2 * BUCKET_FLOATS) if coll else []
-        bw = {"it": None, "done": False, "tasks": [], "keep": [], "handed": set(), "launched": set(), "handles": []}
+        bw = {"it": None, "done": False, "tasks": [], "keep": [], "handed": set(), "launched": set(), "handles": [], "seen": 0}
         box["backward"] = bw
+        n_nodes = len(m.encoder_q.plan().nodes) if pieces else 0
+        tail_nodes = self.TAIL_NODES if self.TAIL_NODES >= 0 else piece_nodes
 
         def piece(host):
             if bw["it"] is None:
@@ -299,14 +305,20 @@ class GraphedPretextStep:
                     # (a cut where a bucket has just completed — unless every bucket has: what is left then is the end of the
                     #  chain, and the flush behind the loop takes the rest)
                     ready = not all(done_now) and any(d and bi not in bw["launched"] for bi, d in enumerate(done_now))
-                    if ready or (pieces and n >= piece_nodes and bw["tasks"]):
+                    bw["seen"] += 1
+                    # The weight gradients of the LAST piece have nothing left to run beside: a big one set aside in the final stretch
+                    # of the chain (S3D-G's sep_conv2: 89 GFLOP, 0.9 ms) starts a piece of its own at once, beside the memory-bound
+                    # BatchNorm / pool / gate passes of the front-end layers that follow, instead of alone behind the end of the chain
+                    tail_cut = (pieces and self.TAIL_CUT_FLOPS > 0 and bw["tasks"] and n_nodes - bw["seen"] <= tail_nodes
+                                and n_nodes - bw["seen"] > 0 and sum(t[2] for t in bw["tasks"]) >= self.TAIL_CUT_FLOPS)
+                    if ready or tail_cut or (pieces and n >= piece_nodes and bw["tasks"]):
                         return
                 bw["done"] = True
             finally:
                 BranchStreams.deferred = None
 
         def wgrads(host):
-            for fn, keep in bw["tasks"]:
+            for fn, keep, _ in bw["tasks"]:
                 fn()
                 # the operands stay alive until the whole backward has been captured: the main lane's later pieces must not be
                 # handed their memory while this graph may still be reading it
