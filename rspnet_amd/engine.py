@@ -317,6 +317,13 @@ class BranchStreams:
     MID_WGRAD_FLOPS = float(os.environ.get("RSP_WGRAD_MID_GFLOP", "400")) * 1e9
     MID_WGRAD_BYTES = float(os.environ.get("RSP_WGRAD_MID_MB", "450")) * 1e6
     EAGER_TASKS = not os.environ.get("RSP_NO_EAGER_OVERLAP")
+    # Issued eagerly, a weight gradient below AHEAD_MAX_FLOPS is handed to the task lane WITHOUT joining the previous one first (the
+    # lane keeps its own order; what the tasks read stays alive until the join): the trunk no longer stalls where a weight gradient
+    # outlasts the trunk's work up to the next one.  profiles/r06/experiments_r6.txt r6u-v: R3D-18 1 321-1 326 -> 1 344-1 346 clips/s,
+    # R(2+1)D 446.3 -> 448.3-450.3, C3D 352.7-353.3 -> 353.6-354.7; without the cap C3D loses 0.5 % (its 177-355 GFLOP weight gradients
+    # queue up beside the input gradients and fight them for the whole backward instead of filling their ragged ends).
+    RUN_AHEAD = bool(int(os.environ.get("RSP_TASK_RUN_AHEAD", "1")))
+    AHEAD_MAX_FLOPS = float(os.environ.get("RSP_TASK_AHEAD_MAX_GFLOP", "100")) * 1e9
     # a list while rspnet_amd/graph_step.py captures a piece of the backward as a LINEAR graph: side tasks are not run but collected
     # there as (fn, keepalive, FLOPs) — the stepper captures them as a graph of their own and replays it on the weight-gradient lane
     deferred = None
@@ -367,12 +374,21 @@ class BranchStreams:
         cur = torch.cuda.current_stream(self.dev) if self.on else None
         if cur is None or cur.cuda_stream != self.origin_h:
             return fn()
-        self.join_task()
+        held = []
+        if BranchStreams.RUN_AHEAD and cost < BranchStreams.AHEAD_MAX_FLOPS and not torch.cuda.is_current_stream_capturing():
+            # issued eagerly the task stream is a lane of its own (rspnet_amd/streams.py) and keeps its own order: the trunk does not
+            # wait for the previous task before it hands over the next one — a weight gradient longer than the trunk's work up to
+            # the next one no longer stalls the trunk — and everything the tasks read stays alive until the join
+            if self.task is not None:
+                held = self.task[1]
+        else:
+            self.join_task()
         ts = self._get("task")
         ts.wait_stream(cur)
         with torch.cuda.stream(ts):
             fn()
-        self.task = (ts, keepalive)
+        held.append(keepalive)
+        self.task = (ts, held)
 
     @contextlib.contextmanager
     def grads_ready(self):

@@ -193,9 +193,16 @@ class GraphedPretextStep:
     import os as _os
     BACKWARD_PIECE = int(_os.environ.get("RSP_BWD_PIECE", "-1"))      # -1: the default policy of `_backward_piece`
     # ... and in the last TAIL_NODES plan nodes of the chain (-1: one piece's worth) a cut as soon as the weight gradients set aside
-    # since the last one add up to TAIL_CUT_FLOPS (0: off)
-    TAIL_CUT_FLOPS = float(_os.environ.get("RSP_BWD_TAIL_CUT_GFLOP", "0")) * 1e9
+    # since the last one add up to TAIL_CUT_FLOPS (0: off): the last piece's weight gradients run ALONE behind the end of the chain
+    # (S3D-G: 1.4 ms of them, sep_conv2's 89 GFLOP among them), a piece of their own lets the big ones start beside the memory-bound
+    # front-end layers instead.  profiles/r06/experiments_r6.txt r6s-w: S3D-G 421.8-424.4 -> 428.6-430.3 on one box, 425.4-426.8 ->
+    # 426.6-428.8 on another (0 / 40 / 60 / 80 / 120 GFLOP: 60 best or equal); R3D-18 through the collectives 1 334-1 336 -> 1 341-1 342.
+    TAIL_CUT_FLOPS = float(_os.environ.get("RSP_BWD_TAIL_CUT_GFLOP", "60")) * 1e9
     TAIL_NODES = int(_os.environ.get("RSP_BWD_TAIL_NODES", "-1"))
+    # A bucket's all-reduce is issued on the "w" lane behind the weight gradients that complete it — but AFTER the next piece has been
+    # handed to the main lane: issued at the boundary itself it held that piece up until the weight gradients were done (R3D-18, gap
+    # wgrad0 -> backward1 +0.03 ms instead of -0.5 ms: the collective's wait sits in front of the piece in a queue they share)
+    REDUCE_LATE = bool(int(_os.environ.get("RSP_REDUCE_LATE", "1")))
 
     def _backward_piece(self, coll: bool) -> int:
         """Plan nodes per backward piece of the "lanes" schedule; 0: the backward is not cut (beyond the gradient-bucket boundaries).
@@ -339,8 +346,12 @@ class GraphedPretextStep:
 
         j = 0
         used_w = False
+        held = []          # all-reduces whose issue is held back until the NEXT piece is in the main lane's queue (REDUCE_LATE)
         while not bw["done"]:
             yield ("g", "main", f"backward{j}", piece)
+            for op in held:
+                yield op
+            del held[:]
             forked = False
             if bw["tasks"]:
                 yield ("fork", "w")
@@ -352,8 +363,14 @@ class GraphedPretextStep:
                     if not forked:
                         yield ("fork", "w")
                         forked = used_w = True
-                    yield ("e", "w", f"all_reduce{bi}", reducer(s, e))
+                    op = ("e", "w", f"all_reduce{bi}", reducer(s, e))
+                    if self.REDUCE_LATE:
+                        held.append(op)
+                    else:
+                        yield op
             j += 1
+        for op in held:
+            yield op
         for bi, (s, e, ids) in enumerate(buckets):
             if bi not in bw["launched"]:
                 bw["launched"].add(bi)
