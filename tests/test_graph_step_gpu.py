@@ -168,3 +168,38 @@ def test_side_lanes_are_on_hardware_queues_of_their_own():
             assert both < 1.5 * one, (i, both, one)
     same = min(streams._timed([lanes[0], lanes[0]], DEV, cycles) for _ in range(3))
     assert same > 1.7 * one, (same, one)          # (the measurement itself tells one queue from two)
+
+
+@pytest.mark.parametrize("arch,B,HW", [("resnet18", 8, 64), ("c3d", 4, 32), ("r2plus1d-vcop", 4, 32)])
+def test_eager_weight_gradient_lane_running_ahead_changes_no_bit(arch, B, HW, monkeypatch):
+    """engine.BranchStreams.side_task (round 6): issued eagerly, a weight gradient below AHEAD_MAX_FLOPS is handed to the task lane
+    without joining the previous one — the lane keeps its own order and the operands stay alive until the end of the pass.  Against the
+    join-before-every-task form, with EVERY weight gradient sent to the lane and none too big to run ahead: the same losses, logits,
+    parameters and momentum buffers over four steps, bit for bit."""
+    from rspnet_amd.engine import BranchStreams
+    monkeypatch.setattr(BranchStreams, "SMALL_WGRAD_FLOPS", 1e18)
+    monkeypatch.setattr(BranchStreams, "AHEAD_MAX_FLOPS", 1e18)
+    K, steps = 64, 4
+    clips = [tuple(torch.from_numpy(c).to(DEV) for c in P.clips(20 + i, 0, (B, 3, 32, HW, HW))) for i in range(steps)]
+    results = []
+    for ahead in (True, False):
+        monkeypatch.setattr(BranchStreams, "RUN_AHEAD", ahead)
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        random.seed(7)
+        wrapped, crit, opt = _build(arch, K)
+        trace = []
+        for im_q, im_k in clips:
+            out, tgt, rl, rt = wrapped(im_q, im_k)
+            loss, la, lm = crit(out, tgt, rl, rt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            trace.append((loss.detach().clone(), out[0].detach().clone(), rl[0].detach().clone()))
+        torch.cuda.synchronize()
+        results.append((trace, {k: v.detach().clone() for k, v in wrapped.module.state_dict().items()},
+                        [opt.state[p]["momentum_buffer"].clone() for g in opt.param_groups for p in g["params"] if "momentum_buffer" in opt.state[p]]))
+    (ta, sa, ma), (tb, sb, mb) = results
+    for i, (x, y) in enumerate(zip(ta, tb)):
+        assert all(torch.equal(a, b) for a, b in zip(x, y)), (arch, "step", i)
+    assert all(torch.equal(sa[k], sb[k]) for k in sa) and len(ma) == len(mb) and all(torch.equal(a, b) for a, b in zip(ma, mb))
