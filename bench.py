@@ -467,6 +467,9 @@ def measure(args, arch, B, hw, base_lr, steps, warmup, dev, rank, ws, want_parit
         seg_gpu = {k: round(_pct(v, 0.5), 3) for k, v in seg_gpu.items()}
     else:
         seg_gpu = None
+        for _ in range(3):      # (the same number of steps in every issue mode: `final_loss` of a seeded run is then comparable
+            step()              #  between --graph off / on / auto — the replayed step is the eager step, bit for bit)
+        fence()
     # (per-launch events are not recorded in the timed region: a replayed graph has none, and the eager step runs its independent
     #  passes on side streams, where a launch's interval also holds its neighbours' time — see the roofline pass below)
     if coll:

@@ -2918,6 +2918,28 @@ static void dgrad_pack_params(const rsp_conv3d_desc* d, const DgradClass& g, con
   pk.kstepd = d->sT; pk.ksteph = d->sH; pk.kstepw = d->sW;
 }
 
+// rows x C floats at a pitch of ld floats := 0.  A KERNEL, not hipMemsetAsync: captured into a linear HIP graph (rspnet_amd/graph_step.py)
+// the memset node was not reliably ordered against the kernel nodes around it on this stack — R3D-18's shortcut input gradients (1x1x1,
+// stride 2: the one place that needs the fill) came out wrong in a few replays out of a hundred, the loss of the step untouched and every
+// gradient below the block off (profiles/r06/experiments_r6.txt r6race; eager issue and graphs with forks inside were never affected).
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, long long total, int cw, int ld, int vec) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+    const long long row = i / cw;
+    const int c = (int)(i - row * cw);
+    if (vec) *reinterpret_cast<float4*>(p + row * ld + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else p[row * ld + c] = 0.f;
+  }
+}
+static int zero_rows(float* p, size_t rows, int C, int ld, hipStream_t s) {
+  const int vec = (C % 4 == 0 && ld % 4 == 0 && rsp_aligned16(p)) ? 1 : 0;
+  const int cw = vec ? C / 4 : C;
+  const long long total = (long long)rows * cw;
+  if (total == 0) return RSP_OK;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, s, p, total, cw, ld, vec);
+  return rsp_check_launch("zero_rows_kernel");
+}
+
 // The GEMM launches of dgrad over already packed per-class weights (class c's block follows class c-1's, O x Kld floats each).
 static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk, float* dx, void* part, size_t part_bytes,
                      hipStream_t s) {
@@ -2930,11 +2952,8 @@ static int dgrad_run(const rsp_conv3d_desc* d, const float* dy, const float* wpk
   if (any_empty) {
     // some input positions receive no gradient at all (kernel smaller than stride, e.g. 1x1x1 stride 2)
     const size_t rows = (size_t)d->N * d->Di * d->Hi * d->Wi;
-    if (d->in_ld == d->Cin) {
-      (void)hipMemsetAsync(dx, 0, rows * d->Cin * sizeof(float), s);
-    } else {
-      (void)hipMemset2DAsync(dx, (size_t)d->in_ld * 4, 0, (size_t)d->Cin * 4, rows, s);
-    }
+    const int rc = zero_rows(dx, rows, d->Cin, d->in_ld, s);
+    if (rc != RSP_OK) return rc;
   }
   // per-class GEMM descriptions
   IgemmParams cls[64];
