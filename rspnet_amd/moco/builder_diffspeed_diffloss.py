@@ -196,6 +196,7 @@ class MoCoDiffLossTwoFc(nn.Module):
         # running statistics reach every rank before each forward (`_broadcast_running_stats`).  DataParallelPretext sets it.
         self.broadcast_buffers = True
         self._bn_flat = None
+        self._lanes_chosen = False
         self.register_load_state_dict_post_hook(lambda mod, keys: mod._state_loaded())
 
     def _dp(self):
@@ -229,6 +230,12 @@ class MoCoDiffLossTwoFc(nn.Module):
         self._flat.ensure()
         self._tie_num_batches_tracked()
         self._tie_running_stats()
+        dev = self.queue.device
+        if dev.type == "cuda" and not self._lanes_chosen and not torch.cuda.is_current_stream_capturing():
+            # the process's side lanes are MEASURED (rspnet_amd/streams.py: spin kernels and device synchronisations) — here, on a quiet
+            # GPU in front of the first step, not in the middle of it between its first collectives
+            _streams.lane(dev, "q")
+            self._lanes_chosen = True
         self._check_q_weights()
 
     def _bns(self, enc):

@@ -205,7 +205,7 @@ def test_eager_weight_gradient_lane_running_ahead_changes_no_bit(arch, B, HW, mo
     assert all(torch.equal(sa[k], sb[k]) for k in sa) and len(ma) == len(mb) and all(torch.equal(a, b) for a, b in zip(ma, mb))
 
 
-@pytest.mark.parametrize("arch,B,HW,steps", [("resnet18", 32, 112, 40)])
+@pytest.mark.parametrize("arch,B,HW,steps", [("resnet18", 32, 112, 40), ("s3dg", 16, 224, 20)])
 def test_replayed_step_is_the_eager_step_at_measured_size(arch, B, HW, steps):
     """tools/graph_vs_eager_fullsize.py at BASELINE size, per-parameter gradient checksums after every step: eager vs replayed and
     replayed vs replayed again.  Round 6 found what the fixture-size test above cannot see: R3D-18's shortcut input gradients (1x1x1,
