@@ -227,7 +227,14 @@ def _agree_worker(rank, ws, port, tmp):
     # per-rank measurements on either side of the threshold: every rank must come out with the same number
     share = stepper._agree(0.2 + 0.2 * rank, max)
     ok = stepper._agree(1.0 if rank == 0 else 0.0, min)
-    np.save(os.path.join(tmp, f"agree{rank}.npy"), np.array([share, ok]))
+    # ... and where the replayed backward is cut follows a LOCAL measurement (is the "w" lane on a hardware queue of its own?): ranks
+    # that cut differently would issue their gradient buckets in different orders.  The smallest answer wins, before the capture.
+    stepper._backward_piece = lambda coll: 12 if rank == 0 else 0
+    stepper.mode = "lanes"
+    stepper._capture_local = lambda key, host: None        # (no HIP device here: nothing to capture — the agreements around it are the subject)
+    assert stepper._capture(("no", "capture", "on", "cpu"), None) is None
+    piece = stepper._piece_agreed
+    np.save(os.path.join(tmp, f"agree{rank}.npy"), np.array([share, ok, piece]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -235,12 +242,13 @@ def _agree_worker(rank, ws, port, tmp):
 def test_issue_mode_decision_is_shared_across_ranks():
     """GraphedPretextStep decides eager-or-graphs per configuration from a host-time measurement, and a capture can fail on one rank
     only; the two issue modes bucket the gradient all-reduce differently, so ranks that decided differently would wait for each
-    other's collectives forever.  Both decisions go through `_agree` (max of the host shares, min of the capture flags)."""
+    other's collectives forever.  Both decisions go through `_agree` (max of the host shares, min of the capture flags), and so does the size of the
+    backward pieces (min)."""
     from oracle.ref_harness import _free_port
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_agree_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
         a0, a1 = np.load(os.path.join(tmp, "agree0.npy")), np.load(os.path.join(tmp, "agree1.npy"))
-    assert a0.tolist() == a1.tolist() == [0.4, 0.0]
+    assert a0.tolist() == a1.tolist() == [0.4, 0.0, 0.0]
 
 
 def _chain_worker(rank, ws, port, tmp, broadcast_buffers=True, issue="eager"):
