@@ -31,7 +31,8 @@ def _build(arch, K, speeds=(2,)):
                                             ("s3dg", 4, 64, "whole"), ("r2plus1d-vcop", 4, 32, "lanes"),
                                             ("s3dg", 4, 64, "lanes+pieces"), ("resnet18", 8, 64, "lanes+pieces"), ("s3dg", 4, 64, "lanes+uncut")])
 def test_graphed_step_equals_eager_step(arch, B, HW, mode, monkeypatch):
-    """mode "lanes" (default): seven linear graphs, the three forward passes replayed side by side on three streams; "whole": one graph
+    """mode "lanes" (default): linear graphs only — the three forward passes replayed side by side on three streams, the backward in pieces
+    beside a weight-gradient lane when that lane is on a hardware queue of its own; "whole": one graph
     with the forks inside the capture (rounds 2-4); "lanes+pieces": the lanes with the backward cut into pieces of 30 plan nodes, the
     small weight gradients of each piece replayed as a graph of their own on the "w" lane beside the next piece (round 6)."""
     from rspnet_amd.graph_step import GraphedPretextStep

@@ -78,7 +78,7 @@ def test_rccl_one_rank_forced_collectives_match_the_fixture(arch):
 @pytest.mark.parametrize("arch,B,HW,mode", [("c3d", 4, 32, "lanes"), ("s3dg", 4, 64, "lanes"), ("s3dg", 4, 64, "segments")])
 def test_rccl_one_rank_segmented_replay_equals_the_eager_dp_step(arch, B, HW, mode):
     """The N > 1 issue mode that is not Python-bound: with the collectives on, GraphedPretextStep replays the
-    step as HIP graphs between its collective points (RCCL calls issued eagerly in between) — "lanes": seven linear graphs, the
+    step as HIP graphs between its collective points (RCCL calls issued eagerly in between) — "lanes": linear graphs, the
     three forward passes side by side on three streams; "segments": four graphs with the forks inside — bit-identical to the eager
     data-parallel loop over seven steps, two of them eager warm-ups.  The ORDER of the replayed step's collectives is checked by
     value: each gradient bucket is snapshot on the issuing stream when its all-reduce is issued and must equal the
