@@ -283,6 +283,27 @@ def main():
                 kept += 1
 
 
+def extra(arch, ws, seeds):
+    """``python -m oracle.gen_golden --extra s3dg 2 2,3``: ADDITIONAL candidate fixtures of one (family, world size) for the given
+    seeds, next to the ones on disk (same guard band, no screening: the caller decides which to keep — e.g. by how the HIP path
+    lands on them, which only a GPU box can tell)."""
+    index_path = os.path.join(GOLDEN, "index.json")
+    case = next(c for c in CASES if c[0] == arch)
+    _, B, HW, K, _, _ = case
+    spec0 = {k: (tuple(s_), d) for k, (s_, d) in reference_spec(arch, K).items()}
+    for seed in seeds:
+        index = json.load(open(index_path))
+        if [arch, ws, seed] in index:
+            continue
+        nudges, rep = guard_for(arch, spec0, B, HW, K, ws, seed)
+        out, spec = run_case(arch, B, HW, K, ws, seed, nudges)
+        relu = min(float(out[f"r{r}.relu_margin"]) for r in range(ws))
+        pool = min(float(out[f"r{r}.pool_margin"]) for r in range(ws))
+        print(f"{arch} ws{ws} seed {seed}: guard {rep}; reference: relu margin {relu:.2f} bands, pool gap {pool:.2e}", flush=True)
+        assert relu >= RELU_CHECK and rep["fp32_margin_in_bands"] >= RELU_CHECK
+        _write(arch, ws, seed, out, spec, index, index_path)
+
+
 def _write(arch, ws, seed, out, spec, index, index_path):
     name = case_name(arch, ws, seed)
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
@@ -298,5 +319,8 @@ def _write(arch, ws, seed, out, spec, index, index_path):
         json.dump(sorted(merged), f)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--extra":
+    extra(sys.argv[2], int(sys.argv[3]), [int(x) for x in sys.argv[4].split(",")])
+    sys.exit(0)
 if __name__ == "__main__":
     main()

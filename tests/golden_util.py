@@ -53,9 +53,12 @@ FWD_TOL_BY_ARCH = {"s3dg": 1e-3}
 # 1.2e-3 ... 1.2e-1 (median 1.4e-2) in the worst tensor over the 13 S3D-G seeds round 6 generated (profiles/r06/experiments_r6.txt), the
 # HIP path sits 5.3e-3 (1 rank: median tensor 2.0e-3, whole gradient 3.2e-3) / 6.6e-2 (2 ranks: median 2.0e-2, whole gradient 2.2e-2 —
 # a handful of flipped arg-maxes in the last two blocks, 32 positions per channel, shift the gradient of EVERY tensor upstream) from
-# the two committed fixtures.  The family's gate is therefore 1e-1 — the level round 5 gave ResNet-34 / -50, under ONE plan now; its
-# exact check is the teacher-forced replay of every op at 2e-5 (tests/test_teacher_forced_gpu.py).
-FAMILY_TOL_MIN = {"s3dg": 1e-1}
+# the two committed fixtures; 2.0e-2 / 2.1e-2 on the full-size step and the fine-tune fixture.  The family's gate is therefore 3e-2 at one
+# rank — everything measured there lies below 2.1e-2, and the kernels' summation orders are fixed, so the numbers do not move from run to
+# run — and 1e-1 for the 2-rank fixture (the level round 5 gave ResNet-34 / -50, under ONE plan now); the family's exact check is the
+# teacher-forced replay of every op at 2e-5 (tests/test_teacher_forced_gpu.py).
+FAMILY_TOL_MIN = {"s3dg": 3e-2}
+FIXTURE_TOL_MIN = {("s3dg", 2): 1e-1}
 
 
 def grad_tol(arch, ws=1):
@@ -67,7 +70,8 @@ def grad_tol(arch, ws=1):
     floor = CONDITIONING.get(arch, {}).get("grad_rel_l2_max", 0.0)
     if ws > 1:
         floor = max(floor, CONDITIONING.get(f"{arch}@ws{ws}", {}).get("grad_rel_l2_max", 0.0))
-    return max(GRAD_TOL_MIN, FAMILY_TOL_MIN.get(arch.split(":")[0], 0.0), 3.0 * floor)
+    fam = arch.split(":")[0]
+    return max(GRAD_TOL_MIN, FAMILY_TOL_MIN.get(fam, 0.0), FIXTURE_TOL_MIN.get((fam, ws), 0.0), 3.0 * floor)
 
 
 def checker_tol(arch, ws=1):
