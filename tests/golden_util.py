@@ -51,14 +51,18 @@ FWD_TOL_BY_ARCH = {"s3dg": 1e-3}
 # 4x4x4 stage ~100 windows per evaluation pair hold their top two within that drift, each routing its gradient to another position,
 # and a per-channel shift cannot separate two elements of one channel.  Measured: the oracle's own fp32 evaluation orders differ by
 # 1.2e-3 ... 1.2e-1 (median 1.4e-2) in the worst tensor over the 13 S3D-G seeds round 6 generated (profiles/r06/experiments_r6.txt), the
-# HIP path sits 5.3e-3 (1 rank: median tensor 2.0e-3, whole gradient 3.2e-3) / 6.6e-2 (2 ranks: median 2.0e-2, whole gradient 2.2e-2 —
+# HIP path sits 5.3e-3 (1 rank: median tensor 2.0e-3, whole gradient 3.2e-3) / 2.8e-2 (2 ranks: median 1.3e-2, whole gradient 1.8e-2 —
 # a handful of flipped arg-maxes in the last two blocks, 32 positions per channel, shift the gradient of EVERY tensor upstream) from
 # the two committed fixtures; 2.0e-2 / 2.1e-2 on the full-size step and the fine-tune fixture.  The family's gate is therefore 3e-2 at one
 # rank — everything measured there lies below 2.1e-2, and the kernels' summation orders are fixed, so the numbers do not move from run to
-# run — and 1e-1 for the 2-rank fixture (the level round 5 gave ResNet-34 / -50, under ONE plan now); the family's exact check is the
-# teacher-forced replay of every op at 2e-5 (tests/test_teacher_forced_gpu.py).
+# run.  The 2-rank fixture needs no minimum of its own: its generator screens seeds with the CPU checker at one rank only, the HIP path
+# landed at 6.6e-2 / 5.0e-2 / 2.8e-2 (worst tensor; whole gradient 2.2e-2 / 1.6e-2 / 1.8e-2) on seeds 1 / 2 / 3 (oracle/gen_golden.py
+# --extra), and seed 3 — the committed one — is the seed whose own floor says so: the oracle's fp32 run is 2.5e-2 from its fp64 run there
+# (conditioning.json `s3dg@ws2`), the HIP path 1.1 floors; the three-floor rule gives 7.4e-2.  (Seed 1: floor 5.3e-3, HIP 6.6e-2 — twelve
+# floors, which round 6 first covered with a hand-set 1e-1.)  The family's exact check is the teacher-forced replay of every op at 2e-5
+# (tests/test_teacher_forced_gpu.py).
 FAMILY_TOL_MIN = {"s3dg": 3e-2}
-FIXTURE_TOL_MIN = {("s3dg", 2): 1e-1}
+FIXTURE_TOL_MIN = {}
 
 
 def grad_tol(arch, ws=1):
