@@ -16,8 +16,12 @@ be = ops.backend()
 dev = torch.device("cuda", 0)
 B = 16
 # (name, T, HW, cin, [o0..o5])
-BLOCKS = [("3c", 8, 28, 256, [128, 128, 192, 32, 96, 64]), ("4c", 4, 14, 512, [160, 112, 224, 24, 64, 64]),
-          ("4f", 4, 14, 528, [256, 160, 320, 32, 128, 128]), ("5c", 2, 7, 832, [384, 192, 384, 48, 128, 128])]
+BLOCKS = [("3b", 8, 28, 192, [64, 96, 128, 16, 32, 32]), ("3c", 8, 28, 256, [128, 128, 192, 32, 96, 64]),
+          ("4b", 4, 14, 480, [192, 96, 208, 16, 48, 64]), ("4c", 4, 14, 512, [160, 112, 224, 24, 64, 64]),
+          ("4d", 4, 14, 512, [128, 128, 256, 24, 64, 64]), ("4e", 4, 14, 512, [112, 144, 288, 32, 64, 64]),
+          ("4f", 4, 14, 528, [256, 160, 320, 32, 128, 128]), ("5b", 2, 7, 832, [256, 160, 320, 32, 128, 128]),
+          ("5c", 2, 7, 832, [384, 192, 384, 48, 128, 128])]
+TOTAL = {"seq": 0.0, "lanes": 0.0}
 
 
 def unit(x, cin, cout, k, p):
@@ -91,5 +95,45 @@ for name, T, HW, cin, o in BLOCKS:
             fn()
         graphs.append(g)
     ga, gb = timeit(graphs[0].replay), timeit(graphs[1].replay)
+    # round 6: ... and the way the lanes schedule would run sibling branches — every branch a LINEAR graph of its own, replayed side by
+    # side on streams MEASURED to sit on hardware queues of their own (rspnet_amd/streams.py): the best case of "the siblings' launches
+    # grouped into one" (all their workgroups on the machine together, no fork bookkeeping inside a graph)
+    from rspnet_amd import streams as _st
+    lanes = _st.distinct(dev, 3)
+    bgraphs = []
+    for b in br:
+        def one(b=b):
+            h = x
+            for u in b:
+                h = u(h)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            one(); one()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one()
+        bgraphs.append(g)
+
+    def lanes_replay():
+        main = torch.cuda.current_stream(dev)
+        for s_ in lanes:
+            s_.wait_stream(main)
+        # the two separable branches and the pooled one on the side lanes, the pointwise branch on the main lane
+        for g, s_ in zip((bgraphs[1], bgraphs[2], bgraphs[3]), lanes):
+            with torch.cuda.stream(s_):
+                g.replay()
+        bgraphs[0].replay()
+        for s_ in lanes:
+            main.wait_stream(s_)
+    gl = timeit(lanes_replay)
+    per = [timeit(g.replay) for g in bgraphs]
+    TOTAL["seq"] += ga
+    TOTAL["lanes"] += gl
+    print(f"sepInc_{name}: branches alone {' / '.join(f'{t:.0f}' for t in per)} us; one linear graph {ga:7.1f} us, four linear graphs on four "
+          f"hardware queues {gl:7.1f} us (x{ga / gl:.2f}; longest branch {max(per):.0f} us)")
     print(f"sepInc_{name} ({T}x{HW}x{HW}, cin {cin}): eager one stream {a:7.1f} us, four streams {b_:7.1f} us (x{a / b_:.2f}) | "
           f"HIP graph one stream {ga:7.1f} us, four streams {gb:7.1f} us (x{ga / gb:.2f})", flush=True)
+print(f"all nine blocks, forward units of one pass: one linear graph {TOTAL['seq'] / 1e3:.2f} ms, branches side by side {TOTAL['lanes'] / 1e3:.2f} ms "
+      f"(-{(TOTAL['seq'] - TOTAL['lanes']) / 1e3:.2f} ms per pass if NOTHING else ran beside it; in the step the other two passes do)")
