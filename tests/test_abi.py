@@ -107,3 +107,22 @@ def test_tile_plan_option_changes_the_dispatch_not_the_interface():
         assert lib.rsp_conv3d_set_option(b"narrow32_max_units", -1) == 0 and lib.rsp_conv3d_set_option(b"tall_min_tiles", -1) == 768
     assert name(tiny).startswith("igemm_persist_kernel<128, 32,") and name(tall).startswith("igemm_persist_kernel<128, 64,")
     assert lib.rsp_conv3d_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.rsp_last_error()
+
+
+def test_no_memset_or_memcpy_nodes_in_the_step_kernels():
+    """Round 6: a hipMemsetAsync captured into a LINEAR HIP graph (rspnet_amd/graph_step.py, "lanes") was not reliably ordered against
+    the kernels around it on this stack — R3D-18's shortcut input gradients came out wrong in a few replays per hundred
+    (profiles/r06/experiments_r6.txt, r6race).  Everything a captured pretext step launches from this library is therefore a KERNEL: no
+    hipMemset* / hipMemcpy* in the sources of the step's ops (augment.hip is the data path: never captured)."""
+    import re
+    csrc = os.path.join(ROOT, "rspnet_amd", "csrc")
+    bad = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")) or name == "augment.hip":
+            continue
+        with open(os.path.join(csrc, name)) as f:
+            for i, line in enumerate(f, 1):
+                code = line.split("//")[0]
+                if re.search(r"\bhipMem(set|cpy)\w*\s*\(", code):
+                    bad.append((name, i, line.strip()))
+    assert not bad, bad
