@@ -224,3 +224,22 @@ def test_replayed_step_is_the_eager_step_at_measured_size(arch, B, HW, steps):
     out = r.stdout
     assert f"eager vs graph -> first difference: none in {steps} steps" in out, out[-1500:]
     assert f"graph vs graph (second run) -> first difference: none in {steps} steps" in out, out[-1500:]
+
+
+@pytest.mark.parametrize("arch,B,HW", [("resnet18", 8, 64), ("s3dg", 4, 64)])
+def test_replayed_step_holds_no_memset_or_memcpy_node(arch, B, HW):
+    """tools/graph_copy_nodes.py: torch.profiler over ONE replayed step.  The only copy activity of a replayed step is the eager upload of
+    its index vectors in front of the first graph (one hipMemcpyAsync); nothing inside the graphs is a memset or memcpy node — see
+    test_replayed_step_is_the_eager_step_at_measured_size for what such a node did."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_copy_nodes.py"), arch, str(B), str(HW)],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith(arch + " replayed step:")][-1]
+    assert "emset" not in line, line
+    copies = re.findall(r"'(hipMemcpy\w*)': (\d+)", line)
+    assert sum(int(n) for _, n in copies) <= 1, line
