@@ -37,3 +37,30 @@ def test_factory_train_and_validate_steps():
     want = (single[0] + single[1] + single[2]) / 3
     assert out["output"].shape == (meta["B"], meta["classes"])
     assert float((out["output"] - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "r2plus1d-vcop"])
+def test_finetune_backward_with_the_lane_running_ahead_changes_no_bit(arch, monkeypatch):
+    """The fine-tune backward runs through the same engine as the pretext step's: its weight gradients go to the task lane and, since
+    round 6, run ahead of the trunk (engine.BranchStreams.side_task).  Every weight gradient sent aside and none too big to run ahead,
+    against the join-before-every-task form: the same logits and parameter gradients, bit for bit."""
+    import finetune_util as F
+    from rspnet_amd.engine import BranchStreams
+    monkeypatch.setattr(BranchStreams, "SMALL_WGRAD_FLOPS", 1e18)
+    monkeypatch.setattr(BranchStreams, "AHEAD_MAX_FLOPS", 1e18)
+    z, meta, spec, state, x = F.load(arch)
+    dev = torch.device("cuda", 0)
+    out = []
+    for ahead in (True, False):
+        monkeypatch.setattr(BranchStreams, "RUN_AHEAD", ahead)
+        model = F.build_model(arch, meta["classes"], state, dev)
+        model.train()
+        logits = model(torch.from_numpy(x).to(dev))
+        loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(z["target"]).to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((logits.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = out
+    assert torch.equal(la, lb) and ga.keys() == gb.keys() and len(ga) > 10
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
